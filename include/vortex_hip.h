@@ -1,0 +1,206 @@
+/*
+ * include/vortex_hip.h -- C ABI of the MI355X-native ray-tracing hot path.
+ *
+ * Two levels, both exported by libvortex-hip.so (plain pointers and sizes, no torch types):
+ *
+ *  (1) DROP-IN DRIVER BOUNDARY.  `vx_dev_init(callbacks_t*)` is the one symbol the reference's
+ *      dispatcher resolves with dlsym after dlopen("libvortex-$VORTEX_DRIVER.so")
+ *      (reference runtime/stub/vortex.cpp:58-82).  It fills the 16 entry points declared in
+ *      reference runtime/common/callbacks.h:23-72; each one replaces the simx implementation in
+ *      reference runtime/simx/vortex.cpp + runtime/common/callbacks.inc (lines cited per member).
+ *      With VORTEX_DRIVER=hip the unmodified host code of tests/regression/raytracing keeps
+ *      calling vx_mem_alloc / vx_copy_to_dev / vx_dcr_write / vx_start / vx_ready_wait.
+ *
+ *  (2) DIRECT LAUNCH API `vxrt_*` for callers that already own device memory and a HIP stream
+ *      (bench.py, tests, embedding in another runtime).  `start` of level (1) is implemented on
+ *      top of it.  All pointers in vxrt_scene_t / rays / hits / dst are DEVICE pointers; `stream`
+ *      is a hipStream_t passed as void* (NULL = default stream).  Launches are asynchronous.
+ *
+ * Error convention of the reference (callbacks.inc): 0 = success, non-zero (-1) = failure; no
+ * exceptions cross this ABI.
+ */
+#ifndef VORTEX_HIP_H
+#define VORTEX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * (1) driver boundary -- mirrors reference runtime/include/vortex.h:27-28 and
+ *     runtime/common/callbacks.h:23-72 (same member order; the struct is filled positionally
+ *     by the backend and read by the dispatcher, so the order IS the ABI).
+ * ---------------------------------------------------------------------------------------- */
+typedef void* vx_device_h;
+typedef void* vx_buffer_h;
+
+typedef struct {
+  int (*dev_open)(vx_device_h* hdevice);                                   /* callbacks.inc:24-36 / simx vortex.cpp:49-78 */
+  int (*dev_close)(vx_device_h hdevice);                                   /* callbacks.inc:38-45 */
+  int (*dev_caps)(vx_device_h hdevice, uint32_t caps_id, uint64_t* value); /* callbacks.inc:47-58 / vortex.cpp:80-135 */
+  int (*mem_alloc)(vx_device_h hdevice, uint64_t size, int flags, vx_buffer_h* hbuffer);   /* callbacks.inc:60-78 / vortex.cpp:209-232 */
+  int (*mem_reserve)(vx_device_h hdevice, uint64_t address, uint64_t size, int flags, vx_buffer_h* hbuffer); /* :80-97 / :234-249 */
+  int (*mem_free)(vx_buffer_h hbuffer);                                    /* callbacks.inc:99-108 */
+  int (*mem_access)(vx_buffer_h hbuffer, uint64_t offset, uint64_t size, int flags);       /* :110-119 */
+  int (*mem_address)(vx_buffer_h hbuffer, uint64_t* address);              /* :121-128 */
+  int (*mem_info)(vx_device_h hdevice, uint64_t* mem_free, uint64_t* mem_used);            /* :130-146 */
+  int (*copy_to_dev)(vx_buffer_h hbuffer, const void* host_ptr, uint64_t dst_offset, uint64_t size);   /* :148-158 / vortex.cpp:276-304 */
+  int (*copy_from_dev)(void* host_ptr, vx_buffer_h hbuffer, uint64_t src_offset, uint64_t size);       /* :160-170 / vortex.cpp:306-327 */
+  int (*start)(vx_device_h hdevice, vx_buffer_h hkernel, vx_buffer_h harguments);          /* :172-180 / vortex.cpp:329-348 */
+  int (*ready_wait)(vx_device_h hdevice, uint64_t timeout);                /* :182-188 / vortex.cpp:350-364 */
+  int (*dcr_read)(vx_device_h hdevice, uint32_t addr, uint32_t* value);    /* :190-201 / vortex.cpp:375-377 */
+  int (*dcr_write)(vx_device_h hdevice, uint32_t addr, uint32_t value);    /* :203-209 / vortex.cpp:366-373 */
+  int (*mpm_query)(vx_device_h hdevice, uint32_t addr, uint32_t core_id, uint64_t* value); /* :211-222 / vortex.cpp:379-391 */
+} callbacks_t;
+
+/* The plug-in entry (callbacks.inc:20). */
+int vx_dev_init(callbacks_t* callbacks);
+
+/* caps ids (vortex.h:31-45) */
+#define VX_CAPS_VERSION 0x0
+#define VX_CAPS_NUM_THREADS 0x1
+#define VX_CAPS_NUM_WARPS 0x2
+#define VX_CAPS_NUM_CORES 0x3
+#define VX_CAPS_CACHE_LINE_SIZE 0x4
+#define VX_CAPS_GLOBAL_MEM_SIZE 0x5
+#define VX_CAPS_LOCAL_MEM_SIZE 0x6
+#define VX_CAPS_ISA_FLAGS 0x7
+#define VX_CAPS_NUM_MEM_BANKS 0x8
+#define VX_CAPS_MEM_BANK_SIZE 0x9
+#define VX_CAPS_NUM_CLUSTERS 0xA
+#define VX_CAPS_SOCKET_SIZE 0xB
+#define VX_CAPS_ISSUE_WIDTH 0xC
+#define VX_CAPS_CLOCK_RATE 0xD
+#define VX_CAPS_PEAK_MEM_BW 0xE
+
+#define VX_MEM_READ 0x1
+#define VX_MEM_WRITE 0x2
+#define VX_MEM_READ_WRITE 0x3
+#define VX_MAX_TIMEOUT (24 * 60 * 60 * 1000)
+
+/* DCR ids the RTU path uses (hw/VX_types.toml:16-19; written by tracer.cpp:252-256). */
+#define VX_DCR_BASE_STARTUP_ADDR0 0x001
+#define VX_DCR_BASE_STARTUP_ADDR1 0x002
+#define VX_DCR_BASE_STARTUP_ARG0 0x003
+#define VX_DCR_BASE_STARTUP_ARG1 0x004
+#define VX_DCR_BASE_MPM_CLASS 0x005
+#define VX_DCR_BASE_RTX_TLAS_PTR 0x006
+#define VX_DCR_BASE_RTX_BLAS_PTR 0x007
+#define VX_DCR_BASE_RTX_BVH_PTR 0x008
+#define VX_DCR_BASE_RTX_TRI_PTR 0x009
+/* Backend extension (no reference counterpart): framebuffer row window rendered by this device,
+ * for sharding one frame over several GPUs/processes.  [begin,end); end==0 means dst_height. */
+#define VX_DCR_HIP_ROW_BEGIN 0x7F0
+#define VX_DCR_HIP_ROW_END 0x7F1
+/* Backend extension: 0 = closest-hit only (reference behaviour), 1 = +1 shadow ray toward light_pos. */
+#define VX_DCR_HIP_SHADOW_RAYS 0x7F2
+
+/* CSRs answered by mpm_query (read by vx_dump_perf at vx_dev_close: stub/perf.cpp:195-227). */
+#define VX_CSR_MPM_BASE 0xB00
+#define VX_CSR_MCYCLE 0xB00
+#define VX_CSR_MINSTRET 0xB02
+
+/* kernel_arg_t of the RTU test (tests/regression/raytracing/common.h:164-195): 216 bytes.  This
+ * is what the host uploads with vx_upload_bytes and what `start` decodes. */
+typedef struct {
+  uint32_t dst_width;
+  uint32_t dst_height;
+  uint64_t dst_addr;
+  uint64_t tri_addr;
+  uint64_t triEx_addr;
+  uint64_t triIdx_addr;
+  uint64_t mat_addr;
+  uint64_t tex_addr;
+  uint64_t bvh_addr;
+  uint64_t qBvh_addr;
+  uint64_t blas_addr;
+  uint64_t tlas_addr;
+  uint32_t tlas_root;
+  float camera_pos[3];
+  float camera_forward[3];
+  float camera_right[3];
+  float camera_up[3];
+  float viewplane[2];
+  uint32_t samples_per_pixel;
+  uint32_t max_depth;
+  float light_pos[3];
+  float light_color[3];
+  float ambient_color[3];
+  float background_color[3];
+  uint64_t sbt_addr;
+} vx_rt_kernel_arg_t;
+
+/* ------------------------------------------------------------------------------------------
+ * (2) direct launch API
+ * ---------------------------------------------------------------------------------------- */
+
+/* Device-resident scene in the reference's own buffer formats:
+ *   tlas, bvh : bvh_quantized_node_t[]  52 B   (common.h:52-67 == sim rt_traversal.h:14-33)
+ *   blas      : blas_node_t[]          160 B   (common.h:86-99)
+ *   tri       : tri_t[]                 36 B   (geometry.h:1401-1405)
+ *   triEx     : tri_ex_t[]              64 B   (common.h:39-43)
+ *   mat       : material_info_t[]       88 B   (common.h:20-36)
+ *   tex       : 0x00RRGGBB u32 texels, concatenated (surface.cpp:28-55)
+ * Counts are element counts and are used for host-side shape checks before every launch. */
+typedef struct {
+  const void* tlas;
+  const void* blas;
+  const void* bvh;
+  const void* tri;
+  const void* triEx;
+  const void* mat;
+  const void* tex;
+  uint32_t n_tlas_nodes;
+  uint32_t n_blas;
+  uint32_t n_bvh_nodes;
+  uint32_t n_tris;
+  uint32_t n_mats;
+  uint32_t reserved;
+  uint64_t tex_bytes;
+} vxrt_scene_t;
+
+/* Hit record: the 6 RTU hit attributes (VX_RT_HIT_DIST..TRI_IDX, hw/VX_types.toml:270-285;
+ * sim rt_traversal.h:48-52).  dist == 1e30f means miss. */
+typedef struct {
+  float dist, bx, by, bz;
+  uint32_t blasIdx, triIdx;
+} vxrt_hit_t;
+
+typedef struct {
+  float ambient[3], light_color[3], light_pos[3], background[3];
+  uint32_t max_depth;
+} vxrt_shade_params_t;
+
+#define VXRT_MODE_CLOSEST 0 /* reference semantics: global closest hit, reference tie order */
+#define VXRT_MODE_ANY 1     /* occlusion: stop at first accepted candidate (extension) */
+
+/* Render rows [y0,y1) of the RTU test's frame: camera ray (kernel.cpp:28-39) -> closest hit ->
+ * closest/miss shade -> RGB8 pack -> dst[x + y*W] (kernel.cpp:95-106).  `dst` points at pixel
+ * (0,0) of the full W x H frame.  shadow != 0 adds one occlusion ray per hit (extension).
+ * rays_traced (device u64, may be NULL) is atomically incremented by the number of rays traced. */
+int vxrt_render(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
+                vxrt_hit_t* hits /* optional, W*H */, float* colors /* optional, 3*W*H */,
+                unsigned long long* rays_traced, void* stream);
+
+/* Trace n rays (6 floats each: origin, direction) read from HBM, write n hit records.
+ * tmax: optional per-ray upper bound (NULL = 1e30). */
+int vxrt_trace(const vxrt_scene_t* scene, const float* rays, uint64_t n, const float* tmax,
+               vxrt_hit_t* hits, int mode, void* stream);
+
+/* Status word of the last launches on this device: 0 = ok, bit0 = traversal stack overflow
+ * (tree deeper than the 32 levels the reference's own trail supports).  Synchronises `stream`. */
+int vxrt_status(void* stream, uint32_t* status);
+
+/* Raw device pointer behind a vx_buffer_h of the hip backend (for zero-copy hand-off to RCCL). */
+int vx_hip_buffer_device_ptr(vx_buffer_h hbuffer, void** dev_ptr);
+
+const char* vxrt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VORTEX_HIP_H */

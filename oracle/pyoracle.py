@@ -1,0 +1,238 @@
+"""ctypes loader of the checker libraries.  TEST INFRASTRUCTURE ONLY (see oracle/README.md)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "librt_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libvxref.so")
+
+HIT_DTYPE = np.dtype([("dist", "<f4"), ("bx", "<f4"), ("by", "<f4"), ("bz", "<f4"), ("blasIdx", "<u4"), ("triIdx", "<u4")])
+assert HIT_DTYPE.itemsize == 24
+
+STAT_FIELDS = ("node_reads", "inst_reads", "tri_reads", "accepts", "restarts", "stale_base", "trail_overflow", "abandon", "oob", "max_stack")
+
+
+class OrcStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in STAT_FIELDS]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in STAT_FIELDS}
+
+
+class RefStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("node_reads", "inst_reads", "tri_reads", "bytes", "accepts", "oob")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class ShadeParams(C.Structure):
+    _fields_ = [("ambient", C.c_float * 3), ("light_color", C.c_float * 3), ("light_pos", C.c_float * 3),
+                ("background", C.c_float * 3), ("max_depth", C.c_uint32)]
+
+
+def shade_params(ambient=(0.4, 0.4, 0.4), light_color=(1, 1, 1), light_pos=(0, 10, -10), background=(0.4, 0.35, 0.25), max_depth=1):
+    p = ShadeParams()
+    p.ambient[:] = ambient
+    p.light_color[:] = light_color
+    p.light_pos[:] = light_pos
+    p.background[:] = background
+    p.max_depth = max_depth
+    return p
+
+
+_orc = None
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def orc():
+    global _orc
+    if _orc is None:
+        if not os.path.exists(ORACLE_SO):
+            from . import build as _b
+            _b.build()
+        L = C.CDLL(ORACLE_SO)
+        vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+        L.orc_trace_faithful.restype = C.c_int
+        L.orc_trace_faithful.argtypes = [vp, u64, u32, u32, u32, u32, vp, u64, vp, vp, C.POINTER(OrcStats), C.c_int]
+        L.orc_trace_canonical.restype = C.c_int
+        L.orc_trace_canonical.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp, C.POINTER(OrcStats), C.c_int]
+        L.orc_generate_ray.argtypes = [u32, u32, u32, u32, vp]
+        L.orc_shade.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(ShadeParams), vp]
+        L.orc_pack_rgb8.restype = u32
+        L.orc_pack_rgb8.argtypes = [vp]
+        L.orc_render.restype = C.c_int
+        L.orc_render.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ShadeParams), vp, vp, vp]
+        L.orc_ray_box.restype = C.c_float
+        L.orc_ray_box.argtypes = [vp] + [C.c_float] * 6
+        _orc = L
+    return _orc
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(REF_SO)
+        vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+        L.vxref_trace.restype = C.c_int
+        L.vxref_trace.argtypes = [vp, u64, u32, u32, u32, u32, vp, u64, vp, C.POINTER(RefStats), C.c_int]
+        L.vxref_scene_create.restype = vp
+        L.vxref_scene_create.argtypes = [C.POINTER(C.c_char_p), C.c_int]
+        L.vxref_scene_destroy.argtypes = [vp]
+        L.vxref_scene_buffer.restype = u64
+        L.vxref_scene_buffer.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.vxref_sizeof.restype = u32
+        L.vxref_generate_ray.argtypes = [u32, u32, u32, u32, vp]
+        L.vxref_shade.restype = u32
+        L.vxref_shade.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, u32, u32, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        _ref = L
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Image:
+    """Flat device-memory image + the four 32-bit DCR offsets (tracer.cpp:252-256), 64-byte aligned."""
+
+    def __init__(self, scene):
+        off = 64
+        self.off = {}
+        parts = []
+        for k in ("tlas", "blas", "bvh", "tri"):
+            b = np.ascontiguousarray(scene[k], np.uint8)
+            self.off[k] = off
+            parts.append((off, b))
+            off = (off + b.size + 63) & ~63
+        self.mem = np.zeros(off + 64, np.uint8)
+        for o, b in parts:
+            self.mem[o:o + b.size] = b
+
+
+def trace_faithful(scene, rays, tmax=None, any_hit=False):
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    img = scene if isinstance(scene, Image) else Image(scene)
+    out = np.zeros(len(rays), HIT_DTYPE)
+    st = OrcStats()
+    tm = np.ascontiguousarray(tmax, np.float32) if tmax is not None else None
+    orc().orc_trace_faithful(_p(img.mem), img.mem.size, img.off["tlas"], img.off["blas"], img.off["bvh"], img.off["tri"],
+                             _p(rays), len(rays), _p(tm), _p(out), C.byref(st), int(any_hit))
+    return out, st.as_dict()
+
+
+def stale_base_mask(scene, rays):
+    """Per-ray flag: the reference expanded a TLAS internal node with a stale (BLAS) base_ptr for
+    this ray (rt_traversal.cpp:91-92 after :119; see DESIGN.md 'reference quirks').  Such rays read
+    unrelated memory in the reference and are outside the parity domain."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    img = scene if isinstance(scene, Image) else Image(scene)
+    mask = np.zeros(len(rays), bool)
+    for i in range(len(rays)):
+        _, st = trace_faithful(img, rays[i:i + 1])
+        mask[i] = st["stale_base"] != 0
+    return mask
+
+
+def trace_canonical(scene, rays, tmax=None, any_hit=False):
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    out = np.zeros(len(rays), HIT_DTYPE)
+    st = OrcStats()
+    tm = np.ascontiguousarray(tmax, np.float32) if tmax is not None else None
+    b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("tlas", "blas", "bvh", "tri")}
+    orc().orc_trace_canonical(_p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(rays), len(rays), _p(tm), _p(out),
+                              C.byref(st), int(any_hit))
+    return out, st.as_dict()
+
+
+def trace_ref(scene, rays, any_hit=False):
+    """The reference's own BVHTraverser (oracle/_ref)."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    img = scene if isinstance(scene, Image) else Image(scene)
+    out = np.zeros(len(rays), HIT_DTYPE)
+    st = RefStats()
+    ref().vxref_trace(_p(img.mem), img.mem.size, img.off["tlas"], img.off["blas"], img.off["bvh"], img.off["tri"],
+                      _p(rays), len(rays), _p(out), C.byref(st), int(any_hit))
+    return out, st.as_dict()
+
+
+def camera_rays(w, h, y0=0, y1=None):
+    y1 = h if y1 is None else y1
+    out = np.zeros(((y1 - y0) * w, 6), np.float32)
+    L = orc()
+    tmp = (C.c_float * 6)()
+    i = 0
+    for y in range(y0, y1):
+        for x in range(w):
+            L.orc_generate_ray(x, y, w, h, tmp)
+            out[i] = tmp[:]
+            i += 1
+    return out
+
+
+def render(scene, w, h, params=None, y0=0, y1=None):
+    """Whole RTU-test frame on the CPU restatement: pixels (h,w) u32, hits, colours."""
+    y1 = h if y1 is None else y1
+    params = params or shade_params()
+    px = np.zeros((h, w), np.uint32)
+    hits = np.zeros(h * w, HIT_DTYPE)
+    col = np.zeros((h * w, 3), np.float32)
+    b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")}
+    orc().orc_render(w, h, y0, y1, _p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(b["triEx"]), _p(b["mat"]),
+                     _p(b["tex"]), C.byref(params), _p(px), _p(hits), _p(col))
+    return px, hits.reshape(h, w), col.reshape(h, w, 3)
+
+
+def shade(scene, rays, hits, params=None):
+    params = params or shade_params()
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    hits = np.ascontiguousarray(hits)
+    b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("blas", "triEx", "mat", "tex")}
+    col = np.zeros((len(rays), 3), np.float32)
+    L = orc()
+    for i in range(len(rays)):
+        L.orc_shade(rays[i].ctypes.data, hits[i:i + 1].ctypes.data, _p(b["blas"]), _p(b["triEx"]), _p(b["mat"]), _p(b["tex"]),
+                    C.byref(params), col[i].ctypes.data)
+    px = np.array([L.orc_pack_rgb8(col[i].ctypes.data) for i in range(len(rays))], np.uint32)
+    return col, px
+
+
+def ref_scene(obj_paths):
+    """Run the reference's own scene builder on OBJ files; returns dict of byte buffers."""
+    L = ref()
+    arr = (C.c_char_p * len(obj_paths))(*[str(p).encode() for p in obj_paths])
+    h = L.vxref_scene_create(arr, len(obj_paths))
+    if not h:
+        raise RuntimeError("reference scene builder failed")
+    try:
+        out = {}
+        for i, k in enumerate(("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")):
+            p = C.c_void_p()
+            n = L.vxref_scene_buffer(h, i, C.byref(p))
+            out[k] = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy() if n else np.zeros(0, np.uint8)
+        return out
+    finally:
+        L.vxref_scene_destroy(h)
+
+
+def ref_shade(scene, rays, hits, params=None):
+    params = params or shade_params()
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("blas", "triEx", "mat", "tex")}
+    L = ref()
+    col = np.zeros((len(rays), 3), np.float32)
+    px = np.zeros(len(rays), np.uint32)
+    for i in range(len(rays)):
+        hh = hits[i]
+        px[i] = L.vxref_shade(rays[i].ctypes.data, float(hh["dist"]), float(hh["bx"]), float(hh["by"]), float(hh["bz"]),
+                              int(hh["blasIdx"]), int(hh["triIdx"]), int(hh["dist"] != np.float32(1e30)),
+                              _p(b["blas"]), _p(b["triEx"]), _p(b["mat"]), _p(b["tex"]),
+                              C.cast(params.ambient, C.c_void_p), C.cast(params.light_color, C.c_void_p),
+                              C.cast(params.light_pos, C.c_void_p), C.cast(params.background, C.c_void_p), col[i].ctypes.data)
+    return col, px

@@ -1,0 +1,119 @@
+"""GPU: the drop-in boundary.  The host-side mirror of the reference Tracer drives the HIP backend
+through vx_dev_open / vx_mem_alloc / vx_copy_to_dev / vx_dcr_write / vx_start / vx_ready_wait only
+(the calls of tests/regression/raytracing/tracer.cpp:114-166,217-259,272-281)."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rtu_test_frame_through_vx_api(vrt, po, gpu_device):
+    sc = vrt.scene.procedural("blob", 4, 0, 1)
+    w, h = 192, 136
+    tr = vrt.tracer.Tracer(w, h)
+    tr.init(sc)
+    tr.setup()
+    px = tr.run()
+    rpx, rhits, _ = po.render(sc, w, h)
+    assert np.array_equal(px, rpx)
+    # perf counters the reference dumps at close (stub/perf.cpp:195-227): rays and cycles of the run
+    assert tr.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0) == w * h
+    assert tr.dev.mpm_query(vrt.runtime.VX_CSR_MCYCLE, 0) > 0
+    assert tr.dev.caps(vrt.runtime.VX_CAPS_NUM_THREADS) == 64
+    assert tr.dev.caps(vrt.runtime.VX_CAPS_NUM_CORES) >= 1
+    # second run on the same device, different light: start waits for the previous run (vortex.cpp:331-333)
+    tr.setup(light_pos=(100.0, 300.0, 50.0))
+    px2 = tr.run()
+    rpx2, _, _ = po.render(sc, w, h, po.shade_params(light_pos=(100.0, 300.0, 50.0)))
+    assert np.array_equal(px2, rpx2)
+    assert not np.array_equal(px, px2)
+    tr.close()
+
+
+def test_row_window_dcrs_shard_a_frame(vrt, po, gpu_device):
+    """Backend extension DCRs 0x7F0/0x7F1: each 'rank' renders its row band; bands tile the frame."""
+    sc = vrt.scene.procedural("cornell")
+    w, h = 80, 64
+    rpx, _, _ = po.render(sc, w, h)
+    frame = np.zeros((h, w), np.uint32)
+    tr = vrt.tracer.Tracer(w, h)
+    tr.init(sc)
+    for (y0, y1) in vrt.sharding.row_bands(h, 3):
+        tr.setup(row_window=(y0, y1))
+        band = tr.run()
+        frame[y0:y1] = band[y0:y1]
+    tr.close()
+    assert np.array_equal(frame, rpx)
+
+
+def test_error_behaviour_of_the_boundary(vrt, gpu_device):
+    rt = vrt.runtime
+    L = rt.lib()
+    d = rt.Device()
+    b = C.c_void_p()
+    assert L.vx_mem_alloc(d.handle, 0, rt.VX_MEM_READ, C.byref(b)) != 0          # callbacks.inc:61-65
+    assert L.vx_mem_alloc(None, 64, rt.VX_MEM_READ, C.byref(b)) != 0
+    assert L.vx_mem_free(None) == 0                                                # callbacks.inc:100-102
+    buf = d.mem_alloc(100)
+    data = (C.c_uint8 * 128)()
+    assert L.vx_copy_to_dev(buf.handle, data, 0, 101) != 0                         # bounds (callbacks.inc:153)
+    assert L.vx_copy_to_dev(buf.handle, data, 64, 64) != 0
+    assert L.vx_copy_to_dev(buf.handle, data, 36, 64) == 0
+    assert L.vx_copy_from_dev(data, buf.handle, 90, 11) != 0
+    assert L.vx_copy_to_dev(buf.handle, None, 0, 4) != 0
+    v = C.c_uint32()
+    assert L.vx_dcr_read(d.handle, 0x123, C.byref(v)) != 0                         # unwritten DCR (common.h:60-66)
+    d.dcr_write(0x123, 77)
+    assert d.dcr_read(0x123) == 77
+    assert L.vx_ready_wait(d.handle, 10) == 0                                      # nothing running
+    # addresses follow the simx allocator convention: 64-byte blocks from USER_BASE_ADDR
+    b2 = d.mem_alloc(1)
+    assert buf.address >= 0x10000 and buf.address % 64 == 0 and b2.address % 64 == 0 and b2.address != buf.address
+    # a RISC-V image cannot be started: start must fail loudly, not fall back to anything
+    blob = struct.pack("<QQ", 0x80000000, 0x80001000) + b"\x13\x00\x00\x00" * 16
+    k = C.c_void_p()
+    assert L.vx_upload_kernel_bytes(d.handle, blob, len(blob), C.byref(k)) == 0
+    args = d.upload_bytes(bytes(216))
+    assert L.vx_start(d.handle, k, args.handle) != 0
+    # reserved range cannot be reserved twice
+    k2 = C.c_void_p()
+    assert L.vx_upload_kernel_bytes(d.handle, blob, len(blob), C.byref(k2)) != 0
+    for h in (buf, b2, args):
+        h.free()
+    assert L.vx_mem_free(k) == 0
+    d.close()
+
+
+def test_missing_dcrs_or_wrong_sbt_fail(vrt, gpu_device):
+    sc = vrt.scene.procedural("cornell")
+    tr = vrt.tracer.Tracer(32, 32)
+    tr.init(sc)
+    tr.setup()
+    # corrupt the shader binding table: closest-hit entry points at the miss selector
+    tr.bufs["sbt"].write(struct.pack("<4Q", tr.miss.address, tr.miss.address, 0, tr.anyhit.address))
+    with pytest.raises(vrt.runtime.VxError):
+        tr.run()
+    tr.setup(background=(0.1, 0.2, 0.3))
+    assert tr.run().shape == (32, 32)
+    tr.close()
+
+
+def test_host_program_renders_and_matches(vrt, po, gpu_device, tmp_path):
+    """The C++ host program (csrc/rt_host.cpp), same CLI as the reference's main.cpp, end to end."""
+    import subprocess
+    exe = os.path.join(vrt.LIB_DIR, "rt_host")
+    if not os.path.exists(exe):
+        pytest.skip("rt_host not built")
+    out = tmp_path / "out.ppm"
+    env = dict(os.environ, LD_LIBRARY_PATH=vrt.LIB_DIR + ":" + os.environ.get("LD_LIBRARY_PATH", ""), VORTEX_DRIVER="hip")
+    r = subprocess.run([exe, "-m", "proc:cornell", "-w", "48", "-h", "40", "-o", str(out), "-k", os.path.join(vrt.VXBIN_DIR, "kernel.vxbin")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    vals = np.array(out.read_text().split()[4:], dtype=np.int64).reshape(40, 48, 3)
+    rpx, _, _ = po.render(vrt.scene.procedural("cornell"), 48, 40)
+    want = np.stack([(rpx >> 16) & 255, (rpx >> 8) & 255, rpx & 255], -1)[::-1]
+    assert np.array_equal(vals, want)

@@ -1,0 +1,109 @@
+"""CPU: the oracle restatement against the committed fixtures produced by the reference's own object
+code (oracle/gen_golden.py).  This is what pins the oracle when /root/reference is absent."""
+import numpy as np
+import pytest
+
+SCENES = ["teapot", "torus", "sphere", "cone", "cylinder", "cube", "teapot_x3", "sphere_x6"]
+# TLAS deeper than one level: the reference traverser addresses the children of a TLAS internal node
+# popped from its short stack relative to the last BLAS's base (rt_traversal.cpp:91-92 vs :119-120),
+# reads unrelated nodes and loses real hits.  The faithful restatement reproduces that bit for bit;
+# the canonical algorithm (and the HIP kernels) address TLAS children from the TLAS base.  Rays that
+# trip the quirk are excluded from canonical-vs-reference comparison and counted instead.
+QUIRK_SCENES = {"sphere_x6"}
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_faithful_restatement_matches_reference_hits(po, golden, name):
+    g = golden(name)
+    hits, st = po.trace_faithful(g, g["rays"])
+    assert np.array_equal(_bits(hits), _bits(g["hits"])), "closest-hit records differ from the reference traverser"
+    # the restatement follows the reference node for node: same number of node / triangle fetches
+    assert st["node_reads"] == int(g["ref_node_reads"])
+    assert st["tri_reads"] == int(g["ref_tri_reads"])
+    assert st["trail_overflow"] == 0 and st["oob"] == 0
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_canonical_algorithm_matches_reference_hits(po, golden, name):
+    """The single-pass full-stack algorithm the HIP kernels implement returns the reference's hit
+    (distance bits, barycentrics, blasIdx, triIdx), exact-distance ties included."""
+    g = golden(name)
+    hits, st = po.trace_canonical(g, g["rays"])
+    ok = ~po.stale_base_mask(g, g["rays"]) if name in QUIRK_SCENES else np.ones(len(hits), bool)
+    assert np.array_equal(_bits(hits[ok]), _bits(g["hits"][ok]))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_any_hit_first_matches_reference(po, golden, name):
+    g = golden(name)
+    f, _ = po.trace_faithful(g, g["rays"], any_hit=True)
+    c, _ = po.trace_canonical(g, g["rays"], any_hit=True)
+    assert np.array_equal(_bits(f), _bits(g["anyhits"]))
+    ok = ~po.stale_base_mask(g, g["rays"]) if name in QUIRK_SCENES else np.ones(len(c), bool)
+    assert np.array_equal(_bits(c[ok]), _bits(g["anyhits"][ok]))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_shading_matches_reference_helpers(po, golden, name):
+    g = golden(name)
+    col, px = po.shade(g, g["rays"], g["hits"])
+    assert np.array_equal(_bits(col), _bits(g["colors"])), "f32 radiance differs from closest.cpp/rtx_shading.h"
+    assert np.array_equal(px, g["rgb8"])
+
+
+def test_camera_rays_match_reference_kernel(po, golden):
+    rows = golden("camera_rays")["rows"]
+    import ctypes as C
+    L = po.orc()
+    tmp = (C.c_float * 6)()
+    for x, y, w, h, *bits in rows[:: max(1, len(rows) // 1500)]:
+        L.orc_generate_ray(int(x), int(y), int(w), int(h), tmp)
+        got = np.array(tmp[:], np.float32).view(np.uint32)
+        assert np.array_equal(got, np.array(bits, np.uint32)), (x, y, w, h)
+
+
+def test_exact_distance_ties_are_present_and_resolved_like_the_reference(po, golden):
+    """on the cube two triangles of one face report bit-identical distances; the winner
+    is decided by traversal order, not by lowest index.  Count the ties so they are never silently
+    tolerated."""
+    g = golden("cube")
+    tri = g["tri"].view(np.float32).reshape(-1, 9)
+    import ctypes as C
+    L = po.orc()
+    L.orc_ray_tri.restype = C.c_float
+    L.orc_ray_tri.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    ties = 0
+    differs_from_lowest_index = 0
+    for r, h in zip(g["rays"], g["hits"]):
+        if h["dist"] >= 1e29:
+            continue
+        same = []
+        for t in range(len(tri)):
+            b = (C.c_float * 3)()
+            d = L.orc_ray_tri(r.ctypes.data, tri[t].ctypes.data, C.byref(b, 0), C.byref(b, 4), C.byref(b, 8))
+            if np.float32(d) == h["dist"]:
+                same.append(t)
+        assert int(h["triIdx"]) in same
+        if len(same) > 1:
+            ties += 1
+            differs_from_lowest_index += int(h["triIdx"]) != same[0]
+    assert ties > 0, "fixture no longer exercises exact-distance ties"
+    print("cube fixture: %d tie rays, %d resolved differently from lowest-index" % (ties, differs_from_lowest_index))
+
+
+def test_stale_base_quirk_is_confined_to_deep_tlas(po, golden):
+    """One-level TLAS (<= 4 instances under the root) never trips the quirk; the 6-instance fixture
+    does, and there the reference loses hits that exist (brute force over all instances finds them)."""
+    _, st = po.trace_faithful(golden("teapot_x3"), golden("teapot_x3")["rays"])
+    assert st["stale_base"] == 0
+    g = golden("sphere_x6")
+    mask = po.stale_base_mask(g, g["rays"])
+    assert mask.any()
+    c, _ = po.trace_canonical(g, g["rays"])
+    lost = (g["hits"]["dist"][mask] >= 1e29) & (c["dist"][mask] < 1e29)
+    print("sphere_x6: %d rays trip the quirk, reference loses a real hit on %d of them" % (mask.sum(), lost.sum()))
+    assert (c["dist"][mask] <= g["hits"]["dist"][mask]).all()

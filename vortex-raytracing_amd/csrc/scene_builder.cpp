@@ -1,0 +1,828 @@
+// libvxrt_scene.so -- host-side producer of the buffers the ray-tracing hot path reads.
+//
+// Role of reference tests/regression/raytracing/{scene,bvh}.cpp: per mesh a 4-wide binned-SAH BVH
+// (8 bins, greedy widening by best SAH gain, triangles reordered in place so leaves index them
+// directly), power-of-two 8-bit child-box quantisation, an instance record per mesh and a TLAS.
+// It is a from-scratch builder, not a restatement: the reference widens clusters using split
+// children whose bounds are never initialised (bvh.cpp:79-86 -> findBestSplitPlane reads
+// centroidMin/Max of L and R), so its tree shape is not reproducible; this builder computes those
+// bounds and additionally makes quantisation provably conservative.  Output FORMATS are the
+// reference's byte for byte (rt_types.h) - that is what the kernels and the oracle consume.
+//
+// Also holds the deterministic procedural scenes of SURVEY.md s8d (none of Sponza/bunny/hairball
+// exist offline) and a minimal OBJ/MTL reader for the reference's own small assets.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+#include "rt_types.h"
+
+namespace {
+
+struct V3 { float x, y, z; };
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 vmin(V3 a, V3 b) { return {a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z}; }
+inline V3 vmax(V3 a, V3 b) { return {a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z}; }
+inline float comp(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 normalize(V3 v) { float l = std::sqrt(dot(v, v)); return l > 0 ? v * (1.0f / l) : V3{0, 1, 0}; }
+
+constexpr float kBig = RT_LARGE_FLOAT;
+constexpr int kBins = 8;   // bvh.cpp:8
+
+struct Box {
+  V3 lo{kBig, kBig, kBig}, hi{-kBig, -kBig, -kBig};
+  void grow(V3 p) { lo = vmin(lo, p); hi = vmax(hi, p); }
+  void grow(const Box& b) { if (b.lo.x != kBig) { grow(b.lo); grow(b.hi); } }
+  float half_area() const { V3 e = hi - lo; return e.x * e.y + e.y * e.z + e.z * e.x; }
+};
+
+struct WideNode {           // float-box node before quantisation (role of bvh_node_t, common.h:70-83)
+  Box box, cbox;
+  uint32_t leftFirst = 0, triCount = 0, childCount = 0;
+};
+
+struct Mesh {
+  std::vector<rt_tri_t> tri;
+  std::vector<rt_triex_t> triEx;
+  std::vector<rt_material_t> mats;
+  std::vector<std::vector<uint32_t>> textures;  // 0x00RRGGBB texels
+  std::vector<std::pair<uint32_t, uint32_t>> tex_dims;
+  float transform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+};
+
+inline V3 tv(const float* p) { return {p[0], p[1], p[2]}; }
+
+// ---------------------------------------------------------------------------------------------
+// BLAS builder
+// ---------------------------------------------------------------------------------------------
+class BlasBuilder {
+public:
+  BlasBuilder(rt_tri_t* tri, rt_triex_t* triEx, uint32_t n) : tri_(tri), triEx_(triEx), n_(n) {
+    cent_.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      V3 s = tv(tri[i].v0) + tv(tri[i].v1) + tv(tri[i].v2);
+      cent_[i] = {s.x / 3, s.y / 3, s.z / 3};     // scene.cpp:87
+    }
+    nodes_.reserve(2 * (size_t)n + 1);
+    nodes_.emplace_back();
+    nodes_[0].leftFirst = 0;
+    nodes_[0].triCount = n;
+    subdivide(0, 0);
+  }
+  std::vector<WideNode> nodes_;
+  uint32_t max_depth_ = 0;
+
+private:
+  struct Split { int axis = -1; int pos = 0; float cost = INFINITY; };
+
+  void bounds(WideNode& nd) const {
+    nd.box = Box(); nd.cbox = Box();
+    for (uint32_t i = 0; i < nd.triCount; ++i) {
+      const rt_tri_t& t = tri_[nd.leftFirst + i];
+      nd.box.grow(tv(t.v0)); nd.box.grow(tv(t.v1)); nd.box.grow(tv(t.v2));
+      nd.cbox.grow(cent_[nd.leftFirst + i]);
+    }
+  }
+
+  int bin_of(float c, float lo, float scale) const {
+    int b = (int)((c - lo) * scale);
+    return b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+  }
+
+  Split best_split(const WideNode& nd) const {   // binned SAH, 7 planes per axis (bvh.cpp:135-191)
+    Split best;
+    for (int a = 0; a < 3; ++a) {
+      const float lo = comp(nd.cbox.lo, a), hi = comp(nd.cbox.hi, a);
+      if (lo == hi) continue;
+      const float scale = kBins / (hi - lo);
+      Box bb[kBins]; int cnt[kBins] = {0};
+      for (uint32_t i = 0; i < nd.triCount; ++i) {
+        const rt_tri_t& t = tri_[nd.leftFirst + i];
+        const int b = bin_of(comp(cent_[nd.leftFirst + i], a), lo, scale);
+        cnt[b]++;
+        bb[b].grow(tv(t.v0)); bb[b].grow(tv(t.v1)); bb[b].grow(tv(t.v2));
+      }
+      float la[kBins - 1], ra[kBins - 1];
+      Box lb, rb; int ls = 0, rs = 0;
+      for (int i = 0; i < kBins - 1; ++i) {
+        ls += cnt[i]; lb.grow(bb[i]);
+        la[i] = ls > 0 ? ls * lb.half_area() : INFINITY;
+        rs += cnt[kBins - 1 - i]; rb.grow(bb[kBins - 1 - i]);
+        ra[kBins - 2 - i] = rs > 0 ? rs * rb.half_area() : INFINITY;
+      }
+      for (int i = 0; i < kBins - 1; ++i) {
+        const float c = la[i] + ra[i];
+        if (c < best.cost) { best.axis = a; best.pos = i + 1; best.cost = c; }
+      }
+    }
+    return best;
+  }
+
+  uint32_t partition(const WideNode& nd, const Split& s) {   // bvh.cpp:111-133
+    const float lo = comp(nd.cbox.lo, s.axis), hi = comp(nd.cbox.hi, s.axis);
+    const float scale = kBins / (hi - lo);
+    int64_t i = 0, j = (int64_t)nd.triCount - 1;
+    while (i <= j) {
+      const uint32_t a = nd.leftFirst + (uint32_t)i;
+      if (bin_of(comp(cent_[a], s.axis), lo, scale) < s.pos) {
+        ++i;
+      } else {
+        const uint32_t b = nd.leftFirst + (uint32_t)j;
+        std::swap(tri_[a], tri_[b]);
+        if (triEx_) std::swap(triEx_[a], triEx_[b]);
+        std::swap(cent_[a], cent_[b]);
+        --j;
+      }
+    }
+    return (uint32_t)i;
+  }
+
+  void subdivide(uint32_t idx, uint32_t depth) {
+    max_depth_ = std::max(max_depth_, depth);
+    bounds(nodes_[idx]);
+    if (nodes_[idx].triCount <= 1) return;
+    std::vector<WideNode> cl;
+    cl.push_back(nodes_[idx]);
+    while (cl.size() < RT_BVH_WIDTH) {
+      Split bs; float bestDelta = 0.f; int bi = -1;
+      for (int i = 0; i < (int)cl.size(); ++i) {
+        if (cl[i].triCount <= 1) continue;
+        Split s = best_split(cl[i]);
+        if (s.cost == INFINITY) continue;
+        // node cost as the reference prices it: surfaceArea * triCount with surfaceArea = 2*half
+        // and split cost in half-areas (common.h:81-83 vs bvh.h:24-27) - kept, it biases to leaves
+        const float delta = 2.0f * cl[i].box.half_area() * cl[i].triCount - s.cost;
+        if (delta > bestDelta) { bestDelta = delta; bs = s; bi = i; }
+      }
+      if (bi < 0) break;
+      const uint32_t lc = partition(cl[bi], bs);
+      const uint32_t rc = cl[bi].triCount - lc;
+      if (lc == 0 || rc == 0) break;
+      WideNode L, R;
+      L.leftFirst = cl[bi].leftFirst; L.triCount = lc;
+      R.leftFirst = cl[bi].leftFirst + lc; R.triCount = rc;
+      bounds(L); bounds(R);
+      cl[bi] = L;
+      cl.push_back(R);
+    }
+    if (cl.size() == 1) return;   // leaf with several triangles
+    const uint32_t first = (uint32_t)nodes_.size();
+    for (size_t i = 0; i < cl.size(); ++i) {
+      nodes_.emplace_back();
+      nodes_.back().leftFirst = cl[i].leftFirst;
+      nodes_.back().triCount = cl[i].triCount;
+    }
+    const uint32_t cc = (uint32_t)cl.size();
+    for (uint32_t i = 0; i < cc; ++i) subdivide(first + i, depth + 1);
+    nodes_[idx].triCount = 0;
+    nodes_[idx].leftFirst = first;
+    nodes_[idx].childCount = cc;
+  }
+
+  rt_tri_t* tri_;
+  rt_triex_t* triEx_;
+  uint32_t n_;
+  std::vector<V3> cent_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Quantisation (format of bvh.cpp:215-264; decode = origin + ldexp(q, e), rt_traversal.cpp:61-67)
+// ---------------------------------------------------------------------------------------------
+int8_t pick_exp(float extent) {
+  if (!(extent > 0.0f)) return 0;   // reference: log2(0) -> -inf -> int8 cast (UB) gave 0 on x86-64 g++ 11
+  float e = std::ceil(std::log2(extent / 255.0f));
+  if (!(e >= -126.0f)) e = -126.0f;
+  if (e > 126.0f) e = 126.0f;
+  return (int8_t)e;
+}
+
+// returns false if some coordinate needs q > 255 at this exponent
+bool quant_axis(float origin, int8_t e, float cmin, float cmax, uint8_t* qlo, uint8_t* qhi) {
+  const float s = std::exp2f((float)e);
+  float fl = std::floor((cmin - origin) / s), fh = std::ceil((cmax - origin) / s);
+  if (fl < 0) fl = 0;
+  if (fh < fl) fh = fl;
+  if (fh > 255.0f) return false;
+  int lo = (int)fl, hi = (int)fh;
+  while (lo > 0 && origin + std::ldexp((float)lo, e) > cmin) --lo;     // conservative after the decode's rounding
+  while (hi < 255 && origin + std::ldexp((float)hi, e) < cmax) ++hi;
+  if (origin + std::ldexp((float)hi, e) < cmax) return false;
+  *qlo = (uint8_t)lo; *qhi = (uint8_t)hi;
+  return true;
+}
+
+template <class ChildBox>
+void quantize_node(rt_qnode_t& q, const Box& box, uint32_t nchild, ChildBox child_box) {
+  q.origin[0] = box.lo.x; q.origin[1] = box.lo.y; q.origin[2] = box.lo.z;
+  int8_t e[3] = {pick_exp(box.hi.x - box.lo.x), pick_exp(box.hi.y - box.lo.y), pick_exp(box.hi.z - box.lo.z)};
+  for (int a = 0; a < 3; ++a) {
+    for (;;) {
+      bool ok = true;
+      for (uint32_t k = 0; k < nchild && ok; ++k) {
+        Box cb = child_box(k);
+        uint8_t l, h;
+        ok = quant_axis(q.origin[a], e[a], comp(cb.lo, a), comp(cb.hi, a), &l, &h);
+        if (ok) { q.children[k].qaabb[a] = l; q.children[k].qaabb[3 + a] = h; }
+      }
+      if (ok || e[a] >= 126) break;
+      ++e[a];
+    }
+  }
+  q.ex = e[0]; q.ey = e[1]; q.ez = e[2];
+  for (uint32_t k = 0; k < RT_BVH_WIDTH; ++k) {
+    if (k < nchild) q.children[k].meta = 1;
+    else std::memset(&q.children[k], 0, sizeof(rt_child_t));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4x4 helpers (row-major, like geometry.h mat4_t)
+// ---------------------------------------------------------------------------------------------
+bool invert4(const float* m, float* out) {
+  double a[4][8];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = m[i * 4 + j]; a[i][4 + j] = i == j; }
+  for (int c = 0; c < 4; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[p][c])) p = r;
+    if (a[p][c] == 0) return false;
+    for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[p][j]);
+    const double d = a[c][c];
+    for (int j = 0; j < 8; ++j) a[c][j] /= d;
+    for (int r = 0; r < 4; ++r) if (r != c) { const double f = a[r][c]; for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j]; }
+  }
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i * 4 + j] = (float)a[i][4 + j];
+  return true;
+}
+V3 xform_point(const float* m, V3 p) {
+  return {m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7], m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scene = what Tracer::init/setup uploads (tracer.cpp:124-161, 217-241)
+// ---------------------------------------------------------------------------------------------
+struct Scene {
+  std::vector<rt_qnode_t> tlas;
+  std::vector<rt_blas_t> blas;
+  std::vector<rt_qnode_t> bvh;
+  std::vector<rt_tri_t> tri;
+  std::vector<rt_triex_t> triEx;
+  std::vector<rt_material_t> mat;
+  std::vector<uint8_t> tex;
+  std::vector<uint32_t> triIdx;
+  uint32_t max_depth = 0, n_leaves = 0, max_leaf = 0;
+  float bounds[6] = {0};
+};
+
+struct TlasItem { Box box; uint32_t blasIdx; };
+
+void build_tlas_rec(Scene& sc, std::vector<TlasItem>& items, uint32_t begin, uint32_t end, uint32_t nodeIdx, uint32_t depth, uint32_t* maxd) {
+  *maxd = std::max(*maxd, depth);
+  rt_qnode_t& q0 = sc.tlas[nodeIdx];
+  std::memset(&q0, 0, sizeof q0);
+  q0.imask = 1;
+  Box box;
+  for (uint32_t i = begin; i < end; ++i) box.grow(items[i].box);
+  if (end - begin == 1) {   // TLAS leaf (bvh.cpp:325-328): leafData = blasIdx
+    q0.origin[0] = box.lo.x; q0.origin[1] = box.lo.y; q0.origin[2] = box.lo.z;
+    q0.ex = pick_exp(box.hi.x - box.lo.x); q0.ey = pick_exp(box.hi.y - box.lo.y); q0.ez = pick_exp(box.hi.z - box.lo.z);
+    q0.leftFirst = 0;
+    q0.leafData = items[begin].blasIdx;
+    return;
+  }
+  // split into up to 4 groups: median cuts along the widest axis of the centroids
+  std::vector<std::pair<uint32_t, uint32_t>> groups{{begin, end}};
+  while (groups.size() < RT_BVH_WIDTH) {
+    int gi = -1; uint32_t best = 1;
+    for (size_t g = 0; g < groups.size(); ++g) { uint32_t c = groups[g].second - groups[g].first; if (c > best) { best = c; gi = (int)g; } }
+    if (gi < 0) break;
+    auto [b, e] = groups[gi];
+    Box cb;
+    for (uint32_t i = b; i < e; ++i) cb.grow((items[i].box.lo + items[i].box.hi) * 0.5f);
+    V3 ext = cb.hi - cb.lo;
+    int ax = ext.x >= ext.y ? (ext.x >= ext.z ? 0 : 2) : (ext.y >= ext.z ? 1 : 2);
+    std::stable_sort(items.begin() + b, items.begin() + e, [ax](const TlasItem& l, const TlasItem& r) {
+      return comp(l.box.lo, ax) + comp(l.box.hi, ax) < comp(r.box.lo, ax) + comp(r.box.hi, ax);
+    });
+    uint32_t mid = b + (e - b) / 2;
+    groups[gi] = {b, mid};
+    groups.push_back({mid, e});
+  }
+  const uint32_t first = (uint32_t)sc.tlas.size();
+  const uint32_t nc = (uint32_t)groups.size();
+  sc.tlas.resize(sc.tlas.size() + nc);
+  std::vector<Box> cbx(nc);
+  for (uint32_t k = 0; k < nc; ++k) for (uint32_t i = groups[k].first; i < groups[k].second; ++i) cbx[k].grow(items[i].box);
+  {
+    rt_qnode_t& q = sc.tlas[nodeIdx];
+    quantize_node(q, box, nc, [&](uint32_t k) { return cbx[k]; });
+    q.leftFirst = first;
+    q.leafData = 0xffffffffu;   // internal (bvh.cpp:417)
+  }
+  for (uint32_t k = 0; k < nc; ++k) build_tlas_rec(sc, items, groups[k].first, groups[k].second, first + k, depth + 1, maxd);
+}
+
+Scene* build_scene(std::vector<Mesh>& meshes) {
+  auto sc = new Scene();
+  size_t ntri = 0, nmat = 0;
+  for (auto& m : meshes) { ntri += m.tri.size(); nmat += m.mats.size(); }
+  sc->tri.reserve(ntri); sc->triEx.reserve(ntri); sc->mat.reserve(nmat);
+  sc->blas.resize(meshes.size());
+  std::vector<TlasItem> items;
+  uint32_t tri_off = 0, bvh_off = 0, mat_off = 0;
+  uint32_t blas_depth = 0;
+  Box world;
+  for (size_t mi = 0; mi < meshes.size(); ++mi) {
+    Mesh& m = meshes[mi];
+    // textures first so materials can point at them (scene.cpp:61-80)
+    std::vector<uint64_t> tex_offsets;
+    for (size_t t = 0; t < m.textures.size(); ++t) {
+      tex_offsets.push_back(sc->tex.size());
+      const uint8_t* p = (const uint8_t*)m.textures[t].data();
+      sc->tex.insert(sc->tex.end(), p, p + m.textures[t].size() * 4);
+    }
+    for (auto mat : m.mats) {
+      if (mat.diffuse_tex_id >= 0 && (size_t)mat.diffuse_tex_id < tex_offsets.size()) {
+        mat.tex_offset = tex_offsets[mat.diffuse_tex_id];
+        mat.tex_width = m.tex_dims[mat.diffuse_tex_id].first;
+        mat.tex_height = m.tex_dims[mat.diffuse_tex_id].second;
+      } else {
+        mat.diffuse_tex_id = -1;
+      }
+      sc->mat.push_back(mat);
+    }
+    const uint32_t n = (uint32_t)m.tri.size();
+    sc->tri.insert(sc->tri.end(), m.tri.begin(), m.tri.end());
+    sc->triEx.insert(sc->triEx.end(), m.triEx.begin(), m.triEx.end());
+    for (uint32_t j = 0; j < n; ++j) sc->triEx[tri_off + j].texId += mat_off;   // scene.cpp:56-58
+
+    BlasBuilder bb(sc->tri.data() + tri_off, sc->triEx.data() + tri_off, n);
+    blas_depth = std::max(blas_depth, bb.max_depth_);
+    const uint32_t nn = (uint32_t)bb.nodes_.size();
+    sc->bvh.resize(bvh_off + nn);
+    for (uint32_t i = 0; i < nn; ++i) {
+      const WideNode& w = bb.nodes_[i];
+      rt_qnode_t& q = sc->bvh[bvh_off + i];
+      std::memset(&q, 0, sizeof q);
+      q.imask = 0;
+      if (w.triCount == 0) {
+        quantize_node(q, w.box, w.childCount, [&](uint32_t k) { return bb.nodes_[w.leftFirst + k].box; });
+        q.leftFirst = w.leftFirst;      // relative to this BLAS's first node (rt_traversal.cpp:92,119)
+        q.leafData = 0;
+      } else {
+        q.origin[0] = w.box.lo.x; q.origin[1] = w.box.lo.y; q.origin[2] = w.box.lo.z;
+        q.ex = pick_exp(w.box.hi.x - w.box.lo.x); q.ey = pick_exp(w.box.hi.y - w.box.lo.y); q.ez = pick_exp(w.box.hi.z - w.box.lo.z);
+        q.leftFirst = w.leftFirst + tri_off;   // bvh.cpp:260
+        q.leafData = w.triCount;
+        sc->n_leaves++;
+        sc->max_leaf = std::max(sc->max_leaf, w.triCount);
+      }
+    }
+    rt_blas_t& b = sc->blas[mi];
+    std::memset(&b, 0, sizeof b);
+    b.bvh_offset = bvh_off;
+    std::memcpy(b.transform, m.transform, sizeof b.transform);
+    if (!invert4(m.transform, b.invTransform)) { delete sc; return nullptr; }
+    b.mat_offset = mat_off;
+    b.reflectivity = 0.0f;   // scene.cpp:96
+    // world-space bounds of the instance (bvh.cpp:295-304)
+    TlasItem it; it.blasIdx = (uint32_t)mi;
+    const Box& rb = bb.nodes_[0].box;
+    for (int c = 0; c < 8; ++c) {
+      V3 p{c & 1 ? rb.hi.x : rb.lo.x, c & 2 ? rb.hi.y : rb.lo.y, c & 4 ? rb.hi.z : rb.lo.z};
+      it.box.grow(xform_point(m.transform, p));
+    }
+    world.grow(it.box);
+    items.push_back(it);
+    tri_off += n; bvh_off += nn; mat_off += (uint32_t)m.mats.size();
+  }
+  sc->triIdx.resize(ntri);
+  for (size_t i = 0; i < ntri; ++i) sc->triIdx[i] = (uint32_t)i;
+  if (sc->mat.empty()) {   // shading always dereferences mat[texId] (closest.cpp:55): give it a default
+    rt_material_t d{};
+    d.diffuse[0] = d.diffuse[1] = d.diffuse[2] = 0.8f;
+    d.diffuse_tex_id = -1;
+    sc->mat.push_back(d);
+  }
+  if (sc->tex.empty()) sc->tex.resize(4, 0);
+  sc->tlas.resize(1);
+  uint32_t tlas_depth = 0;
+  build_tlas_rec(*sc, items, 0, (uint32_t)items.size(), 0, 0, &tlas_depth);
+  sc->max_depth = tlas_depth + blas_depth;   // TLAS leaf and BLAS root share a level (rt_traversal.cpp:109-121)
+  sc->bounds[0] = world.lo.x; sc->bounds[1] = world.lo.y; sc->bounds[2] = world.lo.z;
+  sc->bounds[3] = world.hi.x; sc->bounds[4] = world.hi.y; sc->bounds[5] = world.hi.z;
+  return sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic procedural content
+// ---------------------------------------------------------------------------------------------
+struct Rng {   // Marsaglia xorshift32 seeded through WangHash, as raytracing/common.h:129-147
+  uint32_t s;
+  explicit Rng(uint32_t seed) {
+    uint32_t x = seed;
+    x = (x ^ 61) ^ (x >> 16); x *= 9; x = x ^ (x >> 4); x *= 0x27d4eb2d; x = x ^ (x >> 15);
+    s = x ? x : 1;
+  }
+  uint32_t u32() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+  float f() { return u32() * 2.3283064365387e-10f; }
+  float range(float a, float b) { return a + (b - a) * f(); }
+};
+
+rt_material_t make_mat(float r, float g, float b, int tex) {
+  rt_material_t m{};
+  m.ambient[0] = m.ambient[1] = m.ambient[2] = 0.1f;
+  m.diffuse[0] = r; m.diffuse[1] = g; m.diffuse[2] = b;
+  m.shininess = 1; m.ior = 1; m.dissolve = 1;
+  m.diffuse_tex_id = tex;
+  return m;
+}
+
+void add_tri(Mesh& m, V3 a, V3 b, V3 c, V3 na, V3 nb, V3 nc, float ua, float va, float ub, float vb, float uc, float vc, uint32_t mat) {
+  rt_tri_t t; rt_triex_t e;
+  t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z;
+  t.v1[0] = b.x; t.v1[1] = b.y; t.v1[2] = b.z;
+  t.v2[0] = c.x; t.v2[1] = c.y; t.v2[2] = c.z;
+  e.N0[0] = na.x; e.N0[1] = na.y; e.N0[2] = na.z;
+  e.N1[0] = nb.x; e.N1[1] = nb.y; e.N1[2] = nb.z;
+  e.N2[0] = nc.x; e.N2[1] = nc.y; e.N2[2] = nc.z;
+  e.uv0[0] = ua; e.uv0[1] = va; e.uv1[0] = ub; e.uv1[1] = vb; e.uv2[0] = uc; e.uv2[1] = vc;
+  e.texId = mat;
+  m.tri.push_back(t); m.triEx.push_back(e);
+}
+
+// parametric sheet: nu x nv quads of P(u,v), u,v in [0,1]; normals by finite differences
+template <class F>
+void add_sheet(Mesh& m, uint32_t nu, uint32_t nv, uint32_t mat, float uv_scale, F P) {
+  std::vector<V3> p((size_t)(nu + 1) * (nv + 1)), nrm(p.size());
+  for (uint32_t j = 0; j <= nv; ++j) for (uint32_t i = 0; i <= nu; ++i) p[(size_t)j * (nu + 1) + i] = P((float)i / nu, (float)j / nv);
+  const float h = 1e-3f;
+  for (uint32_t j = 0; j <= nv; ++j) for (uint32_t i = 0; i <= nu; ++i) {
+    float u = (float)i / nu, v = (float)j / nv;
+    V3 du = P(u + h, v) - P(u - h, v), dv = P(u, v + h) - P(u, v - h);
+    nrm[(size_t)j * (nu + 1) + i] = normalize(cross(du, dv));
+  }
+  for (uint32_t j = 0; j < nv; ++j) for (uint32_t i = 0; i < nu; ++i) {
+    size_t a = (size_t)j * (nu + 1) + i, b = a + 1, c = a + nu + 1, d = c + 1;
+    float u0 = uv_scale * i / nu, u1 = uv_scale * (i + 1) / nu, v0 = uv_scale * j / nv, v1 = uv_scale * (j + 1) / nv;
+    add_tri(m, p[a], p[b], p[d], nrm[a], nrm[b], nrm[d], u0, v0, u1, v0, u1, v1, mat);
+    add_tri(m, p[a], p[d], p[c], nrm[a], nrm[d], nrm[c], u0, v0, u1, v1, u0, v1, mat);
+  }
+}
+
+void add_texture(Mesh& m, uint32_t w, uint32_t h, uint32_t kind, uint32_t seed) {
+  std::vector<uint32_t> px((size_t)w * h);
+  Rng rng(seed);
+  uint32_t base[3] = {128 + rng.u32() % 100, 128 + rng.u32() % 100, 128 + rng.u32() % 100};
+  for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) {
+    uint32_t k;
+    switch (kind % 4) {
+    case 0: k = ((x / 16) ^ (y / 16)) & 1 ? 255 : 140; break;                       // checker
+    case 1: k = (y % 32 < 3 || (x + (y / 32 % 2) * 32) % 64 < 3) ? 90 : 230; break;  // bricks
+    case 2: k = 150 + (uint32_t)(100.0 * (0.5 + 0.5 * std::sin(x * 0.11 + 3.0 * std::sin(y * 0.07)))); break;  // marble
+    default: k = 120 + ((x * 2654435761u ^ y * 40503u) >> 27) * 4; break;           // noise
+    }
+    uint32_t r = base[0] * k / 255, g = base[1] * k / 255, b = base[2] * k / 255;
+    px[(size_t)y * w + x] = (r << 16) | (g << 8) | b;
+  }
+  m.textures.push_back(std::move(px));
+  m.tex_dims.push_back({w, h});
+}
+
+inline float bump(float x, float y, float amp) {   // cheap smooth relief so big surfaces are not flat
+  return amp * (std::sin(x * 0.045f) * std::sin(y * 0.06f) + 0.5f * std::sin(x * 0.13f + 1.3f) * std::sin(y * 0.17f + 0.7f));
+}
+
+// small rigid rotation so that nothing in the big scenes is exactly axis aligned (axis-aligned
+// zero-thickness boxes trip the reference traverser's 2^32-iteration spin)
+void tilt(Mesh& m, float ay, float ax) {
+  const float cy = std::cos(ay), sy = std::sin(ay), cx = std::cos(ax), sx = std::sin(ax);
+  auto rot = [&](float* p, float px, float py, float pz) {
+    float x = p[0] - px, y = p[1] - py, z = p[2] - pz;
+    float x1 = cy * x + sy * z, z1 = -sy * x + cy * z;
+    float y2 = cx * y - sx * z1, z2 = sx * y + cx * z1;
+    p[0] = x1 + px; p[1] = y2 + py; p[2] = z2 + pz;
+  };
+  for (auto& t : m.tri) { rot(t.v0, 0, 100, 0); rot(t.v1, 0, 100, 0); rot(t.v2, 0, 100, 0); }
+  for (auto& e : m.triEx) { rot(e.N0, 0, 0, 0); rot(e.N1, 0, 0, 0); rot(e.N2, 0, 0, 0); }
+}
+
+// config 1: 12-triangle Cornell box in front of the RTU kernel's fixed camera (0,100,0)->+x
+Mesh make_cornell() {
+  Mesh m;
+  m.mats = {make_mat(0.73f, 0.73f, 0.73f, -1), make_mat(0.65f, 0.05f, 0.05f, -1), make_mat(0.12f, 0.45f, 0.15f, -1)};
+  const float x0 = 60, x1 = 260, y0 = 0, y1 = 200, z0 = -100, z1 = 100;
+  auto quad = [&](V3 a, V3 b, V3 c, V3 d, uint32_t mat) {
+    V3 n = normalize(cross(b - a, c - a));
+    add_tri(m, a, b, c, n, n, n, 0, 0, 1, 0, 1, 1, mat);
+    add_tri(m, a, c, d, n, n, n, 0, 0, 1, 1, 0, 1, mat);
+  };
+  quad({x0, y0, z0}, {x0, y0, z1}, {x1, y0, z1}, {x1, y0, z0}, 0);   // floor
+  quad({x0, y1, z0}, {x1, y1, z0}, {x1, y1, z1}, {x0, y1, z1}, 0);   // ceiling
+  quad({x1, y0, z0}, {x1, y0, z1}, {x1, y1, z1}, {x1, y1, z0}, 0);   // back wall
+  quad({x0, y0, z0}, {x1, y0, z0}, {x1, y1, z0}, {x0, y1, z0}, 1);   // left (red)
+  quad({x0, y0, z1}, {x0, y1, z1}, {x1, y1, z1}, {x1, y0, z1}, 2);   // right (green)
+  quad({150, 60, -40}, {150, 60, 30}, {210, 60, 30}, {210, 60, -40}, 0);  // top face of the short box
+  return m;
+}
+
+// config 2: "bunny-class" blob: subdivided icosahedron with radial harmonics
+Mesh make_blob(uint32_t subdiv, uint32_t seed) {
+  Mesh m;
+  m.mats = {make_mat(0.8f, 0.7f, 0.6f, 0)};
+  add_texture(m, 256, 256, 2, seed);
+  const float t = (1.0f + std::sqrt(5.0f)) / 2.0f;
+  std::vector<V3> v = {{-1, t, 0}, {1, t, 0}, {-1, -t, 0}, {1, -t, 0}, {0, -1, t}, {0, 1, t}, {0, -1, -t}, {0, 1, -t}, {t, 0, -1}, {t, 0, 1}, {-t, 0, -1}, {-t, 0, 1}};
+  for (auto& p : v) p = normalize(p);
+  std::vector<uint32_t> f = {0, 11, 5, 0, 5, 1, 0, 1, 7, 0, 7, 10, 0, 10, 11, 1, 5, 9, 5, 11, 4, 11, 10, 2, 10, 7, 6, 7, 1, 8,
+                             3, 9, 4, 3, 4, 2, 3, 2, 6, 3, 6, 8, 3, 8, 9, 4, 9, 5, 2, 4, 11, 6, 2, 10, 8, 6, 7, 9, 8, 1};
+  for (uint32_t s = 0; s < subdiv; ++s) {
+    std::map<uint64_t, uint32_t> mid;
+    auto midpoint = [&](uint32_t a, uint32_t b) {
+      uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+      auto it = mid.find(key);
+      if (it != mid.end()) return it->second;
+      v.push_back(normalize((v[a] + v[b]) * 0.5f));
+      return mid[key] = (uint32_t)v.size() - 1;
+    };
+    std::vector<uint32_t> nf;
+    nf.reserve(f.size() * 4);
+    for (size_t i = 0; i < f.size(); i += 3) {
+      uint32_t a = f[i], b = f[i + 1], c = f[i + 2];
+      uint32_t ab = midpoint(a, b), bc = midpoint(b, c), ca = midpoint(c, a);
+      uint32_t q[12] = {a, ab, ca, b, bc, ab, c, ca, bc, ab, bc, ca};
+      nf.insert(nf.end(), q, q + 12);
+    }
+    f.swap(nf);
+  }
+  Rng rng(seed);
+  float ph[6];
+  for (float& x : ph) x = rng.range(0.f, 6.2831853f);
+  auto radius = [&](V3 d) {
+    return 80.0f * (1.0f + 0.15f * std::sin(5 * d.x + ph[0]) * std::sin(4 * d.y + ph[1]) + 0.10f * std::sin(9 * d.z + ph[2]) * std::sin(7 * d.x + ph[3]) +
+                    0.05f * std::sin(17 * d.y + ph[4]) * std::sin(13 * d.z + ph[5]));
+  };
+  const V3 c{220, 100, 0};
+  std::vector<V3> p(v.size());
+  for (size_t i = 0; i < v.size(); ++i) p[i] = c + v[i] * radius(v[i]);
+  std::vector<V3> nrm(v.size(), V3{0, 0, 0});
+  for (size_t i = 0; i < f.size(); i += 3) {
+    V3 n = cross(p[f[i + 1]] - p[f[i]], p[f[i + 2]] - p[f[i]]);
+    nrm[f[i]] = nrm[f[i]] + n; nrm[f[i + 1]] = nrm[f[i + 1]] + n; nrm[f[i + 2]] = nrm[f[i + 2]] + n;
+  }
+  for (auto& n : nrm) n = normalize(n);
+  auto uvof = [&](V3 d, float* u, float* w) { *u = 0.5f + std::atan2(d.z, d.x) / 6.2831853f; *w = 0.5f - std::asin(std::max(-1.f, std::min(1.f, d.y))) / 3.14159265f; };
+  for (size_t i = 0; i < f.size(); i += 3) {
+    float u0, v0, u1, v1, u2, v2;
+    uvof(v[f[i]], &u0, &v0); uvof(v[f[i + 1]], &u1, &v1); uvof(v[f[i + 2]], &u2, &v2);
+    add_tri(m, p[f[i]], p[f[i + 1]], p[f[i + 2]], nrm[f[i]], nrm[f[i + 1]], nrm[f[i + 2]], u0 * 4, v0 * 4, u1 * 4, v1 * 4, u2 * 4, v2 * 4, 0);
+  }
+  return m;
+}
+
+// config 3/4: "Sponza-class" atrium.  `level` scales the tessellation: triangle count = 2^(2*level+4)
+// (level 8 -> 1,048,576).  Hall x in [-600,1400], y in [0,600], z in [-400,400]; camera (0,100,0).
+Mesh make_atrium(uint32_t level, uint32_t seed) {
+  Mesh m;
+  Rng rng(seed);
+  for (int i = 0; i < 16; ++i) m.mats.push_back(make_mat(rng.range(0.4f, 0.9f), rng.range(0.4f, 0.9f), rng.range(0.4f, 0.9f), i < 8 ? i : -1));
+  for (uint32_t i = 0; i < 8; ++i) add_texture(m, 256, 256, i, seed * 31 + i);
+  const uint32_t g = 1u << level;          // 256 at level 8
+  const uint32_t gh = g / 2, gq = g / 8 ? g / 8 : 1;
+  const float X0 = -600, X1 = 1400, Y0 = 0, Y1 = 600, Z0 = -400, Z1 = 400;
+  // floor / ceiling: g x g quads each
+  add_sheet(m, g, g, 0, 16, [&](float u, float v) { float x = X0 + (X1 - X0) * u, z = Z0 + (Z1 - Z0) * v; return V3{x, Y0 + bump(x, z, 1.5f), z}; });
+  add_sheet(m, g, g, 1, 16, [&](float u, float v) { float x = X0 + (X1 - X0) * u, z = Z1 - (Z1 - Z0) * v; return V3{x, Y1 + bump(x, z, 4.0f), z}; });
+  // four walls: g x g/2 quads each
+  add_sheet(m, g, gh, 2, 12, [&](float u, float v) { float x = X0 + (X1 - X0) * u, y = Y0 + (Y1 - Y0) * v; return V3{x, y, Z0 + bump(x, y, 3.0f)}; });
+  add_sheet(m, g, gh, 3, 12, [&](float u, float v) { float x = X1 - (X1 - X0) * u, y = Y0 + (Y1 - Y0) * v; return V3{x, y, Z1 + bump(x, y, 3.0f)}; });
+  add_sheet(m, g, gh, 4, 8, [&](float u, float v) { float z = Z1 - (Z1 - Z0) * u, y = Y0 + (Y1 - Y0) * v; return V3{X0 + bump(z, y, 3.0f), y, z}; });
+  add_sheet(m, g, gh, 5, 8, [&](float u, float v) { float z = Z0 + (Z1 - Z0) * u, y = Y0 + (Y1 - Y0) * v; return V3{X1 + bump(z, y, 3.0f), y, z}; });
+  // 32 fluted columns in two rows: (g/2) x (g/8) quads each
+  for (int c = 0; c < 32; ++c) {
+    const float cx = X0 + 100 + (c / 2) * ((X1 - X0 - 200) / 15.0f), cz = (c & 1) ? 220.0f : -220.0f;
+    const float r0 = 28.0f + 4.0f * rng.f();
+    add_sheet(m, gh, gq, 6 + (c % 4), 4, [&](float u, float v) {
+      float a = 6.2831853f * u, y = Y0 + (Y1 - Y0) * 0.75f * v;
+      float r = r0 * (1.0f + 0.06f * std::cos(16 * a)) * (1.0f - 0.15f * v + 0.2f * std::exp(-40 * v) + 0.25f * std::exp(-40 * (1 - v)));
+      return V3{cx + r * std::cos(a), y, cz - r * std::sin(a)};
+    });
+  }
+  // 16 hanging drapes / arches across the nave: (g/2) x (g/4) quads each
+  for (int d = 0; d < 16; ++d) {
+    const float dx = X0 + 160 + d * ((X1 - X0 - 320) / 15.0f);
+    const float ph = rng.range(0.f, 6.28f), amp = rng.range(10.f, 25.f);
+    add_sheet(m, gh, g / 4 ? g / 4 : 1, 10 + (d % 6), 6, [&](float u, float v) {
+      float z = -200.0f + 400.0f * u;
+      float arch = 450.0f + 100.0f * std::sin(3.14159265f * u);
+      float y = arch - 160.0f * v;
+      return V3{dx + amp * std::sin(10 * u + ph) * (0.3f + v) + 6.0f * std::sin(14 * v + ph), y, z};
+    });
+  }
+  tilt(m, 0.0617f, 0.0291f);
+  return m;
+}
+
+// config 5: hairball - `strands` splines of `segs` thin triangles pairs inside a sphere
+Mesh make_hairball(uint32_t strands, uint32_t segs, uint32_t seed) {
+  Mesh m;
+  m.mats = {make_mat(0.85f, 0.75f, 0.55f, -1)};
+  Rng rng(seed);
+  const V3 c{260, 100, 0};
+  const float R = 120.0f;
+  m.tri.reserve((size_t)strands * segs * 2);
+  m.triEx.reserve((size_t)strands * segs * 2);
+  for (uint32_t s = 0; s < strands; ++s) {
+    V3 d = normalize(V3{rng.range(-1, 1), rng.range(-1, 1), rng.range(-1, 1)});
+    V3 side = normalize(cross(d, V3{0.3f, 1.0f, 0.2f}));
+    V3 w1 = normalize(V3{rng.range(-1, 1), rng.range(-1, 1), rng.range(-1, 1)});
+    const float f1 = rng.range(2.f, 9.f), a1 = rng.range(4.f, 18.f), wdt = 0.35f;
+    V3 prev{0, 0, 0}; bool have = false;
+    for (uint32_t k = 0; k <= segs; ++k) {
+      float t = (float)k / segs;
+      V3 p = c + d * (R * (0.15f + 0.85f * t)) + w1 * (a1 * std::sin(f1 * t * 6.28f) * t);
+      if (have) {
+        V3 n = normalize(cross(p - prev, side));
+        add_tri(m, prev - side * wdt, prev + side * wdt, p + side * wdt, n, n, n, 0, 0, 1, 0, 1, 1, 0);
+        add_tri(m, prev - side * wdt, p + side * wdt, p - side * wdt, n, n, n, 0, 0, 1, 1, 0, 1, 0);
+      }
+      prev = p; have = true;
+    }
+  }
+  return m;
+}
+
+// minimal OBJ (+MTL colours) reader: v / vn / vt / f (fan-triangulated) / usemtl / mtllib
+bool load_obj(const char* path, Mesh& m) {
+  std::ifstream in(path);
+  if (!in) return false;
+  std::vector<V3> P, N; std::vector<std::pair<float, float>> T;
+  std::map<std::string, uint32_t> matid;
+  uint32_t cur = 0;
+  std::string line, dir(path);
+  auto slash = dir.find_last_of('/');
+  dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+  while (std::getline(in, line)) {
+    std::istringstream ss(line);
+    std::string k; ss >> k;
+    if (k == "v") { V3 p; ss >> p.x >> p.y >> p.z; P.push_back(p); }
+    else if (k == "vn") { V3 p; ss >> p.x >> p.y >> p.z; N.push_back(p); }
+    else if (k == "vt") { float u = 0, v = 0; ss >> u >> v; T.push_back({u, v}); }
+    else if (k == "mtllib") {
+      std::string f; ss >> f;
+      std::ifstream mi(dir + f);
+      std::string ml, name;
+      while (std::getline(mi, ml)) {
+        std::istringstream ms(ml); std::string mk; ms >> mk;
+        if (mk == "newmtl") { ms >> name; matid[name] = (uint32_t)m.mats.size(); m.mats.push_back(make_mat(0.8f, 0.8f, 0.8f, -1)); }
+        else if (mk == "Kd" && !m.mats.empty()) { ms >> m.mats.back().diffuse[0] >> m.mats.back().diffuse[1] >> m.mats.back().diffuse[2]; }
+        else if (mk == "Ka" && !m.mats.empty()) { ms >> m.mats.back().ambient[0] >> m.mats.back().ambient[1] >> m.mats.back().ambient[2]; }
+      }
+    } else if (k == "usemtl") { std::string n; ss >> n; auto it = matid.find(n); cur = it == matid.end() ? 0 : it->second; }
+    else if (k == "f") {
+      struct Ix { int p, t, n; };
+      std::vector<Ix> ix; std::string tok;
+      while (ss >> tok) {
+        Ix i{0, 0, 0};
+        if (std::sscanf(tok.c_str(), "%d/%d/%d", &i.p, &i.t, &i.n) == 3) {}
+        else if (std::sscanf(tok.c_str(), "%d//%d", &i.p, &i.n) == 2) { i.t = 0; }
+        else if (std::sscanf(tok.c_str(), "%d/%d", &i.p, &i.t) == 2) { i.n = 0; }
+        else { std::sscanf(tok.c_str(), "%d", &i.p); }
+        ix.push_back(i);
+      }
+      auto P_ = [&](int i) { return i > 0 ? P[i - 1] : P[P.size() + i]; };
+      auto N_ = [&](int i) { return i == 0 ? V3{0, 0, 0} : (i > 0 ? N[i - 1] : N[N.size() + i]); };
+      auto T_ = [&](int i) { return i == 0 ? std::pair<float, float>{0, 0} : (i > 0 ? T[i - 1] : T[T.size() + i]); };
+      for (size_t j = 1; j + 1 < ix.size(); ++j) {
+        auto t0 = T_(ix[0].t), t1 = T_(ix[j].t), t2 = T_(ix[j + 1].t);
+        add_tri(m, P_(ix[0].p), P_(ix[j].p), P_(ix[j + 1].p), N_(ix[0].n), N_(ix[j].n), N_(ix[j + 1].n),
+                t0.first, t0.second, t1.first, t1.second, t2.first, t2.second, cur);
+      }
+    }
+  }
+  return !m.tri.empty();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+// name: "cornell" | "blob" (a = icosphere subdivisions) | "atrium" (a = level, 8 -> 1,048,576 tris)
+//       | "hairball" (a = strands, b = segments per strand)
+void* vxs_scene_create_procedural(const char* name, uint32_t a, uint32_t b, uint32_t seed) {
+  std::vector<Mesh> meshes(1);
+  std::string n(name ? name : "");
+  if (n == "cornell") meshes[0] = make_cornell();
+  else if (n == "blob") meshes[0] = make_blob(a, seed);
+  else if (n == "atrium") meshes[0] = make_atrium(a, seed);
+  else if (n == "hairball") meshes[0] = make_hairball(a, b, seed);
+  else return nullptr;
+  return build_scene(meshes);
+}
+
+// general entry: n_meshes meshes; mesh i has ntris[i] triangles (9 floats each) starting at
+// tris + 9*sum(ntris[0..i)), optional triEx (64 B each, same order), optional per-mesh 4x4
+// row-major transforms, optional materials (88 B each; per-mesh counts nmats[i], texId is
+// mesh-local as in mesh.cpp) and one shared texture blob is not supported here (use procedural).
+void* vxs_scene_create_from_tris(uint32_t n_meshes, const uint32_t* ntris, const float* tris, const void* triEx,
+                                 const float* transforms, const uint32_t* nmats, const void* mats) {
+  if (!n_meshes || !ntris || !tris) return nullptr;
+  std::vector<Mesh> meshes(n_meshes);
+  size_t off = 0, moff = 0;
+  for (uint32_t i = 0; i < n_meshes; ++i) {
+    Mesh& m = meshes[i];
+    if (ntris[i] == 0) return nullptr;
+    m.tri.resize(ntris[i]);
+    std::memcpy(m.tri.data(), tris + off * 9, (size_t)ntris[i] * sizeof(rt_tri_t));
+    m.triEx.resize(ntris[i]);
+    if (triEx) std::memcpy(m.triEx.data(), (const rt_triex_t*)triEx + off, (size_t)ntris[i] * sizeof(rt_triex_t));
+    else {
+      for (uint32_t j = 0; j < ntris[i]; ++j) {
+        rt_triex_t e{};
+        V3 nn = normalize(cross(tv(m.tri[j].v1) - tv(m.tri[j].v0), tv(m.tri[j].v2) - tv(m.tri[j].v0)));
+        for (float* p : {e.N0, e.N1, e.N2}) { p[0] = nn.x; p[1] = nn.y; p[2] = nn.z; }
+        e.uv1[0] = 1; e.uv2[1] = 1;
+        m.triEx[j] = e;
+      }
+    }
+    if (transforms) std::memcpy(m.transform, transforms + 16 * i, sizeof m.transform);
+    if (nmats && mats) {
+      m.mats.resize(nmats[i]);
+      std::memcpy(m.mats.data(), (const rt_material_t*)mats + moff, (size_t)nmats[i] * sizeof(rt_material_t));
+      for (auto& mm : m.mats) mm.diffuse_tex_id = -1;
+      moff += nmats[i];
+    } else {
+      m.mats = {make_mat(0.8f, 0.8f, 0.8f, -1)};
+    }
+    off += ntris[i];
+  }
+  return build_scene(meshes);
+}
+
+// instances: like the reference's `-n mesh_count` (tracer.cpp:92-98): the same model n times, placed
+// on a circle around Y (scene.cpp:214-250) when n > 1
+void* vxs_scene_load_obj(const char* path, uint32_t instances) {
+  if (!path || instances == 0) return nullptr;
+  Mesh base;
+  if (!load_obj(path, base)) return nullptr;
+  if (base.mats.empty()) base.mats = {make_mat(0.8f, 0.8f, 0.8f, -1)};
+  std::vector<Mesh> meshes(instances, base);
+  if (instances > 1) {
+    Box bb;
+    for (auto& t : base.tri) { bb.grow(tv(t.v0)); bb.grow(tv(t.v1)); bb.grow(tv(t.v2)); }
+    const float dx = bb.hi.x - bb.lo.x, dz = bb.hi.z - bb.lo.z;
+    const float radius = 0.5f * std::sqrt(dx * dx + dz * dz);
+    const float step = 2.0f * 3.14159265358979f / (float)instances;
+    const float R = (2 * radius) / (2.0f * std::sin(step / 2.0f));
+    for (uint32_t i = 0; i < instances; ++i) {
+      meshes[i].transform[3] = R * std::cos(step * i);
+      meshes[i].transform[11] = R * std::sin(step * i);
+    }
+  }
+  return build_scene(meshes);
+}
+
+void vxs_scene_destroy(void* h) { delete (Scene*)h; }
+
+// which: 0 tlas 1 blas 2 bvh 3 tri 4 triEx 5 mat 6 tex 7 triIdx ; returns bytes
+uint64_t vxs_scene_buffer(void* h, int which, const void** ptr) {
+  auto s = (Scene*)h;
+  if (!s || !ptr) return 0;
+  switch (which) {
+  case 0: *ptr = s->tlas.data(); return s->tlas.size() * sizeof(rt_qnode_t);
+  case 1: *ptr = s->blas.data(); return s->blas.size() * sizeof(rt_blas_t);
+  case 2: *ptr = s->bvh.data(); return s->bvh.size() * sizeof(rt_qnode_t);
+  case 3: *ptr = s->tri.data(); return s->tri.size() * sizeof(rt_tri_t);
+  case 4: *ptr = s->triEx.data(); return s->triEx.size() * sizeof(rt_triex_t);
+  case 5: *ptr = s->mat.data(); return s->mat.size() * sizeof(rt_material_t);
+  case 6: *ptr = s->tex.data(); return s->tex.size();
+  case 7: *ptr = s->triIdx.data(); return s->triIdx.size() * sizeof(uint32_t);
+  }
+  *ptr = nullptr;
+  return 0;
+}
+
+// out: [0] max_depth (levels, as the reference's trail counts them) [1] leaves [2] max tris/leaf
+//      [3] bvh nodes [4] tlas nodes [5] tris ; bounds6: world AABB
+void vxs_scene_info(void* h, uint32_t* out6, float* bounds6) {
+  auto s = (Scene*)h;
+  if (out6) {
+    out6[0] = s->max_depth; out6[1] = s->n_leaves; out6[2] = s->max_leaf;
+    out6[3] = (uint32_t)s->bvh.size(); out6[4] = (uint32_t)s->tlas.size(); out6[5] = (uint32_t)s->tri.size();
+  }
+  if (bounds6) std::memcpy(bounds6, s->bounds, sizeof s->bounds);
+}
+
+}  // extern "C"

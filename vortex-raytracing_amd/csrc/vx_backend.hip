@@ -1,0 +1,485 @@
+// libvortex-hip.so -- MI355X driver backend behind the reference's runtime plug-in boundary.
+//
+// Exports `vx_dev_init(callbacks_t*)` (reference runtime/common/callbacks.inc:20) and fills the 16
+// callbacks with a HIP implementation of what runtime/simx/vortex.cpp does on the simulator:
+// a device address space (64-byte blocks from USER_BASE_ADDR, like sim/common/mem_alloc.h), copies,
+// DCRs, `start` = decode the uploaded kernel tag + kernel_arg_t and launch the HIP render kernel on
+// a stream, `ready_wait` = join that stream.  It cannot execute RISC-V: the uploaded ".vxbin" blobs
+// are interpreted as kernel selectors (16-byte vxbin header + "VXHIP1:<name>" tag; see
+// INTEGRATION.md).  Anything else makes `start` fail loudly with -1.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+#include "../../include/vortex_hip.h"
+#include "rt_types.h"
+
+namespace {
+
+constexpr uint64_t kUserBase = 0x10000;      // USER_BASE_ADDR (hw/VX_config.toml), runtime/simx/vortex.cpp:52
+constexpr uint64_t kBlockAlign = 64;         // CACHE_BLOCK_SIZE (runtime/common/common.h:29)
+constexpr uint64_t kShadowMax = 64 * 1024;   // buffers up to this size keep a host shadow (args, sbt, kernel tags)
+constexpr const char* kTagPrefix = "VXHIP1:";
+
+#define VXLOG(...) do { std::fprintf(stderr, "[vortex-hip] " __VA_ARGS__); std::fputc('\n', stderr); } while (0)
+
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) & ~(a - 1); }
+
+struct vx_device;
+
+struct Alloc {
+  uint64_t va = 0;
+  uint64_t size = 0;        // requested size
+  uint64_t span = 0;        // block-aligned span in the address space
+  void* dptr = nullptr;     // hipMalloc'ed backing store (span bytes)
+  bool reserved = false;    // created by mem_reserve (kernel images)
+  std::vector<uint8_t> shadow;  // host copy for small buffers
+};
+
+struct vx_buffer {          // same role as callbacks.inc:14-18
+  vx_device* device;
+  uint64_t addr;
+  uint64_t size;
+};
+
+struct vx_device {
+  int hip_dev = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  bool run_pending = false;
+  bool have_timing = false;
+  std::map<uint64_t, Alloc> allocs;   // keyed by va
+  uint64_t used = 0;
+  uint64_t total_mem = 0;
+  std::unordered_map<uint32_t, uint32_t> dcrs;
+  unsigned long long* d_rays = nullptr;
+  unsigned long long last_rays = 0;
+  float last_ms = 0.f;
+  hipDeviceProp_t prop{};
+
+  int init() {
+    const char* e = std::getenv("VORTEX_HIP_DEVICE");
+    if (!e) e = std::getenv("LOCAL_RANK");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { VXLOG("no HIP device"); return -1; }
+    hip_dev = e ? std::atoi(e) % n : 0;
+    if (hipSetDevice(hip_dev) != hipSuccess) return -1;
+    if (hipGetDeviceProperties(&prop, hip_dev) != hipSuccess) return -1;
+    total_mem = prop.totalGlobalMem;
+    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
+    if (hipEventCreate(&ev_begin) != hipSuccess || hipEventCreate(&ev_end) != hipSuccess) return -1;
+    if (hipMalloc((void**)&d_rays, sizeof(unsigned long long)) != hipSuccess) return -1;
+    return 0;
+  }
+
+  ~vx_device() {
+    (void)hipSetDevice(hip_dev);
+    if (stream) (void)hipStreamSynchronize(stream);   // simx dtor waits for the run (vortex.cpp:69-71)
+    for (auto& kv : allocs) if (kv.second.dptr) (void)hipFree(kv.second.dptr);
+    if (d_rays) (void)hipFree(d_rays);
+    if (ev_begin) (void)hipEventDestroy(ev_begin);
+    if (ev_end) (void)hipEventDestroy(ev_end);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  // first-fit in [kUserBase, 2^48), 64-byte blocks
+  bool range_free(uint64_t va, uint64_t span) const {
+    auto it = allocs.upper_bound(va);
+    if (it != allocs.end() && it->first < va + span) return false;
+    if (it != allocs.begin()) {
+      --it;
+      if (it->second.va + it->second.span > va) return false;
+    }
+    return true;
+  }
+
+  int back(Alloc& a) {
+    (void)hipSetDevice(hip_dev);
+    if (hipMalloc(&a.dptr, a.span) != hipSuccess) { VXLOG("hipMalloc(%llu) failed", (unsigned long long)a.span); return -1; }
+    if (a.size <= kShadowMax) a.shadow.assign(a.size, 0);
+    return 0;
+  }
+
+  int mem_alloc(uint64_t size, uint64_t* va_out) {
+    const uint64_t span = align_up(size, kBlockAlign);
+    uint64_t va = kUserBase;
+    for (auto& kv : allocs) {
+      if (kv.second.va >= va + span) break;
+      va = std::max(va, align_up(kv.second.va + kv.second.span, kBlockAlign));
+    }
+    Alloc a; a.va = va; a.size = size; a.span = span;
+    if (back(a) != 0) return -1;
+    used += span;
+    allocs.emplace(va, std::move(a));
+    *va_out = va;
+    return 0;
+  }
+
+  int mem_reserve(uint64_t va, uint64_t size) {
+    const uint64_t span = align_up(size, kBlockAlign);
+    if (!range_free(va, span)) return -1;
+    Alloc a; a.va = va; a.size = size; a.span = span; a.reserved = true;
+    if (back(a) != 0) return -1;
+    used += span;
+    allocs.emplace(va, std::move(a));
+    return 0;
+  }
+
+  int mem_free(uint64_t va) {
+    auto it = allocs.find(va);
+    if (it == allocs.end()) return -1;
+    wait_idle();
+    (void)hipSetDevice(hip_dev);
+    if (it->second.dptr) (void)hipFree(it->second.dptr);
+    used -= it->second.span;
+    allocs.erase(it);
+    return 0;
+  }
+
+  // allocation containing [va, va+len)
+  Alloc* find(uint64_t va, uint64_t len = 1) {
+    auto it = allocs.upper_bound(va);
+    if (it == allocs.begin()) return nullptr;
+    --it;
+    Alloc& a = it->second;
+    if (va < a.va || va + len > a.va + a.span) return nullptr;
+    return &a;
+  }
+
+  // The RTU reads its base pointers from 32-bit DCRs (tracer.cpp:252-256 truncates them).  Resolve
+  // a truncated value: the 64-bit kernel_arg address when its low half agrees, else the value
+  // itself, else the unique allocation whose base has these low 32 bits.
+  Alloc* find_low32(uint32_t low, uint64_t hint64, uint64_t* va_out) {
+    uint64_t va = ((uint32_t)hint64 == low) ? hint64 : (uint64_t)low;
+    if (Alloc* a = find(va)) { *va_out = va; return a; }
+    Alloc* match = nullptr;
+    for (auto& kv : allocs) {
+      if ((uint32_t)kv.first == low) { if (match) return nullptr; match = &kv.second; }
+    }
+    if (match) *va_out = match->va;
+    return match;
+  }
+
+  void wait_idle() {
+    if (run_pending) {
+      (void)hipSetDevice(hip_dev);
+      (void)hipStreamSynchronize(stream);
+      finish_run();
+    }
+  }
+
+  void finish_run() {
+    if (!run_pending) return;
+    run_pending = false;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) { last_ms = ms; have_timing = true; }
+    (void)hipMemcpy(&last_rays, d_rays, sizeof(last_rays), hipMemcpyDeviceToHost);
+  }
+
+  int upload(uint64_t va, const void* src, uint64_t size) {
+    Alloc* a = find(va, size ? size : 1);
+    if (!a) return -1;
+    wait_idle();
+    (void)hipSetDevice(hip_dev);
+    const uint64_t off = va - a->va;
+    if (size && hipMemcpy((char*)a->dptr + off, src, size, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (!a->shadow.empty() && off + size <= a->shadow.size()) std::memcpy(a->shadow.data() + off, src, size);
+    return 0;
+  }
+
+  int download(void* dst, uint64_t va, uint64_t size) {
+    Alloc* a = find(va, size ? size : 1);
+    if (!a) return -1;
+    wait_idle();
+    (void)hipSetDevice(hip_dev);
+    if (size && hipMemcpy(dst, (char*)a->dptr + (va - a->va), size, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
+  }
+
+  std::string tag_of(uint64_t va) {
+    Alloc* a = find(va);
+    if (!a || a->shadow.empty()) return {};
+    const size_t off = va - a->va;
+    const size_t plen = std::strlen(kTagPrefix);
+    if (a->shadow.size() < off + plen || std::memcmp(a->shadow.data() + off, kTagPrefix, plen) != 0) return {};
+    std::string s;
+    for (size_t i = off + plen; i < a->shadow.size() && a->shadow[i]; ++i) s.push_back((char)a->shadow[i]);
+    return s;
+  }
+
+  int start(uint64_t krnl_va, uint64_t args_va);
+  int ready_wait(uint64_t timeout_ms);
+};
+
+int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
+  wait_idle();   // ensure prior run completed (vortex.cpp:331-333)
+  (void)hipSetDevice(hip_dev);
+  dcrs[VX_DCR_BASE_STARTUP_ADDR0] = (uint32_t)krnl_va;
+  dcrs[VX_DCR_BASE_STARTUP_ADDR1] = (uint32_t)(krnl_va >> 32);
+  dcrs[VX_DCR_BASE_STARTUP_ARG0] = (uint32_t)args_va;
+  dcrs[VX_DCR_BASE_STARTUP_ARG1] = (uint32_t)(args_va >> 32);
+
+  const std::string tag = tag_of(krnl_va);
+  if (tag != "raytracing.kernel") {
+    VXLOG("start: kernel image at 0x%llx is not a HIP kernel selector (tag '%s'); this backend cannot run RISC-V binaries",
+          (unsigned long long)krnl_va, tag.c_str());
+    return -1;
+  }
+  Alloc* aa = find(args_va, sizeof(vx_rt_kernel_arg_t));
+  if (!aa || aa->shadow.size() < (args_va - aa->va) + sizeof(vx_rt_kernel_arg_t)) { VXLOG("start: bad kernel_arg buffer"); return -1; }
+  vx_rt_kernel_arg_t ka;
+  std::memcpy(&ka, aa->shadow.data() + (args_va - aa->va), sizeof ka);
+
+  // shader binding table (tracer.cpp:244-250): [0]=miss [1]=closest [3]=anyhit
+  {
+    Alloc* sb = find(ka.sbt_addr, 32);
+    if (!sb || sb->shadow.empty()) { VXLOG("start: sbt_addr does not name a buffer"); return -1; }
+    uint64_t sbt[4];
+    std::memcpy(sbt, sb->shadow.data() + (ka.sbt_addr - sb->va), sizeof sbt);
+    if (tag_of(sbt[0]) != "raytracing.miss" || tag_of(sbt[1]) != "raytracing.closest" || tag_of(sbt[3]) != "raytracing.anyhit") {
+      VXLOG("start: shader binding table does not reference the HIP miss/closest/anyhit selectors");
+      return -1;
+    }
+  }
+  if (ka.samples_per_pixel == 0) { VXLOG("start: samples_per_pixel == 0 leaves pixels undefined in the reference (kernel.cpp:67-80)"); return -1; }
+
+  // traversal buffers come from the RTU DCRs (rt_traversal.cpp:33-36), shading buffers from kernel_arg_t
+  auto dcr = [&](uint32_t id, uint32_t* v) { auto it = dcrs.find(id); if (it == dcrs.end()) return false; *v = it->second; return true; };
+  uint32_t d_tlas, d_blas, d_bvh, d_tri;
+  if (!dcr(VX_DCR_BASE_RTX_TLAS_PTR, &d_tlas) || !dcr(VX_DCR_BASE_RTX_BLAS_PTR, &d_blas) ||
+      !dcr(VX_DCR_BASE_RTX_BVH_PTR, &d_bvh) || !dcr(VX_DCR_BASE_RTX_TRI_PTR, &d_tri)) {
+    VXLOG("start: RTX DCRs 0x6..0x9 not written");
+    return -1;
+  }
+  struct Res { Alloc* a; uint64_t off; };
+  auto res32 = [&](uint32_t low, uint64_t hint) -> Res {
+    uint64_t va = 0;
+    Alloc* a = find_low32(low, hint, &va);
+    return {a, a ? va - a->va : 0};
+  };
+  auto res64 = [&](uint64_t va) -> Res { Alloc* a = find(va); return {a, a ? va - a->va : 0}; };
+  Res r_tlas = res32(d_tlas, ka.tlas_addr), r_blas = res32(d_blas, ka.blas_addr);
+  Res r_bvh = res32(d_bvh, ka.qBvh_addr), r_tri = res32(d_tri, ka.tri_addr);
+  Res r_triex = res64(ka.triEx_addr), r_mat = res64(ka.mat_addr), r_tex = res64(ka.tex_addr), r_dst = res64(ka.dst_addr);
+  if (!r_tlas.a || !r_blas.a || !r_bvh.a || !r_tri.a || !r_triex.a || !r_mat.a || !r_dst.a) {
+    VXLOG("start: a scene/output address does not name device memory");
+    return -1;
+  }
+  auto ptr = [](Res r) { return (const void*)((const char*)r.a->dptr + r.off); };
+  auto count = [](Res r, uint64_t stride) { return (uint64_t)((r.a->size - r.off) / stride); };
+  vxrt_scene_t sc{};
+  sc.tlas = ptr(r_tlas); sc.blas = ptr(r_blas); sc.bvh = ptr(r_bvh); sc.tri = ptr(r_tri);
+  sc.triEx = ptr(r_triex); sc.mat = ptr(r_mat); sc.tex = r_tex.a ? ptr(r_tex) : nullptr;
+  sc.n_tlas_nodes = (uint32_t)std::min<uint64_t>(count(r_tlas, RT_NODE_BYTES), 0x7fffffff);
+  sc.n_blas = (uint32_t)std::min<uint64_t>(count(r_blas, RT_BLAS_STRIDE), 0x7fffffff);
+  sc.n_bvh_nodes = (uint32_t)std::min<uint64_t>(count(r_bvh, RT_NODE_BYTES), 0x7fffffff);
+  sc.n_tris = (uint32_t)std::min<uint64_t>(count(r_tri, RT_TRI_BYTES), 0x7fffffff);
+  sc.n_mats = (uint32_t)std::min<uint64_t>(count(r_mat, RT_MAT_BYTES), 0x7fffffff);
+  sc.tex_bytes = r_tex.a ? r_tex.a->size - r_tex.off : 0;
+  if ((uint64_t)ka.dst_width * ka.dst_height * 4 > r_dst.a->size - r_dst.off) { VXLOG("start: output buffer too small"); return -1; }
+  if (count(r_triex, RT_TRIEX_BYTES) < sc.n_tris) { VXLOG("start: triEx buffer smaller than tri buffer"); return -1; }
+
+  vxrt_shade_params_t sp{};
+  for (int i = 0; i < 3; ++i) {
+    sp.ambient[i] = ka.ambient_color[i]; sp.light_color[i] = ka.light_color[i];
+    sp.light_pos[i] = ka.light_pos[i]; sp.background[i] = ka.background_color[i];
+  }
+  sp.max_depth = ka.max_depth;
+  uint32_t y0 = 0, y1 = 0, shadow = 0;
+  dcr(VX_DCR_HIP_ROW_BEGIN, &y0);
+  dcr(VX_DCR_HIP_ROW_END, &y1);
+  dcr(VX_DCR_HIP_SHADOW_RAYS, &shadow);
+  if (y1 == 0 || y1 > ka.dst_height) y1 = ka.dst_height;
+  if (y0 > y1) y0 = y1;
+
+  if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
+  if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
+  int rc = vxrt_render(&sc, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow,
+                       (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, nullptr, d_rays, stream);
+  if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
+  if (rc != 0) { VXLOG("start: launch rejected (shape check)"); return -1; }
+  run_pending = true;
+  return 0;
+}
+
+int vx_device::ready_wait(uint64_t timeout_ms) {
+  if (!run_pending) return 0;   // vortex.cpp:351-352
+  (void)hipSetDevice(hip_dev);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    hipError_t q = hipStreamQuery(stream);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) { VXLOG("ready_wait: %s", hipGetErrorString(q)); return -1; }
+    const auto el = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if ((uint64_t)el >= timeout_ms) return -1;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  finish_run();
+  uint32_t st = 0;
+  if (vxrt_status(stream, &st) != 0) return -1;
+  if (st != 0) { VXLOG("kernel reported status 0x%x (traversal stack overflow: BVH deeper than %d levels)", st, RT_MAX_LEVELS); return -1; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vx_hip_buffer_device_ptr(vx_buffer_h hbuffer, void** dev_ptr) {
+  if (!hbuffer || !dev_ptr) return -1;
+  auto b = (vx_buffer*)hbuffer;
+  Alloc* a = b->device->find(b->addr);
+  if (!a) return -1;
+  *dev_ptr = (char*)a->dptr + (b->addr - a->va);
+  return 0;
+}
+
+extern "C" int vx_dev_init(callbacks_t* cb) {
+  if (!cb) return -1;
+
+  cb->dev_open = [](vx_device_h* hdevice) -> int {
+    if (!hdevice) return -1;
+    auto d = new (std::nothrow) vx_device();
+    if (!d) return -1;
+    if (d->init() != 0) { delete d; return -1; }
+    *hdevice = d;
+    return 0;
+  };
+
+  cb->dev_close = [](vx_device_h hdevice) -> int {
+    if (!hdevice) return -1;
+    delete (vx_device*)hdevice;
+    return 0;
+  };
+
+  cb->dev_caps = [](vx_device_h hdevice, uint32_t caps_id, uint64_t* value) -> int {
+    if (!hdevice || !value) return -1;
+    auto d = (vx_device*)hdevice;
+    switch (caps_id) {
+    case VX_CAPS_VERSION: *value = 0x950; break;                                   // gfx950
+    case VX_CAPS_NUM_THREADS: *value = 64; break;                                  // lanes per wavefront
+    case VX_CAPS_NUM_WARPS: *value = (uint64_t)d->prop.maxThreadsPerMultiProcessor / 64; break;
+    case VX_CAPS_NUM_CORES: *value = (uint64_t)d->prop.multiProcessorCount; break; // CUs
+    case VX_CAPS_CACHE_LINE_SIZE: *value = 128; break;
+    case VX_CAPS_GLOBAL_MEM_SIZE: *value = d->total_mem; break;
+    case VX_CAPS_LOCAL_MEM_SIZE: *value = (uint64_t)d->prop.sharedMemPerBlock; break;
+    case VX_CAPS_ISA_FLAGS: *value = 0; break;                                     // no RISC-V ISA: every VX_ISA_* bit clear
+    case VX_CAPS_NUM_MEM_BANKS: *value = 8; break;                                 // HBM3E stacks
+    case VX_CAPS_MEM_BANK_SIZE: *value = d->total_mem / 8; break;
+    case VX_CAPS_NUM_CLUSTERS: *value = 8; break;                                  // XCDs
+    case VX_CAPS_SOCKET_SIZE: *value = 1; break;
+    case VX_CAPS_ISSUE_WIDTH: *value = 4; break;                                   // SIMDs per CU
+    case VX_CAPS_CLOCK_RATE: *value = (uint64_t)d->prop.clockRate * 1000ull; break; // kHz -> Hz
+    case VX_CAPS_PEAK_MEM_BW: *value = 8000000; break;                             // MB/s, HBM3E spec
+    default: VXLOG("invalid caps id: %u", caps_id); return -1;
+    }
+    return 0;
+  };
+
+  cb->mem_alloc = [](vx_device_h hdevice, uint64_t size, int, vx_buffer_h* hbuffer) -> int {
+    if (!hdevice || !hbuffer || size == 0) return -1;        // callbacks.inc:61-65
+    auto d = (vx_device*)hdevice;
+    uint64_t va;
+    if (d->mem_alloc(size, &va) != 0) return -1;
+    *hbuffer = new vx_buffer{d, va, size};
+    return 0;
+  };
+
+  cb->mem_reserve = [](vx_device_h hdevice, uint64_t address, uint64_t size, int, vx_buffer_h* hbuffer) -> int {
+    if (!hdevice || !hbuffer || size == 0) return -1;
+    auto d = (vx_device*)hdevice;
+    if (d->mem_reserve(address, size) != 0) return -1;
+    *hbuffer = new vx_buffer{d, address, size};
+    return 0;
+  };
+
+  cb->mem_free = [](vx_buffer_h hbuffer) -> int {
+    if (!hbuffer) return 0;                                   // callbacks.inc:100-102
+    auto b = (vx_buffer*)hbuffer;
+    int err = b->device->mem_free(b->addr);
+    delete b;
+    return err;
+  };
+
+  cb->mem_access = [](vx_buffer_h hbuffer, uint64_t offset, uint64_t size, int) -> int {
+    if (!hbuffer) return -1;
+    auto b = (vx_buffer*)hbuffer;
+    if (offset + size > b->size) return -1;
+    return 0;   // HBM has no per-range ACLs; bounds are still enforced here
+  };
+
+  cb->mem_address = [](vx_buffer_h hbuffer, uint64_t* address) -> int {
+    if (!hbuffer || !address) return -1;
+    *address = ((vx_buffer*)hbuffer)->addr;
+    return 0;
+  };
+
+  cb->mem_info = [](vx_device_h hdevice, uint64_t* mem_free, uint64_t* mem_used) -> int {
+    if (!hdevice) return -1;
+    auto d = (vx_device*)hdevice;
+    if (mem_free) *mem_free = d->total_mem > d->used ? d->total_mem - d->used : 0;
+    if (mem_used) *mem_used = d->used;
+    return 0;
+  };
+
+  cb->copy_to_dev = [](vx_buffer_h hbuffer, const void* host_ptr, uint64_t dst_offset, uint64_t size) -> int {
+    if (!hbuffer || !host_ptr) return -1;
+    auto b = (vx_buffer*)hbuffer;
+    if (dst_offset + size > b->size) return -1;               // callbacks.inc:153-154
+    return b->device->upload(b->addr + dst_offset, host_ptr, size);
+  };
+
+  cb->copy_from_dev = [](void* host_ptr, vx_buffer_h hbuffer, uint64_t src_offset, uint64_t size) -> int {
+    if (!hbuffer || !host_ptr) return -1;
+    auto b = (vx_buffer*)hbuffer;
+    if (src_offset + size > b->size) return -1;
+    return b->device->download(host_ptr, b->addr + src_offset, size);
+  };
+
+  cb->start = [](vx_device_h hdevice, vx_buffer_h hkernel, vx_buffer_h harguments) -> int {
+    if (!hdevice || !hkernel || !harguments) return -1;
+    return ((vx_device*)hdevice)->start(((vx_buffer*)hkernel)->addr, ((vx_buffer*)harguments)->addr);
+  };
+
+  cb->ready_wait = [](vx_device_h hdevice, uint64_t timeout) -> int {
+    if (!hdevice) return -1;
+    return ((vx_device*)hdevice)->ready_wait(timeout);
+  };
+
+  cb->dcr_read = [](vx_device_h hdevice, uint32_t addr, uint32_t* value) -> int {
+    if (!hdevice || !value) return -1;
+    auto d = (vx_device*)hdevice;
+    auto it = d->dcrs.find(addr);
+    if (it == d->dcrs.end()) return -1;                       // DeviceConfig::read, common.h:60-66
+    *value = it->second;
+    return 0;
+  };
+
+  cb->dcr_write = [](vx_device_h hdevice, uint32_t addr, uint32_t value) -> int {
+    if (!hdevice) return -1;
+    auto d = (vx_device*)hdevice;
+    d->wait_idle();                                           // vortex.cpp:367-369
+    d->dcrs[addr] = value;
+    return 0;
+  };
+
+  cb->mpm_query = [](vx_device_h hdevice, uint32_t addr, uint32_t core_id, uint64_t* value) -> int {
+    if (!hdevice || !value) return -1;
+    auto d = (vx_device*)hdevice;
+    const uint32_t offset = addr - VX_CSR_MPM_BASE;
+    if (offset > 31) return -1;                               // vortex.cpp:380-382
+    d->wait_idle();
+    if (addr == VX_CSR_MCYCLE) *value = (uint64_t)((double)d->last_ms * (double)d->prop.clockRate);  // ms * kHz = cycles
+    else if (addr == VX_CSR_MINSTRET) *value = core_id == 0 ? d->last_rays : 0;                      // rays traced by the last run
+    else *value = 0;
+    return 0;
+  };
+
+  return 0;
+}

@@ -1,0 +1,69 @@
+"""ctypes binding of the vxrt_* direct launch API (include/vortex_hip.h level 2): launches on
+caller-owned DEVICE pointers and a caller-owned HIP stream.  Used by bench.py and the GPU tests with
+torch tensors as plain device memory (`tensor.data_ptr()`), nothing torch-typed crosses the ABI."""
+import ctypes as C
+
+from .runtime import hip_lib, check
+
+MODE_CLOSEST, MODE_ANY = 0, 1
+
+
+class VxrtScene(C.Structure):
+    _fields_ = [("tlas", C.c_void_p), ("blas", C.c_void_p), ("bvh", C.c_void_p), ("tri", C.c_void_p),
+                ("triEx", C.c_void_p), ("mat", C.c_void_p), ("tex", C.c_void_p),
+                ("n_tlas_nodes", C.c_uint32), ("n_blas", C.c_uint32), ("n_bvh_nodes", C.c_uint32),
+                ("n_tris", C.c_uint32), ("n_mats", C.c_uint32), ("reserved", C.c_uint32), ("tex_bytes", C.c_uint64)]
+
+
+class ShadeParams(C.Structure):
+    _fields_ = [("ambient", C.c_float * 3), ("light_color", C.c_float * 3), ("light_pos", C.c_float * 3),
+                ("background", C.c_float * 3), ("max_depth", C.c_uint32)]
+
+
+# defaults of the reference host program (tests/regression/raytracing/main.cpp:34-41)
+def default_shade_params():
+    p = ShadeParams()
+    p.ambient[:] = (0.4, 0.4, 0.4)
+    p.light_color[:] = (1.0, 1.0, 1.0)
+    p.light_pos[:] = (0.0, 10.0, -10.0)
+    p.background[:] = (0.4, 0.35, 0.25)
+    p.max_depth = 1
+    return p
+
+
+_proto = False
+
+
+def _lib():
+    global _proto
+    L = hip_lib()
+    if not _proto:
+        L.vxrt_render.restype = C.c_int
+        L.vxrt_render.argtypes = [C.POINTER(VxrtScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vxrt_trace.restype = C.c_int
+        L.vxrt_trace.argtypes = [C.POINTER(VxrtScene), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.vxrt_status.restype = C.c_int
+        L.vxrt_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.vxrt_version.restype = C.c_char_p
+        _proto = True
+    return L
+
+
+def render(scene, width, height, y0, y1, params, dst_ptr, shadow=0, hits_ptr=None, colors_ptr=None, rays_ptr=None, stream=None):
+    check(_lib().vxrt_render(C.byref(scene), width, height, y0, y1, C.byref(params), int(shadow), dst_ptr, hits_ptr,
+                             colors_ptr, rays_ptr, stream), "vxrt_render")
+
+
+def trace(scene, rays_ptr, n, hits_ptr, mode=MODE_CLOSEST, tmax_ptr=None, stream=None):
+    check(_lib().vxrt_trace(C.byref(scene), rays_ptr, n, tmax_ptr, hits_ptr, mode, stream), "vxrt_trace")
+
+
+def status(stream=None):
+    st = C.c_uint32()
+    check(_lib().vxrt_status(stream, C.byref(st)), "vxrt_status")
+    return st.value
+
+
+def version():
+    return _lib().vxrt_version().decode()

@@ -1,0 +1,113 @@
+"""ctypes binding of libvxrt_scene.so (csrc/scene_builder.cpp): scene construction on the host.
+
+Produces the buffers Tracer::init/setup upload (reference tracer.cpp:124-161,217-241) in the
+reference's byte formats."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib_path
+
+NODE_BYTES, BLAS_BYTES, TRI_BYTES, TRIEX_BYTES, MAT_BYTES = 52, 160, 36, 64, 88
+_BUFFERS = ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex", "triIdx")
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        lib = C.CDLL(lib_path("libvxrt_scene.so"))
+        lib.vxs_scene_create_procedural.restype = C.c_void_p
+        lib.vxs_scene_create_procedural.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.vxs_scene_create_from_tris.restype = C.c_void_p
+        lib.vxs_scene_create_from_tris.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.vxs_scene_load_obj.restype = C.c_void_p
+        lib.vxs_scene_load_obj.argtypes = [C.c_char_p, C.c_uint32]
+        lib.vxs_scene_destroy.argtypes = [C.c_void_p]
+        lib.vxs_scene_buffer.restype = C.c_uint64
+        lib.vxs_scene_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        lib.vxs_scene_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+class Scene:
+    """Host copy of the scene buffers as numpy uint8 arrays (owned by Python after construction)."""
+
+    def __init__(self, buffers, info=None, bounds=None, name=""):
+        self.buffers = {k: np.ascontiguousarray(v, dtype=np.uint8) for k, v in buffers.items()}
+        self.info = info or {}
+        self.bounds = bounds
+        self.name = name
+
+    def __getitem__(self, k):
+        return self.buffers[k]
+
+    @property
+    def n_tris(self):
+        return self.buffers["tri"].size // TRI_BYTES
+
+    @property
+    def n_bvh_nodes(self):
+        return self.buffers["bvh"].size // NODE_BYTES
+
+    @property
+    def n_tlas_nodes(self):
+        return self.buffers["tlas"].size // NODE_BYTES
+
+    @property
+    def n_blas(self):
+        return self.buffers["blas"].size // BLAS_BYTES
+
+    @property
+    def n_mats(self):
+        return self.buffers["mat"].size // MAT_BYTES
+
+    def save(self, path):
+        np.savez_compressed(path, **self.buffers)
+
+    @staticmethod
+    def load(path, name=""):
+        with np.load(path) as z:
+            return Scene({k: z[k] for k in z.files}, name=name)
+
+
+def _from_handle(h, name):
+    lib = _load()
+    if not h:
+        raise RuntimeError("scene construction failed: %s" % name)
+    try:
+        bufs = {}
+        for i, k in enumerate(_BUFFERS):
+            p = C.c_void_p()
+            n = lib.vxs_scene_buffer(h, i, C.byref(p))
+            bufs[k] = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy() if n else np.zeros(0, np.uint8)
+        info = (C.c_uint32 * 6)()
+        bounds = (C.c_float * 6)()
+        lib.vxs_scene_info(h, info, bounds)
+        keys = ("max_depth", "n_leaves", "max_leaf", "n_bvh_nodes", "n_tlas_nodes", "n_tris")
+        return Scene(bufs, dict(zip(keys, list(info))), np.array(list(bounds), np.float32), name)
+    finally:
+        lib.vxs_scene_destroy(h)
+
+
+def procedural(name, a=0, b=0, seed=1):
+    """'cornell' | 'blob' (a = icosphere subdivisions) | 'atrium' (a = level; 8 -> 1,048,576 tris)
+    | 'hairball' (a strands x b segments)."""
+    return _from_handle(_load().vxs_scene_create_procedural(name.encode(), a, b, seed), name)
+
+
+def from_triangles(meshes, transforms=None):
+    """meshes: list of float32 arrays [n_i, 9] (v0,v1,v2).  transforms: optional list of 4x4."""
+    ntris = np.array([len(m) for m in meshes], np.uint32)
+    tris = np.ascontiguousarray(np.concatenate([np.asarray(m, np.float32).reshape(-1, 9) for m in meshes]), np.float32)
+    tr = None
+    if transforms is not None:
+        tr = np.ascontiguousarray(np.stack([np.asarray(t, np.float32).reshape(16) for t in transforms]), np.float32)
+    h = _load().vxs_scene_create_from_tris(len(meshes), ntris.ctypes.data, tris.ctypes.data, None,
+                                           tr.ctypes.data if tr is not None else None, None, None)
+    return _from_handle(h, "triangles")
+
+
+def load_obj(path, instances=1):
+    return _from_handle(_load().vxs_scene_load_obj(str(path).encode(), instances), str(path))

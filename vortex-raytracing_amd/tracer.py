@@ -1,0 +1,122 @@
+"""Host-side mirror of the reference's Tracer (tests/regression/raytracing/tracer.{h,cpp}) written
+against the vx_* API only, so it exercises exactly the calls the reference host program makes:
+init (:90-169) = open device, upload the 4 kernel images, 11 vx_mem_alloc + vx_mem_address;
+setup (:171-260) = 9 vx_copy_to_dev, shader binding table, 4 DCR writes; run (:262-288) =
+vx_upload_bytes(kernel_arg), vx_start, vx_ready_wait, vx_copy_from_dev.
+
+DeviceScene is the equivalent for the vxrt_* direct API: scene buffers as torch uint8 CUDA tensors."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+from . import VXBIN_DIR, runtime, rtapi
+from .scene import NODE_BYTES, BLAS_BYTES, TRI_BYTES, MAT_BYTES
+
+KERNEL_ARG_FMT = "<IIQ" + "Q" * 9 + "I" + "3f3f3f3f" + "2f" + "II" + "3f3f3f3f" + "4xQ"
+assert struct.calcsize(KERNEL_ARG_FMT) == 216  # raytracing/common.h:164-195
+
+# main.cpp:34-41
+DEFAULT_LIGHT_POS = (0.0, 10.0, -10.0)
+DEFAULT_LIGHT_COLOR = (1.0, 1.0, 1.0)
+DEFAULT_AMBIENT = (0.4, 0.4, 0.4)
+DEFAULT_BACKGROUND = (0.4, 0.35, 0.25)
+
+
+class Tracer:
+    def __init__(self, width, height, samples_per_pixel=1, max_depth=1):
+        self.width, self.height = width, height
+        self.spp, self.max_depth = samples_per_pixel, max_depth
+        self.dev = None
+        self.bufs = {}
+        self.args = None
+
+    def init(self, scene, vxbin_dir=VXBIN_DIR):
+        self.scene = scene
+        d = self.dev = runtime.Device()
+        self.krnl = d.upload_kernel_file(os.path.join(vxbin_dir, "kernel.vxbin"))
+        self.miss = d.upload_kernel_file(os.path.join(vxbin_dir, "miss.vxbin"))
+        self.closest = d.upload_kernel_file(os.path.join(vxbin_dir, "closest.vxbin"))
+        self.anyhit = d.upload_kernel_file(os.path.join(vxbin_dir, "anyhit.vxbin"))
+        for k in ("tri", "triEx", "triIdx", "tlas", "blas", "bvh", "mat", "tex"):
+            self.bufs[k] = d.mem_alloc(int(scene[k].size), runtime.VX_MEM_READ)
+        # the reference also uploads the un-quantised BVH2-style nodes (tracer.cpp:144-145); the RTU
+        # never reads them, so the mirror allocates a token buffer to keep kernel_arg_t complete
+        self.bufs["bvh2"] = d.mem_alloc(64, runtime.VX_MEM_READ)
+        self.bufs["out"] = d.mem_alloc(self.width * self.height * 4, runtime.VX_MEM_WRITE)
+        self.bufs["sbt"] = d.mem_alloc(32, runtime.VX_MEM_READ)
+        return 0
+
+    def setup(self, light_pos=DEFAULT_LIGHT_POS, light_color=DEFAULT_LIGHT_COLOR, ambient=DEFAULT_AMBIENT,
+              background=DEFAULT_BACKGROUND, row_window=None, shadow=False):
+        d = self.dev
+        for k in ("tri", "triEx", "triIdx", "tlas", "blas", "bvh", "mat", "tex"):
+            self.bufs[k].write(self.scene[k])
+        sbt = struct.pack("<4Q", self.miss.address, self.closest.address, 0, self.anyhit.address)
+        self.bufs["sbt"].write(sbt)
+        a = {k: b.address for k, b in self.bufs.items()}
+        d.dcr_write(runtime.VX_DCR_BASE_RTX_TLAS_PTR, a["tlas"])   # tracer.cpp:252-256 (truncated to 32 bit)
+        d.dcr_write(runtime.VX_DCR_BASE_RTX_BLAS_PTR, a["blas"])
+        d.dcr_write(runtime.VX_DCR_BASE_RTX_BVH_PTR, a["bvh"])
+        d.dcr_write(runtime.VX_DCR_BASE_RTX_TRI_PTR, a["tri"])
+        y0, y1 = row_window if row_window else (0, 0)
+        d.dcr_write(runtime.VX_DCR_HIP_ROW_BEGIN, y0)
+        d.dcr_write(runtime.VX_DCR_HIP_ROW_END, y1)
+        d.dcr_write(runtime.VX_DCR_HIP_SHADOW_RAYS, 1 if shadow else 0)
+        self.kernel_arg = struct.pack(
+            KERNEL_ARG_FMT, self.width, self.height, a["out"], a["tri"], a["triEx"], a["triIdx"], a["mat"], a["tex"],
+            a["bvh2"], a["bvh"], a["blas"], a["tlas"], 0,
+            0.0, 100.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 1.0, 0.0,   # camera_* are unused by the RTU kernel
+            1.0, 1.0, self.spp, self.max_depth, *light_pos, *light_color, *ambient, *background, a["sbt"])
+        return 0
+
+    def run(self):
+        d = self.dev
+        if self.args is not None:
+            self.args.free()
+        self.args = d.upload_bytes(self.kernel_arg)
+        d.start(self.krnl, self.args)
+        d.ready_wait(runtime.VX_MAX_TIMEOUT)
+        raw = self.bufs["out"].read()
+        return np.frombuffer(raw, dtype=np.uint32).reshape(self.height, self.width).copy()
+
+    def close(self):
+        if self.dev is None:
+            return
+        for b in list(self.bufs.values()) + [self.args, self.krnl, self.miss, self.closest, self.anyhit]:
+            if b is not None:
+                b.free()
+        self.bufs = {}
+        self.dev.close()
+        self.dev = None
+
+
+class DeviceScene:
+    """Scene buffers resident in HBM as torch uint8 tensors + the vxrt_scene_t that points at them."""
+
+    def __init__(self, scene, device="cuda:0"):
+        import torch
+        self.t = {k: torch.from_numpy(np.ascontiguousarray(scene[k])).to(device) for k in ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")}
+        s = rtapi.VxrtScene()
+        for k, t in self.t.items():
+            setattr(s, k, t.data_ptr() if t.numel() else None)
+        s.n_tlas_nodes = scene["tlas"].size // NODE_BYTES
+        s.n_blas = scene["blas"].size // BLAS_BYTES
+        s.n_bvh_nodes = scene["bvh"].size // NODE_BYTES
+        s.n_tris = scene["tri"].size // TRI_BYTES
+        s.n_mats = scene["mat"].size // MAT_BYTES
+        s.tex_bytes = scene["tex"].size
+        self.c = s
+        self.device = device
+
+
+def write_ppm(pixels, path):
+    """ASCII P3 writer with the reference's byte order and vertical flip (tracer.cpp:15-33)."""
+    h, w = pixels.shape
+    px = pixels[::-1].reshape(-1)
+    b0, b1, b2 = px & 255, (px >> 8) & 255, (px >> 16) & 255
+    with open(path, "w") as f:
+        f.write("P3\n%d %d\n255\n" % (w, h))
+        # the reference streams float(byte) through operator<<, i.e. "b g r" of the little-endian pixel bytes 2,1,0
+        np.savetxt(f, np.stack([b2, b1, b0], axis=1), fmt="%d")
