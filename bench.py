@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the ray-tracing hot path on MI355X.
+
+Metric (BASELINE.json): Mrays/s (primary + shadow) at 1920x1080 on the 1M-triangle "Sponza-class"
+BVH.  A step = one frame of the RTU test on that scene: camera ray -> closest hit -> Lambert shade
+with one occlusion ray toward the light per hit -> RGB8, i.e. one launch of rt_render_kernel<SHADOW>
+through the C ABI (vxrt_render) on this rank's GPU, scene already resident in HBM.
+
+Multi-GPU (one process per GPU, torch.distributed over RCCL): the reference's own per-pixel
+`for s < samples_per_pixel` loop (kernel.cpp:67-80) is the data-parallel axis -- rank r traces
+sample r of every pixel (weak scaling: one full frame of rays per GPU and step, no data-path
+collective), then ONE gather over xGMI assembles the per-sample frames on rank 0 (north_star:
+"RCCL gather only for final image assembly").  `--shard rows` instead splits ONE frame into
+tile-aligned row bands (strong scaling).  value = rays traced by all ranks / max-over-ranks time.
+
+Prints one JSON line (driver contract) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--level", type=int, default=8, help="atrium tessellation level; 8 -> 1,048,576 triangles")
+    ap.add_argument("--shard", choices=["samples", "rows"], default="samples")
+    ap.add_argument("--no-shadow", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--random-rays", type=int, default=0, help="also time N incoherent random rays (vxrt_trace), reported under extras")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, w, h, budget_s):
+    """The reference's own BVHTraverser (oracle/_ref, kind 'reference') -- or, if that library is
+    absent or exceeds its watchdog, the C restatement (kind 'port') -- timed on this box's host cores
+    over a bounded sample of the same workload: camera rays of every 12th row of the frame (closest
+    hit only; the reference has no shadow rays).  Checker code is used here as the thing timed for
+    the reported baseline only, never for `value`."""
+    import concurrent.futures as cf
+    import numpy as np
+    from oracle import pyoracle as po
+    cores = os.cpu_count() or 1
+    rows = list(range(0, h, 12))
+    rays = np.concatenate([po.camera_rays(w, h, y, y + 1) for y in rows])
+    img = po.Image(scene)
+    chunks = np.array_split(np.arange(len(rays)), cores * 8)
+
+    def run(fn):
+        t0 = time.perf_counter()
+        done = 0
+        with cf.ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL during the foreign call
+            futs = [ex.submit(fn, img, rays[c]) for c in chunks]
+            for f in futs:
+                try:
+                    out, _ = f.result(timeout=max(1.0, 4 * budget_s - (time.perf_counter() - t0)))
+                    done += len(out)
+                except cf.TimeoutError:
+                    return None
+        return done, time.perf_counter() - t0
+
+    kind = "port"
+    res = None
+    if po.have_ref():
+        # size the sample to the time budget from a short probe
+        t0 = time.perf_counter()
+        po.trace_ref(img, rays[:2000])
+        per_ray = (time.perf_counter() - t0) / 2000
+        n = int(min(len(rays), max(4000, budget_s * cores / per_ray)))
+        rays = rays[:n]
+        chunks = np.array_split(np.arange(n), cores * 8)
+        res = run(po.trace_ref)
+        kind = "reference" if res else "port"
+    if res is None:
+        res = run(po.trace_faithful)
+    done, dt = res
+    return {"value": round(done / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": kind,
+            "sample": "%d primary camera rays (every 12th row of the %dx%d frame, closest hit, no shadow rays), %s, %d host threads, %.1f s"
+                      % (done, w, h, "reference sim/simx/rt_traversal.cpp via oracle/_ref" if kind == "reference" else "oracle/rt_oracle.c restatement", cores, dt)}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    vrt = importlib.import_module("vortex-raytracing_amd")
+    rtapi, sharding = vrt.rtapi, vrt.sharding
+
+    W, H = a.width, a.height
+    scene = vrt.scene.procedural("atrium", a.level, 0, 3)
+    ds = vrt.tracer.DeviceScene(scene, dev)
+    shadow = 0 if a.no_shadow else 1
+    params = rtapi.default_shade_params()
+    params.light_pos[:] = (300.0, 480.0, 60.0)   # inside the hall, so shadow rays are real work
+
+    if a.shard == "rows" and world > 1:
+        y0, y1 = sharding.row_bands(H, world)[rank]
+    else:
+        y0, y1 = 0, H
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+    frames = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(2)]
+    counters = torch.zeros(8, dtype=torch.int64, device=dev)
+
+    def launch(buf, count_ptr=None):
+        rtapi.render(ds.c, W, H, y0, y1, params, buf.data_ptr(), shadow, None, None, count_ptr, sptr)
+
+    # rays per step on this rank (primary + shadow), counted once by the kernel itself
+    launch(frames[0], counters.data_ptr())
+    torch.cuda.synchronize()
+    assert rtapi.status(sptr) == 0, "kernel status (traversal stack overflow)"
+    rays_rank = int(counters[0].item())
+    algo = None
+    if hasattr(rtapi, "render_stats"):
+        algo = rtapi.render_stats(ds.c, W, H, y0, y1, params, frames[0].data_ptr(), shadow, sptr)
+
+    gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    gdone = [None, None]   # per framebuffer: event of the last gather that read it
+
+    def step(i, ev=None):
+        b = i & 1
+        buf = frames[b]
+        if gdone[b] is not None:
+            stream.wait_event(gdone[b])        # do not overwrite a frame that is still being gathered
+        if ev is not None:
+            ev[0].record(stream)
+        launch(buf)
+        if ev is not None:
+            ev[1].record(stream)
+        if world > 1:
+            # image assembly overlaps the next step's traversal: the gather runs on its own stream
+            gather_stream.wait_stream(stream)
+            with torch.cuda.stream(gather_stream):
+                if a.shard == "rows":
+                    sharding.gather_frame(buf[y0:y1], H, W, rank, world)
+                else:
+                    out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+                    dist.gather(buf, out, dst=0)
+                gdone[b] = torch.cuda.Event()
+                gdone[b].record(gather_stream)
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i, evs[i])
+    if gather_stream is not None:
+        stream.wait_stream(gather_stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays_rank], dtype=torch.int64, device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_all = int(r.item())
+    else:
+        rays_all = rays_rank
+    assert rtapi.status(sptr) == 0
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps   # HIP events on the launch stream
+
+    extras = {}
+    if a.random_rays and rank == 0:
+        n = a.random_rays
+        g = torch.Generator(device=dev).manual_seed(12345)
+        lo = torch.tensor(scene.bounds[:3], device=dev)
+        hi = torch.tensor(scene.bounds[3:], device=dev)
+        o = lo + (hi - lo) * torch.rand((n, 3), generator=g, device=dev)
+        d = torch.randn((n, 3), generator=g, device=dev)
+        d = d / d.norm(dim=1, keepdim=True)
+        rays = torch.cat([o, d], 1).contiguous()
+        hits = torch.zeros(n * 24, dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            rtapi.trace(ds.c, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(5):
+            rtapi.trace(ds.c, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        extras["random_rays_mrays_s"] = round(n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 1)
+        extras["random_rays_n"] = n
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (primary+shadow) at %dx%d, 1M-tri BVH" % (W, H),
+            "value": round(rays_all * a.steps / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong" if (a.shard == "rows" and world > 1) else "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (procedural 'Sponza-class' atrium, seed 3; no Sponza/bunny asset exists offline)",
+            "config": {"workload": "configs[2]: Sponza-class %d tris, %dx%d, primary + 1 shadow ray per hit%s" % (scene.n_tris, W, H, "" if shadow else " (shadow disabled)"),
+                       "rays_per_step_per_gpu": rays_rank,
+                       "parallelism": ("spp-sharded x%d: one sample (full frame) per GPU, RCCL gather of frames to rank 0" % world) if a.shard == "samples"
+                                      else ("row bands x%d of one frame, RCCL gather to rank 0" % world),
+                       "bvh_nodes": scene.n_bvh_nodes, "bvh_depth": scene.info.get("max_depth")},
+        }
+        bytes_launch = None
+        if algo is not None:
+            bytes_launch = algo["bytes"]
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": "rt_render_kernel<%s>" % ("true" if shadow else "false"), "kernel_ms": round(kern_ms, 4)}
+        if bytes_launch:
+            ach = bytes_launch / (kern_ms * 1e-3) / 1e9
+            roof.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": bytes_launch,
+                         "bytes_per_ray": round(bytes_launch / rays_rank, 1), "counts": algo})
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                roof["traffic"] = json.load(open(tf)).get("bytes_per_launch")
+            except Exception:
+                pass
+        out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, W, H, a.cpu_seconds)
+        if extras:
+            out["extras"] = extras
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
