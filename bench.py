@@ -47,14 +47,18 @@ def parse():
 def cpu_baseline(scene, w, h, budget_s):
     """The reference's own BVHTraverser (oracle/_ref, kind 'reference') -- or, if that library is
     absent or exceeds its watchdog, the C restatement (kind 'port') -- timed on this box's host cores
-    over a bounded sample of the same workload: camera rays of every 12th row of the frame (closest
+    over a bounded sample of the same workload: camera rays of every 3rd row of the frame (truncated to the time budget) (closest
     hit only; the reference has no shadow rays).  Checker code is used here as the thing timed for
     the reported baseline only, never for `value`."""
     import concurrent.futures as cf
     import numpy as np
     from oracle import pyoracle as po
-    cores = os.cpu_count() or 1
-    rows = list(range(0, h, 12))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))   # the box's CPU share for one GPU is 16 cores
+    rows = list(range(0, h, 3))
     rays = np.concatenate([po.camera_rays(w, h, y, y + 1) for y in rows])
     img = po.Image(scene)
     chunks = np.array_split(np.arange(len(rays)), cores * 8)
@@ -88,7 +92,7 @@ def cpu_baseline(scene, w, h, budget_s):
         res = run(po.trace_faithful)
     done, dt = res
     return {"value": round(done / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": kind,
-            "sample": "%d primary camera rays (every 12th row of the %dx%d frame, closest hit, no shadow rays), %s, %d host threads, %.1f s"
+            "sample": "%d primary camera rays (rows 0,3,6,.. of the %dx%d frame until the time budget, closest hit, no shadow rays), %s, %d host threads, %.1f s"
                       % (done, w, h, "reference sim/simx/rt_traversal.cpp via oracle/_ref" if kind == "reference" else "oracle/rt_oracle.c restatement", cores, dt)}
 
 

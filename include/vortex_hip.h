@@ -186,6 +186,14 @@ int vxrt_render(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint
                 vxrt_hit_t* hits /* optional, W*H */, float* colors /* optional, 3*W*H */,
                 unsigned long long* rays_traced, void* stream);
 
+/* vxrt_render with the fetch counters compiled in (diagnostic build of the same kernel, never
+ * timed): counters = device u64[7]: rays, node fetches, instance fetches, triangle fetches,
+ * shaded hits, textured hits, pixels written.  Counts are what the reference logs per ray in
+ * RT_mem_accesses (rt_traversal.cpp:54,116,148,158) without its restart re-reads. */
+int vxrt_render_stats(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                      const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
+                      unsigned long long* counters, void* stream);
+
 /* Trace n rays (6 floats each: origin, direction) read from HBM, write n hit records.
  * tmax: optional per-ray upper bound (NULL = 1e30). */
 int vxrt_trace(const vxrt_scene_t* scene, const float* rays, uint64_t n, const float* tmax,

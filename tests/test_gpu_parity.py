@@ -181,3 +181,23 @@ def test_shadow_rays_extension(vrt, po, gpu_device):
     rcol = rcol.reshape(-1, 3)[hit_mask]
     np.testing.assert_allclose(col[~occluded], rcol[~occluded], rtol=COLOR_RTOL)
     assert (col[occluded] <= rcol[occluded] + 1e-7).all()
+
+
+def test_fetch_counters_equal_oracle_counts(vrt, po, gpu_device):
+    """The counting build of the render kernel reports N_node / N_inst / N_tri per launch (inputs of
+    roofline.achieved): they must equal what the canonical CPU restatement counts on the same frame."""
+    import torch
+    sc = vrt.scene.procedural("atrium", 5, 0, 3)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    w, h = 160, 96
+    px = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
+    c = vrt.rtapi.render_stats(ds.c, w, h, 0, h, vrt.rtapi.default_shade_params(), px.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    rays = po.camera_rays(w, h)
+    hits, st = po.trace_canonical(sc, rays)
+    assert c["rays"] == w * h and c["pixels"] == w * h
+    assert c["node_fetches"] == st["node_reads"]
+    assert c["inst_fetches"] == st["inst_reads"]
+    assert c["tri_fetches"] == st["tri_reads"]
+    assert c["shaded_hits"] == int((hits["dist"] < 1e29).sum())
+    rpx, _, _ = po.render(sc, w, h)
+    assert np.array_equal(px.cpu().numpy().view(np.uint32), rpx)

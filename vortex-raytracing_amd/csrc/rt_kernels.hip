@@ -135,10 +135,14 @@ __device__ __forceinline__ void eval_children(const uint32_t* w, float px, float
   }
 }
 
+// per-lane fetch counters of the STATS build (algorithmic bytes): what the
+// reference logs in RT_mem_accesses (rt_traversal.cpp:54,116,148,158), without restart re-reads
+struct Fetches { unsigned node = 0, inst = 0, tri = 0; };
+
 // One closest-hit (or any-hit) query.  Returns true if a candidate was accepted.
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool STATS = false>
 __device__ bool trace_ray(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
-                          float tmax, HitRec& hit, uint32_t* status) {
+                          float tmax, HitRec& hit, uint32_t* status, Fetches* fx = nullptr) {
   // world-space ray (TLAS nodes) and object-space ray (BLAS nodes), with reciprocals
   const float wix = 1.0f / dx, wiy = 1.0f / dy, wiz = 1.0f / dz;
   float cox = ox, coy = oy, coz = oz, cdx = dx, cdy = dy, cdz = dz;
@@ -167,6 +171,7 @@ __device__ bool trace_ray(const SceneDev& sc, float ox, float oy, float oz, floa
     uint32_t w[RT_NODE_DWORDS];
 #pragma unroll
     for (int i = 0; i < RT_NODE_DWORDS; ++i) w[i] = np[i];
+    if (STATS) fx->node++;
 
     const float px = __uint_as_float(w[0]), py = __uint_as_float(w[1]), pz = __uint_as_float(w[2]);
     const int ex = (int)(int8_t)(w[3] & 0xff), ey = (int)(int8_t)((w[3] >> 8) & 0xff), ez = (int)(int8_t)((w[3] >> 16) & 0xff);
@@ -202,6 +207,7 @@ __device__ bool trace_ray(const SceneDev& sc, float ox, float oy, float oz, floa
       uint32_t bw[13];
 #pragma unroll
       for (int i = 0; i < 13; ++i) bw[i] = bp[i];
+      if (STATS) fx->inst++;
       const float m00 = __uint_as_float(bw[1]), m01 = __uint_as_float(bw[2]), m02 = __uint_as_float(bw[3]), m03 = __uint_as_float(bw[4]);
       const float m10 = __uint_as_float(bw[5]), m11 = __uint_as_float(bw[6]), m12 = __uint_as_float(bw[7]), m13 = __uint_as_float(bw[8]);
       const float m20 = __uint_as_float(bw[9]), m21 = __uint_as_float(bw[10]), m22 = __uint_as_float(bw[11]), m23 = __uint_as_float(bw[12]);
@@ -227,6 +233,7 @@ __device__ bool trace_ray(const SceneDev& sc, float ox, float oy, float oz, floa
         float t[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) t[j] = tp[j];
+        if (STATS) fx->tri++;
         float bx, by, bz;
         float d = ray_tri(cox, coy, coz, cdx, cdy, cdz, t, bx, by, bz);
         if (d < hit.dist) {
@@ -262,10 +269,11 @@ struct ShadeParams { float amb[3], lcol[3], lpos[3], bg[3]; uint32_t max_depth; 
 
 __device__ __forceinline__ uint32_t f2u_x86(float f) { return (uint32_t)(long long)f; } // rtx_shading.h:7-8 as x86-64 g++ lowers it
 
-template <bool SHADOW>
+template <bool SHADOW, bool STATS = false>
 __device__ void shade(const SceneDev& sc, const ShadeParams& p, float ox, float oy, float oz,
                       float dx, float dy, float dz, const HitRec& hit, bool found,
-                      float& r, float& g, float& b, uint32_t* status, unsigned& extra_rays) {
+                      float& r, float& g, float& b, uint32_t* status, unsigned& extra_rays,
+                      Fetches* fx = nullptr, unsigned* textured = nullptr) {
   if (!found) { r = p.bg[0]; g = p.bg[1]; b = p.bg[2]; return; }
   const uint32_t* bp = sc.blas + (size_t)hit.blasIdx * (RT_BLAS_STRIDE / 4);
   const rt_triex_t te = sc.triEx[hit.triIdx];
@@ -291,6 +299,7 @@ __device__ void shade(const SceneDev& sc, const ShadeParams& p, float ox, float 
   const float v = te.uv1[1] * hit.bx + te.uv2[1] * hit.by + te.uv0[1] * hit.bz;
   float cr, cg, cb;
   if (mat->diffuse_tex_id >= 0) {  // :72-77, texSample rtx_shading.h:5-18, RGB8toRGB32F common.h:156-162
+    if (STATS) *textured += 1;
     const uint32_t tw = mat->tex_width, th = mat->tex_height;
     uint32_t iu = f2u_x86(u * (float)tw), iv = f2u_x86(v * (float)th);
     iu %= tw; iv %= th;
@@ -313,7 +322,7 @@ __device__ void shade(const SceneDev& sc, const ShadeParams& p, float ox, float 
     // extension (no reference counterpart): one occlusion ray toward the light; occluded -> no
     // direct term.  Origin pushed 1e-3 along L like the reference's mirror bounce (closest.cpp:104).
     HitRec sh;
-    bool occ = trace_ray<true>(sc, Ix + Lx * 0.001f, Iy + Ly * 0.001f, Iz + Lz * 0.001f, Lx, Ly, Lz, dist, sh, status);
+    bool occ = trace_ray<true, STATS>(sc, Ix + Lx * 0.001f, Iy + Ly * 0.001f, Iz + Lz * 0.001f, Lx, Ly, Lz, dist, sh, status, fx);
     extra_rays += 1;
     if (occ) NdotL = 0.0f;
   }
@@ -356,7 +365,7 @@ __device__ __forceinline__ void generate_ray(uint32_t x, uint32_t y, uint32_t W,
 }
 
 // One wavefront == one 8x8 tile (block of the reference grid); 4 tiles per 256-thread workgroup.
-template <bool SHADOW>
+template <bool SHADOW, bool STATS = false>
 __global__ __launch_bounds__(256) void rt_render_kernel(SceneDev sc, ShadeParams p, uint32_t W, uint32_t H,
                                                         uint32_t y0, uint32_t tiles_x, uint32_t n_tiles,
                                                         uint32_t y1, uint32_t* __restrict__ dst,
@@ -369,25 +378,32 @@ __global__ __launch_bounds__(256) void rt_render_kernel(SceneDev sc, ShadeParams
   const uint32_t x = tx * 8u + (lane & 7u);
   const uint32_t y = y0 + ty * 8u + (lane >> 3);
   const bool active = (x < W) && (y < y1);   // kernel.cpp:62,101
-  unsigned nrays = 0;
+  unsigned nrays = 0, nhit = 0, ntex = 0;
+  Fetches fx;
   if (active) {
     float ox, oy, oz, dx, dy, dz;
     generate_ray(x, y, W, H, ox, oy, oz, dx, dy, dz);
     HitRec hit;
-    bool found = trace_ray<false>(sc, ox, oy, oz, dx, dy, dz, RT_LARGE_FLOAT, hit, status);
+    bool found = trace_ray<false, STATS>(sc, ox, oy, oz, dx, dy, dz, RT_LARGE_FLOAT, hit, status, &fx);
     nrays = 1;
+    nhit = found ? 1u : 0u;
     float r, g, b;
-    shade<SHADOW>(sc, p, ox, oy, oz, dx, dy, dz, hit, found, r, g, b, status, nrays);
+    shade<SHADOW, STATS>(sc, p, ox, oy, oz, dx, dy, dz, hit, found, r, g, b, status, nrays, &fx, &ntex);
     const size_t idx = (size_t)x + (size_t)y * W;
     dst[idx] = pack_rgb8(r, g, b);
     if (hits) hits[idx] = hit;
     if (colors) { colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b; }
   }
   if (rays_traced) {
-    // wave-level reduction, one atomic per wavefront
-    unsigned s = nrays;
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if (lane == 0 && s) atomicAdd(rays_traced, (unsigned long long)s);
+    // wave-level reduction, one atomic per wavefront and counter.  STATS build: rays_traced[0..6] =
+    // rays, node fetches, instance fetches, triangle fetches, shaded hits, textured hits, pixels
+    unsigned v[7] = {nrays, fx.node, fx.inst, fx.tri, nhit, ntex, active ? 1u : 0u};
+#pragma unroll
+    for (int k = 0; k < (STATS ? 7 : 1); ++k) {
+      unsigned s = v[k];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+      if (lane == 0 && s) atomicAdd(rays_traced + k, (unsigned long long)s);
+    }
   }
 }
 
@@ -465,6 +481,40 @@ int vxrt_render(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint
   else
     hipLaunchKernelGGL(rt_render_kernel<false>, grid, block, 0, s, sc, p, width, height, y0, tiles_x, n_tiles, y1,
                        dst, (HitRec*)hits, colors, rays_traced, st);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Same launch as vxrt_render with the fetch counters compiled in (slower; never the timed path).
+// counters: device u64[7] = rays, node fetches, instance fetches, triangle fetches, shaded hits,
+// textured hits, pixels written -- the inputs of the algorithmic-bytes formula.
+int vxrt_render_stats(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                      const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
+                      unsigned long long* counters, void* stream) {
+  SceneDev sc;
+  if (check_scene(scene, &sc) != 0 || !params || !dst || !counters) return -1;
+  if (!scene->triEx || !scene->mat || scene->n_mats == 0) return -1;
+  if (width == 0 || height == 0 || y0 > y1 || y1 > height) return -1;
+  if (y0 == y1) return 0;
+  uint32_t* st = status_word();
+  if (!st) return -1;
+  ShadeParams p;
+  for (int i = 0; i < 3; ++i) {
+    p.amb[i] = params->ambient[i]; p.lcol[i] = params->light_color[i];
+    p.lpos[i] = params->light_pos[i]; p.bg[i] = params->background[i];
+  }
+  p.max_depth = params->max_depth;
+  const uint32_t tiles_x = (width + 7) / 8, tiles_y = (y1 - y0 + 7) / 8;
+  const uint64_t n_tiles64 = (uint64_t)tiles_x * tiles_y;
+  if (n_tiles64 > 0x7fffffffull) return -1;
+  const uint32_t n_tiles = (uint32_t)n_tiles64;
+  dim3 grid((n_tiles + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (shadow)
+    hipLaunchKernelGGL((rt_render_kernel<true, true>), grid, block, 0, s, sc, p, width, height, y0, tiles_x, n_tiles, y1,
+                       dst, (HitRec*)nullptr, (float*)nullptr, counters, st);
+  else
+    hipLaunchKernelGGL((rt_render_kernel<false, true>), grid, block, 0, s, sc, p, width, height, y0, tiles_x, n_tiles, y1,
+                       dst, (HitRec*)nullptr, (float*)nullptr, counters, st);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

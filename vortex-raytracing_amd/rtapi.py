@@ -41,6 +41,9 @@ def _lib():
         L.vxrt_render.restype = C.c_int
         L.vxrt_render.argtypes = [C.POINTER(VxrtScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vxrt_render_stats.restype = C.c_int
+        L.vxrt_render_stats.argtypes = [C.POINTER(VxrtScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vxrt_trace.restype = C.c_int
         L.vxrt_trace.argtypes = [C.POINTER(VxrtScene), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.vxrt_status.restype = C.c_int
@@ -53,6 +56,30 @@ def _lib():
 def render(scene, width, height, y0, y1, params, dst_ptr, shadow=0, hits_ptr=None, colors_ptr=None, rays_ptr=None, stream=None):
     check(_lib().vxrt_render(C.byref(scene), width, height, y0, y1, C.byref(params), int(shadow), dst_ptr, hits_ptr,
                              colors_ptr, rays_ptr, stream), "vxrt_render")
+
+
+STAT_KEYS = ("rays", "node_fetches", "inst_fetches", "tri_fetches", "shaded_hits", "textured_hits", "pixels")
+
+
+def algorithmic_bytes(c):
+    """SURVEY.md s8d per-ray formula summed over one launch of the render kernel: 52 B per node and
+    per instance record fetched, 36 B per triangle tested, 64 B triEx + 88 B material (+4 B texel)
+    per shaded hit, 4 B per pixel written.  Rays are generated in registers and hit records stay in
+    registers, so the formula's 24 B ray read / 24 B hit write do not apply to this kernel."""
+    return (52 * (c["node_fetches"] + c["inst_fetches"]) + 36 * c["tri_fetches"]
+            + (64 + 88) * c["shaded_hits"] + 4 * c["textured_hits"] + 4 * c["pixels"])
+
+
+def render_stats(scene, width, height, y0, y1, params, dst_ptr, shadow=0, stream=None):
+    """Runs the counting build of the render kernel once; returns the counters + algorithmic bytes."""
+    import torch
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda:%d" % torch.cuda.current_device())
+    check(_lib().vxrt_render_stats(C.byref(scene), width, height, y0, y1, C.byref(params), int(shadow), dst_ptr,
+                                   cnt.data_ptr(), stream), "vxrt_render_stats")
+    torch.cuda.synchronize()
+    c = dict(zip(STAT_KEYS, [int(v) for v in cnt[:7].tolist()]))
+    c["bytes"] = algorithmic_bytes(c)
+    return c
 
 
 def trace(scene, rays_ptr, n, hits_ptr, mode=MODE_CLOSEST, tmax_ptr=None, stream=None):
