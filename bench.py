@@ -135,7 +135,7 @@ def main():
     counters = torch.zeros(8, dtype=torch.int64, device=dev)
 
     def launch(buf, count_ptr=None):
-        rtapi.render(ds.c, W, H, y0, y1, params, buf.data_ptr(), shadow, None, None, count_ptr, sptr)
+        rtapi.render(ds.accel, W, H, y0, y1, params, buf.data_ptr(), shadow, None, None, count_ptr, sptr)
 
     # rays per step on this rank (primary + shadow), counted once by the kernel itself
     launch(frames[0], counters.data_ptr())
@@ -144,7 +144,7 @@ def main():
     rays_rank = int(counters[0].item())
     algo = None
     if hasattr(rtapi, "render_stats"):
-        algo = rtapi.render_stats(ds.c, W, H, y0, y1, params, frames[0].data_ptr(), shadow, sptr)
+        algo = rtapi.render_stats(ds.accel, W, H, y0, y1, params, frames[0].data_ptr(), shadow, sptr)
 
     gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     gdone = [None, None]   # per framebuffer: event of the last gather that read it
@@ -212,12 +212,12 @@ def main():
         rays = torch.cat([o, d], 1).contiguous()
         hits = torch.zeros(n * 24, dtype=torch.uint8, device=dev)
         for _ in range(2):
-            rtapi.trace(ds.c, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
+            rtapi.trace(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(5):
-            rtapi.trace(ds.c, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
+            rtapi.trace(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
         e1.record(stream)
         torch.cuda.synchronize()
         extras["random_rays_mrays_s"] = round(n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 1)

@@ -177,11 +177,21 @@ typedef struct {
 #define VXRT_MODE_CLOSEST 0 /* reference semantics: global closest hit, reference tie order */
 #define VXRT_MODE_ANY 1     /* occlusion: stop at first accepted candidate (extension) */
 
+/* Device-side acceleration layout built ONCE per scene from the reference-format buffers above
+ * (decoded child boxes, inlined leaf descriptors, edge-form triangles).  The build
+ * validates every index the traversal can follow and fails (-1) on a malformed tree instead of
+ * letting a kernel fault.  The vxrt_scene_t buffers must stay alive and unchanged while the accel
+ * is in use (shading reads blas/triEx/mat/tex from them).  Synchronous with respect to `stream`. */
+typedef struct vxrt_accel vxrt_accel_t;
+int vxrt_accel_build(const vxrt_scene_t* scene, void* stream, vxrt_accel_t** out);
+int vxrt_accel_destroy(vxrt_accel_t* accel);
+uint64_t vxrt_accel_bytes(const vxrt_accel_t* accel);
+
 /* Render rows [y0,y1) of the RTU test's frame: camera ray (kernel.cpp:28-39) -> closest hit ->
  * closest/miss shade -> RGB8 pack -> dst[x + y*W] (kernel.cpp:95-106).  `dst` points at pixel
  * (0,0) of the full W x H frame.  shadow != 0 adds one occlusion ray per hit (extension).
  * rays_traced (device u64, may be NULL) is atomically incremented by the number of rays traced. */
-int vxrt_render(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+int vxrt_render(const vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                 const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                 vxrt_hit_t* hits /* optional, W*H */, float* colors /* optional, 3*W*H */,
                 unsigned long long* rays_traced, void* stream);
@@ -189,20 +199,22 @@ int vxrt_render(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint
 /* vxrt_render with the fetch counters compiled in (diagnostic build of the same kernel, never
  * timed): counters = device u64[7]: rays, node fetches, instance fetches, triangle fetches,
  * shaded hits, textured hits, pixels written.  Counts are what the reference logs per ray in
- * RT_mem_accesses (rt_traversal.cpp:54,116,148,158) without its restart re-reads. */
-int vxrt_render_stats(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+ * RT_mem_accesses (rt_traversal.cpp:54,116,148,158) without its restart re-reads.
+ * tile_clock (optional): device u64[2 * tiles]: constant-rate (100 MHz) clock at begin / end of
+ * every 8x8 tile's wavefront, to study load balance. */
+int vxrt_render_stats(const vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                       const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
-                      unsigned long long* counters, void* stream);
+                      unsigned long long* counters, unsigned long long* tile_clock, void* stream);
 
 /* Trace n rays (6 floats each: origin, direction) read from HBM, write n hit records.
  * tmax: optional per-ray upper bound (NULL = 1e30). */
-int vxrt_trace(const vxrt_scene_t* scene, const float* rays, uint64_t n, const float* tmax,
+int vxrt_trace(const vxrt_accel_t* accel, const float* rays, uint64_t n, const float* tmax,
                vxrt_hit_t* hits, int mode, void* stream);
 
 /* Status word of the last launches on this device: 0 = ok, bit0 = traversal stack overflow
- * (tree deeper than the 32 levels the reference's own trail supports).  Synchronises `stream`. */
+ * (tree deeper than the 32 levels the reference's own trail supports), bit1 = iteration limit.
+ * Synchronises `stream`. */
 int vxrt_status(void* stream, uint32_t* status);
-
 /* Raw device pointer behind a vx_buffer_h of the hip backend (for zero-copy hand-off to RCCL). */
 int vx_hip_buffer_device_ptr(vx_buffer_h hbuffer, void** dev_ptr);
 

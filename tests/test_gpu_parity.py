@@ -28,7 +28,7 @@ def gpu_trace(vrt, dscene, rays, mode=0, tmax=None):
     out = torch.zeros(max(n, 1) * 24, dtype=torch.uint8, device=dscene.device)
     tm = torch.from_numpy(np.ascontiguousarray(tmax, np.float32)).to(dscene.device) if tmax is not None else None
     stream = torch.cuda.current_stream().cuda_stream
-    vrt.rtapi.trace(dscene.c, r.data_ptr() if n else None, n, out.data_ptr() if n else None, mode,
+    vrt.rtapi.trace(dscene.accel, r.data_ptr() if n else None, n, out.data_ptr() if n else None, mode,
                     tm.data_ptr() if tm is not None else None, stream)
     assert vrt.rtapi.status(stream) == 0
     return _hits_np(out)[:n]
@@ -44,7 +44,7 @@ def gpu_render(vrt, dscene, w, h, y0=0, y1=None, shadow=0, params=None):
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     params = params or vrt.rtapi.default_shade_params()
-    vrt.rtapi.render(dscene.c, w, h, y0, y1, params, px.data_ptr(), shadow, hits.data_ptr(), col.data_ptr(), cnt.data_ptr(), stream)
+    vrt.rtapi.render(dscene.accel, w, h, y0, y1, params, px.data_ptr(), shadow, hits.data_ptr(), col.data_ptr(), cnt.data_ptr(), stream)
     assert vrt.rtapi.status(stream) == 0
     return (px.cpu().numpy().view(np.uint32), _hits_np(hits).reshape(h, w), col.cpu().numpy().reshape(h, w, 3), int(cnt.item()))
 
@@ -146,9 +146,56 @@ def test_empty_and_bad_arguments(vrt, golden, gpu_device):
     C.memmove(C.byref(bad), C.byref(ds.c), C.sizeof(bad))
     bad.n_tris = 0
     with pytest.raises(vrt.runtime.VxError):
-        vrt.rtapi.trace(bad, None, 4, None, 0, None, None)
+        vrt.rtapi.accel_build(bad)
     with pytest.raises(vrt.runtime.VxError):
-        vrt.rtapi.trace(ds.c, None, 4, None, 7, None, None)   # unknown mode
+        vrt.rtapi.trace(ds.accel, None, 4, None, 0, None, None)   # n > 0 without buffers
+    with pytest.raises(vrt.runtime.VxError):
+        vrt.rtapi.trace(ds.accel, 1, 4, 1, 7, None, None)         # unknown mode
+    with pytest.raises(vrt.runtime.VxError):
+        vrt.rtapi.trace(None, 1, 4, 1, 0, None, None)             # no accel
+
+
+def test_malformed_trees_are_rejected_at_build_time(vrt, golden, gpu_device):
+    """Every index the traversal can follow is validated when the acceleration layout is built, so a
+    corrupt scene fails on the host (-1) instead of faulting the GPU."""
+    import torch
+    g = golden("teapot")
+    node = np.dtype([("o", "<f4", 3), ("e", "i1", 3), ("imask", "u1"), ("lf", "<u4"), ("ld", "<u4"), ("ch", "u1", (4, 7))])
+
+    def try_build(mut):
+        sc = {k: v.copy() for k, v in g.items() if k in ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")}
+        mut(sc)
+        return vrt.tracer.DeviceScene(sc, gpu_device)
+
+    try_build(lambda sc: None).close()
+    nodes = g["bvh"].view(node)
+    internal = int(np.nonzero(nodes["ld"] == 0)[0][0])
+    leaf = int(np.nonzero(nodes["ld"] != 0)[0][0])
+
+    def child_out_of_range(sc):
+        sc["bvh"].view(node)["lf"][internal] = 0x7FFFFFF0
+
+    def child_before_parent(sc):   # would be a cycle
+        n = sc["bvh"].view(node)
+        i2 = int(np.nonzero((n["ld"] == 0) & (np.arange(len(n)) > 4))[0][0])
+        n["lf"][i2] = 0
+
+    def leaf_past_triangles(sc):
+        sc["bvh"].view(node)["lf"][leaf] = len(sc["tri"]) // 36
+
+    def wrong_kind(sc):
+        sc["bvh"].view(node)["imask"][internal] = 1
+
+    def bad_instance(sc):
+        sc["tlas"].view(node)["ld"][0] = 5
+
+    def bad_bvh_offset(sc):
+        sc["blas"].view(np.uint32)[0] = 0x7FFFFFFF
+
+    for mut in (child_out_of_range, child_before_parent, leaf_past_triangles, wrong_kind, bad_instance, bad_bvh_offset):
+        with pytest.raises(vrt.runtime.VxError):
+            try_build(mut)
+    torch.cuda.synchronize()
 
 
 def test_shadow_rays_extension(vrt, po, gpu_device):
@@ -191,7 +238,7 @@ def test_fetch_counters_equal_oracle_counts(vrt, po, gpu_device):
     ds = vrt.tracer.DeviceScene(sc, gpu_device)
     w, h = 160, 96
     px = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
-    c = vrt.rtapi.render_stats(ds.c, w, h, 0, h, vrt.rtapi.default_shade_params(), px.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    c = vrt.rtapi.render_stats(ds.accel, w, h, 0, h, vrt.rtapi.default_shade_params(), px.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
     rays = po.camera_rays(w, h)
     hits, st = po.trace_canonical(sc, rays)
     assert c["rays"] == w * h and c["pixels"] == w * h

@@ -24,6 +24,7 @@ ARCH = "gfx950"
 
 # -ffp-contract=off is part of the numerical contract of the hit path
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+HIP_FLAGS += os.environ.get("VXRT_EXTRA_HIPFLAGS", "").split()   # experiments only (e.g. -DLDS_STACK=8)
 CXX_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall"]
 
 # fixed VMAs of the four images of the RTU test (tests/regression/raytracing/Makefile:104-107)

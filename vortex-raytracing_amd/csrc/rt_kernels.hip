@@ -22,12 +22,39 @@
 
 #define TLAS_FLAG 0x80000000u
 #define STATUS_STACK_OVERFLOW 1u
+#define STATUS_ITER_LIMIT 2u
+#define STATUS_BAD_SCENE 4u
+
+// ---------------------------------------------------------------------------------------------
+// Device-side acceleration layout, derived once per scene from the reference-format buffers by
+// accel_* kernels below (the reference bytes stay the source of truth):
+//
+//  wide node, 128 B, one per INTERNAL node i of the tlas / bvh buffer (same index i):
+//     float box[4][6]   child k: min.xyz, max.xyz, already decoded with the reference's formula
+//                       origin + ldexp(float(q), e)  (rt_traversal.cpp:61-67) -> bit-identical slabs
+//     uint32 a[4], b[4] child descriptor:
+//        b == 0              internal child, a = node index (bit31 set for TLAS nodes; BLAS
+//                            indices are absolute: bvh_offset of the owning instance added)
+//        1 <= b < 2^31       BLAS leaf child: a = first triangle, b = triangle count
+//        b == 0x80000000     TLAS leaf child (instance): a = blasIdx
+//        b == 0xFFFFFFFF     no child (meta == 0)
+//     -> a leaf never costs a node fetch of its own, and the 4 box tests need no byte unpacking.
+//  wide triangle, 48 B: v0, edge1 = v1 - v0, edge2 = v2 - v0 (the subtractions of
+//     rt_traversal.cpp:272-278 done once), padded so that a triangle is three aligned 16-B loads.
+//  roots: descriptor (a, b) of the TLAS root and of every BLAS root.
+// ---------------------------------------------------------------------------------------------
+#define KIND_INSTANCE 0x80000000u
+#define KIND_NONE 0xFFFFFFFFu
+#define WIDE_DWORDS 32
+#define WTRI_FLOATS 12
 
 struct SceneDev {
-  const uint32_t* tlas;   // 13 dwords per node
-  const uint32_t* bvh;
-  const uint32_t* blas;   // 40 dwords per record
-  const float* tri;       // 9 floats per triangle
+  const uint4* tlas_w;      // wide TLAS nodes
+  const uint4* bvh_w;       // wide BLAS nodes
+  const float4* tri_w;      // wide triangles
+  const uint2* blas_root;   // per instance record: root descriptor
+  uint2 tlas_root;
+  const uint32_t* blas;     // reference blas_node_t records (40 dwords each)
   const rt_triex_t* triEx;
   const rt_material_t* mat;
   const uint8_t* tex;
@@ -38,13 +65,6 @@ struct HitRec { float dist, bx, by, bz; uint32_t blasIdx, triIdx; };
 // libstdc++ std::min / std::max (rt_traversal.cpp:327-337 use them; NaN behaviour is part of parity)
 __device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
-
-__device__ __forceinline__ float ubyte_f(const uint32_t* w, int byte_off) {
-  return (float)((w[byte_off >> 2] >> ((byte_off & 3) * 8)) & 0xffu);
-}
-__device__ __forceinline__ uint32_t ubyte_u(const uint32_t* w, int byte_off) {
-  return (w[byte_off >> 2] >> ((byte_off & 3) * 8)) & 0xffu;
-}
 
 // rt_traversal.cpp:318-339 with idir hoisted (1.0f/rd is recomputed per child there; same value).
 // EXACT selects the libstdc++ min/max forms; the fast form uses v_min/v_max, which differs only
@@ -64,22 +84,18 @@ __device__ __forceinline__ float ray_box(float ox, float oy, float oz, float ix,
     tmin = std_max(tmin, std_min(tz1, tz2));
     tmax = std_min(tmax, std_max(tz1, tz2));
   } else {
-    tmin = fminf(tx1, tx2);
-    tmax = fmaxf(tx1, tx2);
-    tmin = fmaxf(tmin, fminf(ty1, ty2));
-    tmax = fminf(tmax, fmaxf(ty1, ty2));
-    tmin = fmaxf(tmin, fminf(tz1, tz2));
-    tmax = fminf(tmax, fmaxf(tz1, tz2));
+    tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));   // v_min, v_min, v_min, v_max3
+    tmax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
   }
   return (tmax < tmin || tmax <= 0) ? RT_LARGE_FLOAT : tmin;
 }
 
-// rt_traversal.cpp:263-316
+// rt_traversal.cpp:263-316 on a wide triangle (v0, edge1, edge2)
 __device__ __forceinline__ float ray_tri(float ox, float oy, float oz, float dx, float dy, float dz,
-                                         const float* __restrict__ t, float& bx, float& by, float& bz) {
-  float v0x = t[0], v0y = t[1], v0z = t[2];
-  float e1x = t[3] - v0x, e1y = t[4] - v0y, e1z = t[5] - v0z;
-  float e2x = t[6] - v0x, e2y = t[7] - v0y, e2z = t[8] - v0z;
+                                         float4 t0, float4 t1, float4 t2, float& bx, float& by, float& bz) {
+  const float v0x = t0.x, v0y = t0.y, v0z = t0.z;
+  const float e1x = t0.w, e1y = t1.x, e1z = t1.y;
+  const float e2x = t1.z, e2y = t1.w, e2z = t2.x;
   float hx = dy * e2z - dz * e2y;
   float hy = dz * e2x - dx * e2z;
   float hz = dx * e2y - dy * e2x;
@@ -102,42 +118,44 @@ __device__ __forceinline__ float ray_tri(float ox, float oy, float oz, float dx,
   return tf;
 }
 
-struct Cand { float d; uint32_t idx; };
+struct Cand { float d; uint32_t a, b, idx; };
 // visit order: nearer first; equal distance -> higher child index first (stable far->near sort of
 // rt_traversal.cpp:76-78 read from the back).  Filtered children carry d = +inf.
-__device__ __forceinline__ void cmpx(Cand& a, Cand& b) {
-  bool sw = (b.d < a.d) || (b.d == a.d && b.idx > a.idx);
-  Cand ta = a, tb = b;
-  a.d = sw ? tb.d : ta.d; a.idx = sw ? tb.idx : ta.idx;
-  b.d = sw ? ta.d : tb.d; b.idx = sw ? ta.idx : tb.idx;
+__device__ __forceinline__ void cmpx(Cand& x, Cand& y) {
+  const bool sw = (y.d < x.d) || (y.d == x.d && y.idx > x.idx);
+  const Cand tx = x, ty = y;
+  x.d = sw ? ty.d : tx.d; x.a = sw ? ty.a : tx.a; x.b = sw ? ty.b : tx.b; x.idx = sw ? ty.idx : tx.idx;
+  y.d = sw ? tx.d : ty.d; y.a = sw ? tx.a : ty.a; y.b = sw ? tx.b : ty.b; y.idx = sw ? tx.idx : ty.idx;
 }
 
-// Box tests of the <=4 children of an internal node (rt_traversal.cpp:59-74).
+// Box tests of the <=4 children of an internal node (rt_traversal.cpp:59-74) on decoded boxes.
 template <bool EXACT>
-__device__ __forceinline__ void eval_children(const uint32_t* w, float px, float py, float pz, int ex, int ey, int ez,
-                                              float rox, float roy, float roz, float rix, float riy, float riz,
-                                              float hit_dist, Cand* c) {
+__device__ __forceinline__ void eval_children(const uint4* __restrict__ w, float rox, float roy, float roz,
+                                              float rix, float riy, float riz, float hit_dist, Cand* c) {
+  // w[0..5] = 24 box floats (child-major), w[6] = a[4], w[7] = b[4]
+  const uint4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3], q4 = w[4], q5 = w[5], qa = w[6], qb = w[7];
+  const float f[24] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w),
+                       __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w),
+                       __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w),
+                       __uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z), __uint_as_float(q3.w),
+                       __uint_as_float(q4.x), __uint_as_float(q4.y), __uint_as_float(q4.z), __uint_as_float(q4.w),
+                       __uint_as_float(q5.x), __uint_as_float(q5.y), __uint_as_float(q5.z), __uint_as_float(q5.w)};
+  const uint32_t ca[4] = {qa.x, qa.y, qa.z, qa.w}, cb[4] = {qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int b = 24 + 7 * k;
-    const uint32_t meta = ubyte_u(w, b);
-    // :61-67  origin + ldexp(float(q), e)
-    float mnx = px + ldexpf(ubyte_f(w, b + 1), ex);
-    float mny = py + ldexpf(ubyte_f(w, b + 2), ey);
-    float mnz = pz + ldexpf(ubyte_f(w, b + 3), ez);
-    float mxx = px + ldexpf(ubyte_f(w, b + 4), ex);
-    float mxy = py + ldexpf(ubyte_f(w, b + 5), ey);
-    float mxz = pz + ldexpf(ubyte_f(w, b + 6), ez);
-    float d = ray_box<EXACT>(rox, roy, roz, rix, riy, riz, mnx, mny, mnz, mxx, mxy, mxz);
-    bool ok = (meta != 0u) && (d < hit_dist);             // :60, :71
+    const float d = ray_box<EXACT>(rox, roy, roz, rix, riy, riz, f[6 * k], f[6 * k + 1], f[6 * k + 2], f[6 * k + 3], f[6 * k + 4], f[6 * k + 5]);
+    const bool ok = (cb[k] != KIND_NONE) && (d < hit_dist);     // :60, :71
     c[k].d = ok ? d : __builtin_inff();
-    c[k].idx = (uint32_t)k;
+    c[k].a = ca[k]; c[k].b = cb[k]; c[k].idx = (uint32_t)k;
   }
 }
 
 // per-lane fetch counters of the STATS build (algorithmic bytes): what the
-// reference logs in RT_mem_accesses (rt_traversal.cpp:54,116,148,158), without restart re-reads
+// reference logs in RT_mem_accesses (rt_traversal.cpp:54,116,148,158), without restart re-reads.
+// A leaf or instance child still counts as one 52-byte node fetch: the reference reads that node.
 struct Fetches { unsigned node = 0, inst = 0, tri = 0; };
+
+#define ITER_LIMIT (1u << 22)   // exit condition every lane reaches even on a cyclic (corrupt) tree
 
 // One closest-hit (or any-hit) query.  Returns true if a candidate was accepted.
 template <bool ANY_HIT, bool STATS = false>
@@ -152,62 +170,50 @@ __device__ bool trace_ray(const SceneDev& sc, float ox, float oy, float oz, floa
   bool lane_fast = (wix - wix == 0.0f) && (wiy - wiy == 0.0f) && (wiz - wiz == 0.0f) &&
                    (ox - ox == 0.0f) && (oy - oy == 0.0f) && (oz - oz == 0.0f);
 
-  uint32_t stk_node[RT_STACK_ENTRIES];
+  uint32_t stk_a[RT_STACK_ENTRIES], stk_b[RT_STACK_ENTRIES];
   float stk_m[RT_STACK_ENTRIES];
   int sp = 0;
 
   hit.dist = tmax; hit.bx = 0; hit.by = 0; hit.bz = 0; hit.blasIdx = 0; hit.triIdx = 0;
   bool found = false;
   uint32_t blasIdx = 0;
-  uint32_t bvh_off = 0;          // node offset of the instance being traversed
-  uint32_t cur = TLAS_FLAG | 0u; // TLAS root (rt_traversal.cpp:39-40)
+  uint32_t cur_a = sc.tlas_root.x, cur_b = sc.tlas_root.y;   // TLAS root (rt_traversal.cpp:39-40)
   float path_m = -__builtin_inff();
-  bool have = true;
+  uint32_t iters = 0;
 
-  while (have) {
-    const bool top_addr = (cur & TLAS_FLAG) != 0;
-    const uint32_t* np = top_addr ? sc.tlas + (size_t)(cur & ~TLAS_FLAG) * RT_NODE_DWORDS
-                                  : sc.bvh + (size_t)(bvh_off + cur) * RT_NODE_DWORDS;
-    uint32_t w[RT_NODE_DWORDS];
-#pragma unroll
-    for (int i = 0; i < RT_NODE_DWORDS; ++i) w[i] = np[i];
-    if (STATS) fx->node++;
-
-    const float px = __uint_as_float(w[0]), py = __uint_as_float(w[1]), pz = __uint_as_float(w[2]);
-    const int ex = (int)(int8_t)(w[3] & 0xff), ey = (int)(int8_t)((w[3] >> 8) & 0xff), ez = (int)(int8_t)((w[3] >> 16) & 0xff);
-    const bool istop = (w[3] >> 24) == 1u;                   // isTopLevel (:219-221)
-    const uint32_t leftFirst = w[4], leafData = w[5];
-    const bool leaf = istop ? (leafData != 0xffffffffu) : (leafData != 0u); // isLeaf (:223-225)
-    bool descend = false;
-
-    if (!leaf) {
-      const float rox = istop ? ox : cox, roy = istop ? oy : coy, roz = istop ? oz : coz;
-      const float rix = istop ? wix : cix, riy = istop ? wiy : ciy, riz = istop ? wiz : ciz;
+  for (;;) {
+    bool next = false;   // true: (cur_a, cur_b) holds the next work item of this lane
+    if (cur_b == 0u) {
+      // ---- internal node: 4 box tests, order, push the far ones, continue with the nearest ----
+      const bool top = (cur_a & TLAS_FLAG) != 0u;
+      const uint4* np = top ? sc.tlas_w + (size_t)(cur_a & ~TLAS_FLAG) * (WIDE_DWORDS / 4) : sc.bvh_w + (size_t)cur_a * (WIDE_DWORDS / 4);
+      if (STATS) fx->node++;
+      const float rox = top ? ox : cox, roy = top ? oy : coy, roz = top ? oz : coz;
+      const float rix = top ? wix : cix, riy = top ? wiy : ciy, riz = top ? wiz : ciz;
       Cand c[4];
       // wave-uniform choice: v_min/v_max slabs unless some active lane could see a NaN product
-      if (__all(lane_fast)) eval_children<false>(w, px, py, pz, ex, ey, ez, rox, roy, roz, rix, riy, riz, hit.dist, c);
-      else                  eval_children<true>(w, px, py, pz, ex, ey, ez, rox, roy, roz, rix, riy, riz, hit.dist, c);
+      if (__all(lane_fast)) eval_children<false>(np, rox, roy, roz, rix, riy, riz, hit.dist, c);
+      else                  eval_children<true>(np, rox, roy, roz, rix, riy, riz, hit.dist, c);
       int n = (c[0].d < __builtin_inff()) + (c[1].d < __builtin_inff()) + (c[2].d < __builtin_inff()) + (c[3].d < __builtin_inff());
       cmpx(c[0], c[1]); cmpx(c[2], c[3]); cmpx(c[0], c[2]); cmpx(c[1], c[3]); cmpx(c[1], c[2]);
       if (n > 0) {
-        const uint32_t fl = cur & TLAS_FLAG;
         if (sp + 3 > RT_STACK_ENTRIES) { atomicOr(status, STATUS_STACK_OVERFLOW); n = 1; }
         // far first so that the nearest pending sibling is on top (:98-103)
-        if (n > 3) { stk_node[sp] = fl | (leftFirst + c[3].idx); stk_m[sp] = fmaxf(path_m, c[3].d); ++sp; }
-        if (n > 2) { stk_node[sp] = fl | (leftFirst + c[2].idx); stk_m[sp] = fmaxf(path_m, c[2].d); ++sp; }
-        if (n > 1) { stk_node[sp] = fl | (leftFirst + c[1].idx); stk_m[sp] = fmaxf(path_m, c[1].d); ++sp; }
-        cur = fl | (leftFirst + c[0].idx);
+        if (n > 3) { stk_a[sp] = c[3].a; stk_b[sp] = c[3].b; stk_m[sp] = fmaxf(path_m, c[3].d); ++sp; }
+        if (n > 2) { stk_a[sp] = c[2].a; stk_b[sp] = c[2].b; stk_m[sp] = fmaxf(path_m, c[2].d); ++sp; }
+        if (n > 1) { stk_a[sp] = c[1].a; stk_b[sp] = c[1].b; stk_m[sp] = fmaxf(path_m, c[1].d); ++sp; }
+        cur_a = c[0].a; cur_b = c[0].b;
         path_m = fmaxf(path_m, c[0].d);
-        descend = true;
+        next = true;
       }
-    } else if (istop) {
-      // TLAS leaf (:109-121): fetch the instance record, move the ray to object space
-      blasIdx = leafData;
+    } else if (cur_b == KIND_INSTANCE) {
+      // ---- TLAS leaf (:109-121): fetch the instance record, move the ray to object space ----
+      blasIdx = cur_a;
       const uint32_t* bp = sc.blas + (size_t)blasIdx * (RT_BLAS_STRIDE / 4);
       uint32_t bw[13];
 #pragma unroll
       for (int i = 0; i < 13; ++i) bw[i] = bp[i];
-      if (STATS) fx->inst++;
+      if (STATS) { fx->node++; fx->inst++; }
       const float m00 = __uint_as_float(bw[1]), m01 = __uint_as_float(bw[2]), m02 = __uint_as_float(bw[3]), m03 = __uint_as_float(bw[4]);
       const float m10 = __uint_as_float(bw[5]), m11 = __uint_as_float(bw[6]), m12 = __uint_as_float(bw[7]), m13 = __uint_as_float(bw[8]);
       const float m20 = __uint_as_float(bw[9]), m21 = __uint_as_float(bw[10]), m22 = __uint_as_float(bw[11]), m23 = __uint_as_float(bw[12]);
@@ -221,21 +227,20 @@ __device__ bool trace_ray(const SceneDev& sc, float ox, float oy, float oz, floa
       const bool s2 = (cix - cix == 0.0f) && (ciy - ciy == 0.0f) && (ciz - ciz == 0.0f) &&
                       (cox - cox == 0.0f) && (coy - coy == 0.0f) && (coz - coz == 0.0f);
       lane_fast = lane_fast && s2;
-      bvh_off = bw[0];
-      cur = 0u;  // BLAS root; same level, path_m unchanged
-      descend = true;
+      const uint2 r = sc.blas_root[blasIdx];   // BLAS root; same level, path_m unchanged
+      cur_a = r.x; cur_b = r.y;
+      next = true;
     } else {
-      // BLAS leaf (:123-161): triangles in index order, strict '<'
-      const uint32_t triCount = leafData;
+      // ---- BLAS leaf (:123-161): triangles in index order, strict '<' ----
+      if (STATS) fx->node++;
+      const uint32_t leftFirst = cur_a, triCount = cur_b;
       for (uint32_t i = 0; i < triCount; ++i) {
         const uint32_t triIdx = leftFirst + i;
-        const float* tp = sc.tri + (size_t)triIdx * 9;
-        float t[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) t[j] = tp[j];
+        const float4* tp = sc.tri_w + (size_t)triIdx * 3;
+        const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
         if (STATS) fx->tri++;
         float bx, by, bz;
-        float d = ray_tri(cox, coy, coz, cdx, cdy, cdz, t, bx, by, bz);
+        const float d = ray_tri(cox, coy, coz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
         if (d < hit.dist) {
           hit.dist = d; hit.bx = bx; hit.by = by; hit.bz = bz;
           hit.blasIdx = blasIdx; hit.triIdx = triIdx;
@@ -249,14 +254,15 @@ __device__ bool trace_ray(const SceneDev& sc, float ox, float oy, float oz, floa
       if (ANY_HIT && found) break;
     }
 
-    if (!descend) {
-      have = false;
+    if (!next) {
       while (sp > 0) {
         --sp;
         const float m = stk_m[sp];
-        if (m < hit.dist) { cur = stk_node[sp]; path_m = m; have = true; break; }
+        if (m < hit.dist) { cur_a = stk_a[sp]; cur_b = stk_b[sp]; path_m = m; next = true; break; }
       }
+      if (!next) break;
     }
+    if (++iters > ITER_LIMIT) { atomicOr(status, STATUS_ITER_LIMIT); break; }
   }
   if (!found) hit.dist = RT_LARGE_FLOAT;
   return found;
@@ -365,12 +371,16 @@ __device__ __forceinline__ void generate_ray(uint32_t x, uint32_t y, uint32_t W,
 }
 
 // One wavefront == one 8x8 tile (block of the reference grid); 4 tiles per 256-thread workgroup.
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 4
+#endif
 template <bool SHADOW, bool STATS = false>
-__global__ __launch_bounds__(256) void rt_render_kernel(SceneDev sc, ShadeParams p, uint32_t W, uint32_t H,
+__global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_render_kernel(SceneDev sc, ShadeParams p, uint32_t W, uint32_t H,
                                                         uint32_t y0, uint32_t tiles_x, uint32_t n_tiles,
                                                         uint32_t y1, uint32_t* __restrict__ dst,
                                                         HitRec* __restrict__ hits, float* __restrict__ colors,
-                                                        unsigned long long* rays_traced, uint32_t* status) {
+                                                        unsigned long long* rays_traced, uint32_t* status,
+                                                        unsigned long long* tile_clock = nullptr) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (tile >= n_tiles) return;
@@ -378,6 +388,8 @@ __global__ __launch_bounds__(256) void rt_render_kernel(SceneDev sc, ShadeParams
   const uint32_t x = tx * 8u + (lane & 7u);
   const uint32_t y = y0 + ty * 8u + (lane >> 3);
   const bool active = (x < W) && (y < y1);   // kernel.cpp:62,101
+  unsigned long long t_begin = 0;
+  if (STATS && tile_clock) t_begin = wall_clock64();
   unsigned nrays = 0, nhit = 0, ntex = 0;
   Fetches fx;
   if (active) {
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(256) void rt_render_kernel(SceneDev sc, ShadeParams
     if (hits) hits[idx] = hit;
     if (colors) { colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b; }
   }
+  if (STATS && tile_clock && lane == 0) { tile_clock[2 * (size_t)tile] = t_begin; tile_clock[2 * (size_t)tile + 1] = wall_clock64(); }
   if (rays_traced) {
     // wave-level reduction, one atomic per wavefront and counter.  STATS build: rays_traced[0..6] =
     // rays, node fetches, instance fetches, triangle fetches, shaded hits, textured hits, pixels
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(256) void rt_render_kernel(SceneDev sc, ShadeParams
 }
 
 template <bool ANY_HIT>
-__global__ __launch_bounds__(256) void rt_trace_kernel(SceneDev sc, const float* __restrict__ rays, uint64_t n,
+__global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_trace_kernel(SceneDev sc, const float* __restrict__ rays, uint64_t n,
                                                        const float* __restrict__ tmax, HitRec* __restrict__ hits,
                                                        uint32_t* status) {
   const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -421,8 +434,111 @@ __global__ __launch_bounds__(256) void rt_trace_kernel(SceneDev sc, const float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// acceleration-layout build (one pass over the reference-format buffers, validates every index
+// the traversal will follow so that a malformed scene is rejected on the host side instead of
+// faulting the GPU)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float q_decode(float origin, uint32_t q, int e) { return origin + ldexpf((float)q, e); }  // rt_traversal.cpp:61-67
+
+// one thread per reference node of one buffer.  bases/ends: sorted BLAS node ranges (nb of them).
+__global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_nodes, uint4* __restrict__ wide, int is_tlas,
+                                   const uint32_t* __restrict__ bases, const uint32_t* __restrict__ ends, uint32_t nb,
+                                   uint32_t n_tris, uint32_t n_blas, uint32_t* status) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const uint32_t* w = ref + (size_t)i * RT_NODE_DWORDS;
+  const uint32_t imask = w[3] >> 24, leftFirst = w[4], leafData = w[5];
+  uint32_t base = 0, end = n_nodes;
+  if (!is_tlas) {
+    bool in = false;
+    for (uint32_t j = 0; j < nb; ++j) if (i >= bases[j] && i < ends[j]) { base = bases[j]; end = ends[j]; in = true; }
+    if (!in) return;   // node outside every instance's range: unreachable, leave untouched
+  }
+  if (imask != (is_tlas ? 1u : 0u)) return;   // not a node of this kind (e.g. unused tail of the buffer): only reachable nodes are checked, via their parent
+  const bool leaf = is_tlas ? (leafData != 0xffffffffu) : (leafData != 0u);
+  if (leaf) return;
+  const float px = __uint_as_float(w[0]), py = __uint_as_float(w[1]), pz = __uint_as_float(w[2]);
+  const int ex = (int)(int8_t)(w[3] & 0xff), ey = (int)(int8_t)((w[3] >> 8) & 0xff), ez = (int)(int8_t)((w[3] >> 16) & 0xff);
+  float box[24];
+  uint32_t ca[4], cb[4];
+  const uint8_t* bytes = (const uint8_t*)w;
+  for (int k = 0; k < 4; ++k) {
+    const uint8_t* c = bytes + 24 + 7 * k;
+    for (int j = 0; j < 6; ++j) box[6 * k + j] = 0.0f;
+    ca[k] = 0; cb[k] = KIND_NONE;
+    if (c[0] == 0) continue;   // meta (rt_traversal.cpp:60)
+    box[6 * k + 0] = q_decode(px, c[1], ex); box[6 * k + 1] = q_decode(py, c[2], ey); box[6 * k + 2] = q_decode(pz, c[3], ez);
+    box[6 * k + 3] = q_decode(px, c[4], ex); box[6 * k + 4] = q_decode(py, c[5], ey); box[6 * k + 5] = q_decode(pz, c[6], ez);
+    const uint64_t ci64 = (uint64_t)base + leftFirst + (uint32_t)k;   // calcNodePtr(base_ptr, leftFirst + childIdx), :91-92
+    // children are allocated after their parent by the builders (bvh.cpp:94-97, 371-402): requiring
+    // that makes every accepted tree acyclic, so traversal terminates
+    if (ci64 >= end || ci64 <= i) { atomicOr(status, STATUS_BAD_SCENE); continue; }
+    const uint32_t ci = (uint32_t)ci64;
+    const uint32_t* cw = ref + (size_t)ci * RT_NODE_DWORDS;
+    const uint32_t c_imask = cw[3] >> 24, c_lf = cw[4], c_ld = cw[5];
+    if (c_imask != (is_tlas ? 1u : 0u)) { atomicOr(status, STATUS_BAD_SCENE); continue; }
+    if (is_tlas) {
+      if (c_ld != 0xffffffffu) {
+        if (c_ld >= n_blas) { atomicOr(status, STATUS_BAD_SCENE); continue; }
+        ca[k] = c_ld; cb[k] = KIND_INSTANCE;
+      } else { ca[k] = TLAS_FLAG | ci; cb[k] = 0u; }
+    } else {
+      if (c_ld != 0u) {
+        if (c_ld >= 0x80000000u || (uint64_t)c_lf + c_ld > n_tris) { atomicOr(status, STATUS_BAD_SCENE); continue; }
+        ca[k] = c_lf; cb[k] = c_ld;
+      } else { ca[k] = ci; cb[k] = 0u; }
+    }
+  }
+  uint4* o = wide + (size_t)i * (WIDE_DWORDS / 4);
+  for (int v = 0; v < 6; ++v)
+    o[v] = make_uint4(__float_as_uint(box[4 * v]), __float_as_uint(box[4 * v + 1]), __float_as_uint(box[4 * v + 2]), __float_as_uint(box[4 * v + 3]));
+  o[6] = make_uint4(ca[0], ca[1], ca[2], ca[3]);
+  o[7] = make_uint4(cb[0], cb[1], cb[2], cb[3]);
+}
+
+__global__ void accel_tris_kernel(const float* __restrict__ tri, uint32_t n, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* t = tri + (size_t)i * 9;
+  const float v0x = t[0], v0y = t[1], v0z = t[2];
+  // edge1 = v1 - v0, edge2 = v2 - v0 exactly as rt_traversal.cpp:272-278 computes them per test
+  out[(size_t)i * 3 + 0] = make_float4(v0x, v0y, v0z, t[3] - v0x);
+  out[(size_t)i * 3 + 1] = make_float4(t[4] - v0y, t[5] - v0z, t[6] - v0x, t[7] - v0y);
+  out[(size_t)i * 3 + 2] = make_float4(t[8] - v0z, 0.f, 0.f, 0.f);
+}
+
+// root descriptors: thread 0 -> TLAS root, thread 1+j -> BLAS root of instance record j
+__global__ void accel_roots_kernel(const uint32_t* __restrict__ tlas, const uint32_t* __restrict__ bvh, const uint32_t* __restrict__ blas,
+                                   uint32_t n_tlas, uint32_t n_bvh, uint32_t n_blas, uint32_t n_tris, uint2* tlas_root, uint2* blas_root,
+                                   uint32_t* status) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    const uint32_t imask = tlas[3] >> 24, ld = tlas[5];
+    if (imask != 1u) { atomicOr(status, STATUS_BAD_SCENE); *tlas_root = make_uint2(0u, KIND_NONE); }
+    else if (ld != 0xffffffffu) {
+      if (ld >= n_blas) { atomicOr(status, STATUS_BAD_SCENE); *tlas_root = make_uint2(0u, KIND_NONE); }
+      else *tlas_root = make_uint2(ld, KIND_INSTANCE);
+    } else *tlas_root = make_uint2(TLAS_FLAG | 0u, 0u);
+  } else if (t - 1 < n_blas) {
+    const uint32_t j = t - 1;
+    const uint32_t off = blas[(size_t)j * (RT_BLAS_STRIDE / 4)];
+    if (off >= n_bvh) { atomicOr(status, STATUS_BAD_SCENE); blas_root[j] = make_uint2(0u, KIND_NONE); return; }
+    const uint32_t* w = bvh + (size_t)off * RT_NODE_DWORDS;
+    const uint32_t imask = w[3] >> 24, lf = w[4], ld = w[5];
+    if (imask != 0u) { atomicOr(status, STATUS_BAD_SCENE); blas_root[j] = make_uint2(0u, KIND_NONE); }
+    else if (ld != 0u) {
+      if (ld >= 0x80000000u || (uint64_t)lf + ld > n_tris) { atomicOr(status, STATUS_BAD_SCENE); blas_root[j] = make_uint2(0u, KIND_NONE); }
+      else blas_root[j] = make_uint2(lf, ld);
+    } else blas_root[j] = make_uint2(off, 0u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host entry points (C ABI, include/vortex_hip.h level 2)
 // ---------------------------------------------------------------------------------------------
+#include <algorithm>
+#include <vector>
+
 static uint32_t* g_status[16] = {nullptr};
 
 static uint32_t* status_word() {
@@ -435,31 +551,105 @@ static uint32_t* status_word() {
   return g_status[dev];
 }
 
-static int check_scene(const vxrt_scene_t* s, SceneDev* d) {
-  if (!s || !s->tlas || !s->blas || !s->bvh || !s->tri) return -1;
-  if (s->n_tlas_nodes == 0 || s->n_blas == 0 || s->n_bvh_nodes == 0 || s->n_tris == 0) return -1;
-  if (s->n_tlas_nodes >= 0x80000000u || s->n_bvh_nodes >= 0x80000000u) return -1;
-  d->tlas = (const uint32_t*)s->tlas;
-  d->bvh = (const uint32_t*)s->bvh;
-  d->blas = (const uint32_t*)s->blas;
-  d->tri = (const float*)s->tri;
-  d->triEx = (const rt_triex_t*)s->triEx;
-  d->mat = (const rt_material_t*)s->mat;
-  d->tex = (const uint8_t*)s->tex;
-  return 0;
+struct vxrt_accel {
+  SceneDev dev{};
+  vxrt_scene_t ref{};
+  void* tlas_w = nullptr; void* bvh_w = nullptr; void* tri_w = nullptr; void* blas_root = nullptr;
+  int device = 0;
+};
+
+static void accel_free(vxrt_accel* a) {
+  if (!a) return;
+  (void)hipFree(a->tlas_w); (void)hipFree(a->bvh_w); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
+  delete a;
 }
 
 extern "C" {
 
-const char* vxrt_version(void) { return "vortex-rt-mi355x 0.1 (gfx950)"; }
+const char* vxrt_version(void) { return "vortex-rt-mi355x 0.2 (gfx950, wide-node layout)"; }
 
-int vxrt_render(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
-                const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits,
-                float* colors, unsigned long long* rays_traced, void* stream) {
-  SceneDev sc;
-  if (check_scene(scene, &sc) != 0 || !params || !dst) return -1;
-  if (!scene->triEx || !scene->mat || scene->n_mats == 0) return -1;  // shading needs them (closest.cpp:52-55)
+int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
+  if (!s || !out || !s->tlas || !s->blas || !s->bvh || !s->tri) return -1;
+  if (s->n_tlas_nodes == 0 || s->n_blas == 0 || s->n_bvh_nodes == 0 || s->n_tris == 0) return -1;
+  if (s->n_tlas_nodes >= 0x7fffffffu || s->n_bvh_nodes >= 0x7fffffffu || s->n_tris >= 0x7fffffffu) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  // instance node ranges (host side, n_blas is small): sorted unique bvh_offsets
+  std::vector<uint32_t> recs((size_t)s->n_blas * (RT_BLAS_STRIDE / 4));
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;
+  if (hipMemcpy(recs.data(), s->blas, recs.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  std::vector<uint32_t> bases;
+  for (uint32_t j = 0; j < s->n_blas; ++j) {
+    const uint32_t off = recs[(size_t)j * (RT_BLAS_STRIDE / 4)];
+    if (off >= s->n_bvh_nodes) return -1;
+    bases.push_back(off);
+  }
+  std::sort(bases.begin(), bases.end());
+  bases.erase(std::unique(bases.begin(), bases.end()), bases.end());
+  std::vector<uint32_t> ends(bases.size());
+  for (size_t j = 0; j < bases.size(); ++j) ends[j] = j + 1 < bases.size() ? bases[j + 1] : s->n_bvh_nodes;
+
+  auto a = new (std::nothrow) vxrt_accel();
+  if (!a) return -1;
+  a->ref = *s;
+  (void)hipGetDevice(&a->device);
+  uint32_t* d_ranges = nullptr;
+  uint32_t* d_status = nullptr;
+  uint2* d_troot = nullptr;
+  bool ok = hipMalloc(&a->tlas_w, (size_t)s->n_tlas_nodes * WIDE_DWORDS * 4) == hipSuccess &&
+            hipMalloc(&a->bvh_w, (size_t)s->n_bvh_nodes * WIDE_DWORDS * 4) == hipSuccess &&
+            hipMalloc(&a->tri_w, (size_t)s->n_tris * WTRI_FLOATS * 4) == hipSuccess &&
+            hipMalloc(&a->blas_root, (size_t)s->n_blas * sizeof(uint2)) == hipSuccess &&
+            hipMalloc((void**)&d_ranges, bases.size() * 8) == hipSuccess &&
+            hipMalloc((void**)&d_status, 4) == hipSuccess && hipMalloc((void**)&d_troot, sizeof(uint2)) == hipSuccess;
+  uint32_t hstatus = 0;
+  uint2 troot = make_uint2(0u, KIND_NONE);
+  if (ok) {
+    ok = hipMemcpy(d_ranges, bases.data(), bases.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_ranges + bases.size(), ends.data(), ends.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(d_status, 0, 4) == hipSuccess;
+  }
+  if (ok) {
+    const uint32_t nb = (uint32_t)bases.size();
+    hipLaunchKernelGGL(accel_nodes_kernel, dim3((s->n_tlas_nodes + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->tlas, s->n_tlas_nodes,
+                       (uint4*)a->tlas_w, 1, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, s->n_tris, s->n_blas, d_status);
+    hipLaunchKernelGGL(accel_nodes_kernel, dim3((s->n_bvh_nodes + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->bvh, s->n_bvh_nodes,
+                       (uint4*)a->bvh_w, 0, d_ranges, d_ranges + nb, nb, s->n_tris, s->n_blas, d_status);
+    hipLaunchKernelGGL(accel_tris_kernel, dim3((s->n_tris + 255) / 256), dim3(256), 0, st, (const float*)s->tri, s->n_tris, (float4*)a->tri_w);
+    hipLaunchKernelGGL(accel_roots_kernel, dim3((s->n_blas + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->tlas, (const uint32_t*)s->bvh,
+                       (const uint32_t*)s->blas, s->n_tlas_nodes, s->n_bvh_nodes, s->n_blas, s->n_tris, d_troot, (uint2*)a->blas_root, d_status);
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+         hipMemcpy(&hstatus, d_status, 4, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(&troot, d_troot, sizeof troot, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(d_ranges); (void)hipFree(d_status); (void)hipFree(d_troot);
+  if (!ok || hstatus != 0) { accel_free(a); return -1; }   // malformed tree: rejected before any traversal
+  a->dev.tlas_w = (const uint4*)a->tlas_w; a->dev.bvh_w = (const uint4*)a->bvh_w; a->dev.tri_w = (const float4*)a->tri_w;
+  a->dev.blas_root = (const uint2*)a->blas_root; a->dev.tlas_root = troot;
+  a->dev.blas = (const uint32_t*)s->blas; a->dev.triEx = (const rt_triex_t*)s->triEx;
+  a->dev.mat = (const rt_material_t*)s->mat; a->dev.tex = (const uint8_t*)s->tex;
+  *out = a;
+  return 0;
+}
+
+int vxrt_accel_destroy(vxrt_accel_t* a) {
+  if (!a) return 0;
+  accel_free(a);
+  return 0;
+}
+
+uint64_t vxrt_accel_bytes(const vxrt_accel_t* a) {
+  if (!a) return 0;
+  return (uint64_t)a->ref.n_tlas_nodes * WIDE_DWORDS * 4 + (uint64_t)a->ref.n_bvh_nodes * WIDE_DWORDS * 4 +
+         (uint64_t)a->ref.n_tris * WTRI_FLOATS * 4 + (uint64_t)a->ref.n_blas * 8;
+}
+
+static int render_common(const vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                         const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits, float* colors,
+                         unsigned long long* counters, bool stats, void* stream, unsigned long long* tile_clock = nullptr) {
+  if (!a || !params || !dst) return -1;
+  if (!a->ref.triEx || !a->ref.mat || a->ref.n_mats == 0) return -1;  // shading needs them (closest.cpp:52-55)
   if (width == 0 || height == 0 || y0 > y1 || y1 > height) return -1;
+  if (stats && !counters) return -1;
   if (y0 == y1) return 0;
   uint32_t* st = status_word();
   if (!st) return -1;
@@ -475,53 +665,33 @@ int vxrt_render(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint
   const uint32_t n_tiles = (uint32_t)n_tiles64;
   dim3 grid((n_tiles + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (shadow)
-    hipLaunchKernelGGL(rt_render_kernel<true>, grid, block, 0, s, sc, p, width, height, y0, tiles_x, n_tiles, y1,
-                       dst, (HitRec*)hits, colors, rays_traced, st);
-  else
-    hipLaunchKernelGGL(rt_render_kernel<false>, grid, block, 0, s, sc, p, width, height, y0, tiles_x, n_tiles, y1,
-                       dst, (HitRec*)hits, colors, rays_traced, st);
+  const SceneDev& sc = a->dev;
+#define LAUNCH_RENDER(SH, ST) hipLaunchKernelGGL((rt_render_kernel<SH, ST>), grid, block, 0, s, sc, p, width, height, y0, tiles_x, n_tiles, y1, \
+                                                 dst, (HitRec*)hits, colors, counters, st, tile_clock)
+  if (stats) { if (shadow) LAUNCH_RENDER(true, true); else LAUNCH_RENDER(false, true); }
+  else       { if (shadow) LAUNCH_RENDER(true, false); else LAUNCH_RENDER(false, false); }
+#undef LAUNCH_RENDER
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int vxrt_render(const vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits,
+                float* colors, unsigned long long* rays_traced, void* stream) {
+  return render_common(accel, width, height, y0, y1, params, shadow, dst, hits, colors, rays_traced, false, stream);
 }
 
 // Same launch as vxrt_render with the fetch counters compiled in (slower; never the timed path).
 // counters: device u64[7] = rays, node fetches, instance fetches, triangle fetches, shaded hits,
 // textured hits, pixels written -- the inputs of the algorithmic-bytes formula.
-int vxrt_render_stats(const vxrt_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+int vxrt_render_stats(const vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                       const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
-                      unsigned long long* counters, void* stream) {
-  SceneDev sc;
-  if (check_scene(scene, &sc) != 0 || !params || !dst || !counters) return -1;
-  if (!scene->triEx || !scene->mat || scene->n_mats == 0) return -1;
-  if (width == 0 || height == 0 || y0 > y1 || y1 > height) return -1;
-  if (y0 == y1) return 0;
-  uint32_t* st = status_word();
-  if (!st) return -1;
-  ShadeParams p;
-  for (int i = 0; i < 3; ++i) {
-    p.amb[i] = params->ambient[i]; p.lcol[i] = params->light_color[i];
-    p.lpos[i] = params->light_pos[i]; p.bg[i] = params->background[i];
-  }
-  p.max_depth = params->max_depth;
-  const uint32_t tiles_x = (width + 7) / 8, tiles_y = (y1 - y0 + 7) / 8;
-  const uint64_t n_tiles64 = (uint64_t)tiles_x * tiles_y;
-  if (n_tiles64 > 0x7fffffffull) return -1;
-  const uint32_t n_tiles = (uint32_t)n_tiles64;
-  dim3 grid((n_tiles + 3) / 4), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (shadow)
-    hipLaunchKernelGGL((rt_render_kernel<true, true>), grid, block, 0, s, sc, p, width, height, y0, tiles_x, n_tiles, y1,
-                       dst, (HitRec*)nullptr, (float*)nullptr, counters, st);
-  else
-    hipLaunchKernelGGL((rt_render_kernel<false, true>), grid, block, 0, s, sc, p, width, height, y0, tiles_x, n_tiles, y1,
-                       dst, (HitRec*)nullptr, (float*)nullptr, counters, st);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+                      unsigned long long* counters, unsigned long long* tile_clock, void* stream) {
+  return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream, tile_clock);
 }
 
-int vxrt_trace(const vxrt_scene_t* scene, const float* rays, uint64_t n, const float* tmax,
+int vxrt_trace(const vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax,
                vxrt_hit_t* hits, int mode, void* stream) {
-  SceneDev sc;
-  if (check_scene(scene, &sc) != 0 || (n && (!rays || !hits))) return -1;
+  if (!a || (n && (!rays || !hits))) return -1;
   if (mode != VXRT_MODE_CLOSEST && mode != VXRT_MODE_ANY) return -1;
   if (n == 0) return 0;
   if ((n + 255) / 256 > 0x7fffffffull) return -1;
@@ -530,9 +700,9 @@ int vxrt_trace(const vxrt_scene_t* scene, const float* rays, uint64_t n, const f
   dim3 grid((uint32_t)((n + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (mode == VXRT_MODE_ANY)
-    hipLaunchKernelGGL(rt_trace_kernel<true>, grid, block, 0, s, sc, rays, n, tmax, (HitRec*)hits, st);
+    hipLaunchKernelGGL(rt_trace_kernel<true>, grid, block, 0, s, a->dev, rays, n, tmax, (HitRec*)hits, st);
   else
-    hipLaunchKernelGGL(rt_trace_kernel<false>, grid, block, 0, s, sc, rays, n, tmax, (HitRec*)hits, st);
+    hipLaunchKernelGGL(rt_trace_kernel<false>, grid, block, 0, s, a->dev, rays, n, tmax, (HitRec*)hits, st);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

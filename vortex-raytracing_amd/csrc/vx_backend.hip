@@ -41,6 +41,7 @@ struct Alloc {
   uint64_t span = 0;        // block-aligned span in the address space
   void* dptr = nullptr;     // hipMalloc'ed backing store (span bytes)
   bool reserved = false;    // created by mem_reserve (kernel images)
+  uint64_t version = 0;     // bumped by every copy_to_dev into this allocation
   std::vector<uint8_t> shadow;  // host copy for small buffers
 };
 
@@ -64,6 +65,10 @@ struct vx_device {
   unsigned long long last_rays = 0;
   float last_ms = 0.f;
   hipDeviceProp_t prop{};
+  // acceleration layout of the scene last started, rebuilt only when one of the four traversal
+  // buffers was re-uploaded or re-pointed (key = device pointers + upload versions)
+  vxrt_accel_t* accel = nullptr;
+  uint64_t accel_key[12] = {0};
 
   int init() {
     const char* e = std::getenv("VORTEX_HIP_DEVICE");
@@ -83,6 +88,7 @@ struct vx_device {
   ~vx_device() {
     (void)hipSetDevice(hip_dev);
     if (stream) (void)hipStreamSynchronize(stream);   // simx dtor waits for the run (vortex.cpp:69-71)
+    if (accel) (void)vxrt_accel_destroy(accel);
     for (auto& kv : allocs) if (kv.second.dptr) (void)hipFree(kv.second.dptr);
     if (d_rays) (void)hipFree(d_rays);
     if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -138,6 +144,7 @@ struct vx_device {
     if (it == allocs.end()) return -1;
     wait_idle();
     (void)hipSetDevice(hip_dev);
+    if (accel) { (void)vxrt_accel_destroy(accel); accel = nullptr; }   // may reference this buffer
     if (it->second.dptr) (void)hipFree(it->second.dptr);
     used -= it->second.span;
     allocs.erase(it);
@@ -192,6 +199,7 @@ struct vx_device {
     const uint64_t off = va - a->va;
     if (size && hipMemcpy((char*)a->dptr + off, src, size, hipMemcpyHostToDevice) != hipSuccess) return -1;
     if (!a->shadow.empty() && off + size <= a->shadow.size()) std::memcpy(a->shadow.data() + off, src, size);
+    a->version++;
     return 0;
   }
 
@@ -300,9 +308,18 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   if (y1 == 0 || y1 > ka.dst_height) y1 = ka.dst_height;
   if (y0 > y1) y0 = y1;
 
+  const uint64_t key[12] = {(uint64_t)sc.tlas, r_tlas.a->version, (uint64_t)sc.blas, r_blas.a->version, (uint64_t)sc.bvh, r_bvh.a->version,
+                            (uint64_t)sc.tri, r_tri.a->version, (uint64_t)sc.triEx, (uint64_t)sc.mat, (uint64_t)sc.tex,
+                            ((uint64_t)sc.n_bvh_nodes << 32) | sc.n_tris};
+  if (!accel || std::memcmp(key, accel_key, sizeof key) != 0) {
+    if (accel) { (void)vxrt_accel_destroy(accel); accel = nullptr; }
+    if (vxrt_accel_build(&sc, stream, &accel) != 0) { VXLOG("start: scene rejected (malformed BVH: index out of range, wrong node kind or child not after parent)"); return -1; }
+    std::memcpy(accel_key, key, sizeof key);
+  }
+
   if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
   if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
-  int rc = vxrt_render(&sc, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow,
+  int rc = vxrt_render(accel, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow,
                        (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, nullptr, d_rays, stream);
   if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
   if (rc != 0) { VXLOG("start: launch rejected (shape check)"); return -1; }

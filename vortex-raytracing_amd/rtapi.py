@@ -38,14 +38,20 @@ def _lib():
     global _proto
     L = hip_lib()
     if not _proto:
+        L.vxrt_accel_build.restype = C.c_int
+        L.vxrt_accel_build.argtypes = [C.POINTER(VxrtScene), C.c_void_p, C.POINTER(C.c_void_p)]
+        L.vxrt_accel_destroy.restype = C.c_int
+        L.vxrt_accel_destroy.argtypes = [C.c_void_p]
+        L.vxrt_accel_bytes.restype = C.c_uint64
+        L.vxrt_accel_bytes.argtypes = [C.c_void_p]
         L.vxrt_render.restype = C.c_int
-        L.vxrt_render.argtypes = [C.POINTER(VxrtScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+        L.vxrt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vxrt_render_stats.restype = C.c_int
-        L.vxrt_render_stats.argtypes = [C.POINTER(VxrtScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                        C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vxrt_render_stats.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vxrt_trace.restype = C.c_int
-        L.vxrt_trace.argtypes = [C.POINTER(VxrtScene), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.vxrt_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.vxrt_status.restype = C.c_int
         L.vxrt_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.vxrt_version.restype = C.c_char_p
@@ -53,8 +59,24 @@ def _lib():
     return L
 
 
-def render(scene, width, height, y0, y1, params, dst_ptr, shadow=0, hits_ptr=None, colors_ptr=None, rays_ptr=None, stream=None):
-    check(_lib().vxrt_render(C.byref(scene), width, height, y0, y1, C.byref(params), int(shadow), dst_ptr, hits_ptr,
+def accel_build(scene, stream=None):
+    """Build the device-side acceleration layout for a VxrtScene; returns the opaque handle."""
+    h = C.c_void_p()
+    check(_lib().vxrt_accel_build(C.byref(scene), stream, C.byref(h)), "vxrt_accel_build")
+    return h
+
+
+def accel_destroy(accel):
+    if accel:
+        check(_lib().vxrt_accel_destroy(accel), "vxrt_accel_destroy")
+
+
+def accel_bytes(accel):
+    return int(_lib().vxrt_accel_bytes(accel))
+
+
+def render(accel, width, height, y0, y1, params, dst_ptr, shadow=0, hits_ptr=None, colors_ptr=None, rays_ptr=None, stream=None):
+    check(_lib().vxrt_render(accel, width, height, y0, y1, C.byref(params), int(shadow), dst_ptr, hits_ptr,
                              colors_ptr, rays_ptr, stream), "vxrt_render")
 
 
@@ -70,20 +92,26 @@ def algorithmic_bytes(c):
             + (64 + 88) * c["shaded_hits"] + 4 * c["textured_hits"] + 4 * c["pixels"])
 
 
-def render_stats(scene, width, height, y0, y1, params, dst_ptr, shadow=0, stream=None):
-    """Runs the counting build of the render kernel once; returns the counters + algorithmic bytes."""
+def render_stats(accel, width, height, y0, y1, params, dst_ptr, shadow=0, stream=None, tile_clock=False):
+    """Runs the counting build of the render kernel once; returns the counters + algorithmic bytes
+    (and, with tile_clock=True, the [tiles, 2] begin/end 100 MHz clock of every tile's wavefront)."""
     import torch
-    cnt = torch.zeros(8, dtype=torch.int64, device="cuda:%d" % torch.cuda.current_device())
-    check(_lib().vxrt_render_stats(C.byref(scene), width, height, y0, y1, C.byref(params), int(shadow), dst_ptr,
-                                   cnt.data_ptr(), stream), "vxrt_render_stats")
+    dev = "cuda:%d" % torch.cuda.current_device()
+    cnt = torch.zeros(8, dtype=torch.int64, device=dev)
+    n_tiles = ((width + 7) // 8) * ((y1 - y0 + 7) // 8)
+    clk = torch.zeros((n_tiles, 2), dtype=torch.int64, device=dev) if tile_clock else None
+    check(_lib().vxrt_render_stats(accel, width, height, y0, y1, C.byref(params), int(shadow), dst_ptr,
+                                   cnt.data_ptr(), clk.data_ptr() if tile_clock else None, stream), "vxrt_render_stats")
     torch.cuda.synchronize()
     c = dict(zip(STAT_KEYS, [int(v) for v in cnt[:7].tolist()]))
     c["bytes"] = algorithmic_bytes(c)
+    if tile_clock:
+        c["tile_clock"] = clk.cpu().numpy()
     return c
 
 
-def trace(scene, rays_ptr, n, hits_ptr, mode=MODE_CLOSEST, tmax_ptr=None, stream=None):
-    check(_lib().vxrt_trace(C.byref(scene), rays_ptr, n, tmax_ptr, hits_ptr, mode, stream), "vxrt_trace")
+def trace(accel, rays_ptr, n, hits_ptr, mode=MODE_CLOSEST, tmax_ptr=None, stream=None):
+    check(_lib().vxrt_trace(accel, rays_ptr, n, tmax_ptr, hits_ptr, mode, stream), "vxrt_trace")
 
 
 def status(stream=None):

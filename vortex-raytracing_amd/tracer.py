@@ -109,6 +109,20 @@ class DeviceScene:
         s.tex_bytes = scene["tex"].size
         self.c = s
         self.device = device
+        # one-time re-layout on the GPU (decoded boxes, inlined leaves, edge-form triangles)
+        with torch.cuda.device(device):
+            self.accel = rtapi.accel_build(s, torch.cuda.current_stream().cuda_stream)
+
+    def close(self):
+        if getattr(self, "accel", None):
+            rtapi.accel_destroy(self.accel)
+            self.accel = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def write_ppm(pixels, path):
