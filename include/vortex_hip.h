@@ -190,8 +190,11 @@ uint64_t vxrt_accel_bytes(const vxrt_accel_t* accel);
 /* Render rows [y0,y1) of the RTU test's frame: camera ray (kernel.cpp:28-39) -> closest hit ->
  * closest/miss shade -> RGB8 pack -> dst[x + y*W] (kernel.cpp:95-106).  `dst` points at pixel
  * (0,0) of the full W x H frame.  shadow != 0 adds one occlusion ray per hit (extension).
- * rays_traced (device u64, may be NULL) is atomically incremented by the number of rays traced. */
-int vxrt_render(const vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+ * rays_traced (device u64, may be NULL) is atomically incremented by the number of rays traced.
+ * Two launches on `stream`: the persistent traversal kernel leaves 24-byte hit records in a W*H
+ * buffer owned by the accel, the shading kernel turns them into pixels; one render may be in
+ * flight per accel at a time. */
+int vxrt_render(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                 const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                 vxrt_hit_t* hits /* optional, W*H */, float* colors /* optional, 3*W*H */,
                 unsigned long long* rays_traced, void* stream);
@@ -202,7 +205,7 @@ int vxrt_render(const vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
  * RT_mem_accesses (rt_traversal.cpp:54,116,148,158) without its restart re-reads.
  * tile_clock (optional): device u64[2 * tiles]: constant-rate (100 MHz) clock at begin / end of
  * every 8x8 tile's wavefront, to study load balance. */
-int vxrt_render_stats(const vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                       const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                       unsigned long long* counters, unsigned long long* tile_clock, void* stream);
 

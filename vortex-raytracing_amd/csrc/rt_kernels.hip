@@ -275,11 +275,26 @@ struct ShadeParams { float amb[3], lcol[3], lpos[3], bg[3]; uint32_t max_depth; 
 
 __device__ __forceinline__ uint32_t f2u_x86(float f) { return (uint32_t)(long long)f; } // rtx_shading.h:7-8 as x86-64 g++ lowers it
 
-template <bool SHADOW, bool STATS = false>
-__device__ void shade(const SceneDev& sc, const ShadeParams& p, float ox, float oy, float oz,
-                      float dx, float dy, float dz, const HitRec& hit, bool found,
-                      float& r, float& g, float& b, uint32_t* status, unsigned& extra_rays,
-                      Fetches* fx = nullptr, unsigned* textured = nullptr) {
+// Occlusion ray of the shadow extension (no reference counterpart): from the hit point toward the
+// light, origin pushed 1e-3 along L like the reference's mirror bounce (closest.cpp:104), tmax = |L|.
+// I, L and dist are computed exactly as shade_eval computes them.
+__device__ __forceinline__ void shadow_ray(const ShadeParams& p, float ox, float oy, float oz, float dx, float dy, float dz,
+                                           float hit_dist, float& sox, float& soy, float& soz, float& sdx, float& sdy, float& sdz, float& sdist) {
+  const float Ix = ox + dx * hit_dist, Iy = oy + dy * hit_dist, Iz = oz + dz * hit_dist;
+  float Lx = p.lpos[0] - Ix, Ly = p.lpos[1] - Iy, Lz = p.lpos[2] - Iz;
+  const float dist = sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
+  const float il = 1.0f / dist;
+  Lx *= il; Ly *= il; Lz *= il;
+  sox = Ix + Lx * 0.001f; soy = Iy + Ly * 0.001f; soz = Iz + Lz * 0.001f;
+  sdx = Lx; sdy = Ly; sdz = Lz;
+  sdist = dist;
+}
+
+// closest.cpp:57-127 / miss.cpp:9-14.  occluded: result of the shadow extension (false = reference).
+template <bool STATS = false>
+__device__ void shade_eval(const SceneDev& sc, const ShadeParams& p, float ox, float oy, float oz,
+                           float dx, float dy, float dz, const HitRec& hit, bool found, bool occluded,
+                           float& r, float& g, float& b, unsigned* textured = nullptr) {
   if (!found) { r = p.bg[0]; g = p.bg[1]; b = p.bg[2]; return; }
   const uint32_t* bp = sc.blas + (size_t)hit.blasIdx * (RT_BLAS_STRIDE / 4);
   const rt_triex_t te = sc.triEx[hit.triIdx];
@@ -324,14 +339,7 @@ __device__ void shade(const SceneDev& sc, const ShadeParams& p, float ox, float 
   Lx *= il; Ly *= il; Lz *= il;
   const float att = 1.0f / (1.0f + dist * 0.1f);
   float NdotL = std_max(0.0f, Nx * Lx + Ny * Ly + Nz * Lz);
-  if (SHADOW) {
-    // extension (no reference counterpart): one occlusion ray toward the light; occluded -> no
-    // direct term.  Origin pushed 1e-3 along L like the reference's mirror bounce (closest.cpp:104).
-    HitRec sh;
-    bool occ = trace_ray<true, STATS>(sc, Ix + Lx * 0.001f, Iy + Ly * 0.001f, Iz + Lz * 0.001f, Lx, Ly, Lz, dist, sh, status, fx);
-    extra_rays += 1;
-    if (occ) NdotL = 0.0f;
-  }
+  if (occluded) NdotL = 0.0f;   // shadow extension: occluded -> no direct term
   const float dr = cr * (p.amb[0] + att * p.lcol[0] * NdotL);
   const float dg = cg * (p.amb[1] + att * p.lcol[1] * NdotL);
   const float db = cb * (p.amb[2] + att * p.lcol[2] * NdotL);
@@ -344,6 +352,23 @@ __device__ void shade(const SceneDev& sc, const ShadeParams& p, float ox, float 
   r = r + p.bg[0] * thr;                        // :123 (no secondary ray: scene.cpp:96 sets reflectivity 0)
   g = g + p.bg[1] * thr;
   b = b + p.bg[2] * thr;
+}
+
+// shade of the one-tile-per-wave kernel: occlusion query traced inline
+template <bool SHADOW, bool STATS = false>
+__device__ void shade(const SceneDev& sc, const ShadeParams& p, float ox, float oy, float oz,
+                      float dx, float dy, float dz, const HitRec& hit, bool found,
+                      float& r, float& g, float& b, uint32_t* status, unsigned& extra_rays,
+                      Fetches* fx = nullptr, unsigned* textured = nullptr) {
+  bool occ = false;
+  if (SHADOW && found) {
+    float sox, soy, soz, sdx, sdy, sdz, sdist;
+    shadow_ray(p, ox, oy, oz, dx, dy, dz, hit.dist, sox, soy, soz, sdx, sdy, sdz, sdist);
+    HitRec sh;
+    occ = trace_ray<true, STATS>(sc, sox, soy, soz, sdx, sdy, sdz, sdist, sh, status, fx);
+    extra_rays += 1;
+  }
+  shade_eval<STATS>(sc, p, ox, oy, oz, dx, dy, dz, hit, found, occ, r, g, b, textured);
 }
 
 __device__ __forceinline__ uint32_t pack_rgb8(float r, float g, float b) {  // common.h:149-154
@@ -431,6 +456,323 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_trace_kernel(SceneDev
   HitRec hit;
   trace_ray<ANY_HIT>(sc, ox, oy, oz, dx, dy, dz, tmax ? tmax[i] : RT_LARGE_FLOAT, hit, status);
   hits[i] = hit;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent while-while kernel with per-lane dynamic ray fetch.
+//
+// The one-tile-per-wave kernel above is bounded by its slowest lane (rocprof + per-tile clocks: 1 % of
+// the wavefronts live 4x the mean and the second half of a frame runs at half occupancy).  Here a
+// fixed grid of wavefronts pulls rays from one global queue; a lane that finishes its ray takes the
+// next job, so wavefronts stay full and the launch ends within one ray of the last job.  Inside,
+// traversal is "while-while": all lanes with an internal node step together, then all lanes with a
+// leaf, so the two bodies are not serialised for every mixed wavefront.  Primary and occlusion rays
+// of different pixels share a wavefront (any-hit is a per-lane flag).  Per-ray semantics -- and
+// therefore results -- are exactly those of trace_ray; only the schedule differs.
+// ---------------------------------------------------------------------------------------------
+#define KIND_DONE 0xFFFFFFFEu
+#define KIND_IDLE 0xFFFFFFFDu
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 64    // fetch new jobs once this many lanes are idle (64 = whole tiles: coherent primary rays
+                            // lose more from mixed tiles than they gain from refilled lanes; measured)
+#endif
+#ifndef RT_FINISH_MIN
+#define RT_FINISH_MIN 64    // leave the traversal loop once this many lanes have a finished ray
+#endif
+#ifndef RT_WHILE_WHILE
+#define RT_WHILE_WHILE 0    // 1: node steps loop until no lane holds a node before leaves are tested
+#endif
+
+#ifndef RT_CHUNK
+#define RT_CHUNK 64         // jobs reserved per global atomic (one 8x8 tile)
+#endif
+#ifndef QUEUE_SHARDS
+#define QUEUE_SHARDS 8u
+#endif
+#define QUEUE_STRIDE 32u    // one 128-byte line per shard counter
+
+enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2 };
+
+struct PersistArgs {
+  uint32_t W, H, y0, y1, tiles_x;
+  uint32_t total;                 // number of jobs (tiles*64 pixels, or rays)
+  uint32_t* dst; HitRec* hits; float* colors;          // render outputs (hits / colors optional)
+  const float* rays; const float* tmax; int any_hit;   // trace inputs
+  unsigned long long* counters;   // [0] rays (+ STATS: [1..6])
+  uint32_t* status;
+  uint32_t* queue;                // QUEUE_SHARDS counters (QUEUE_STRIDE dwords apart), zeroed by the host before the launch
+  uint32_t per_shard;             // jobs per shard (multiple of 64)
+};
+
+__device__ __forceinline__ bool is_leaf_kind(uint32_t b) { return b - 1u < 0x7fffffffu; }
+__device__ __forceinline__ bool is_work_kind(uint32_t b) { return b <= KIND_INSTANCE; }   // node, leaf or instance
+
+template <int JOB, bool STATS>
+__global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+  const uint32_t lane = threadIdx.x & 63u;
+
+  // ---- per-lane ray state ----
+  float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, wix = 0, wiy = 0, wiz = 0;          // world ray
+  float cox = 0, coy = 0, coz = 0, cdx = 0, cdy = 0, cdz = 0, cix = 0, ciy = 0, ciz = 0;    // object-space ray
+  float hitd = 0, hbx = 0, hby = 0, hbz = 0, path_m = 0;
+  uint32_t hblas = 0, htri = 0, blasIdx = 0, cur_a = 0, cur_b = KIND_IDLE, job = 0, iters = 0;
+  bool found = false, anyhit = false, lane_fast = true, shadow_phase = false;
+  uint32_t stk_a[RT_STACK_ENTRIES], stk_b[RT_STACK_ENTRIES];
+  float stk_m[RT_STACK_ENTRIES];
+  int sp = 0;
+  // wave-uniform job-queue state
+  bool queue_empty = false;
+  uint32_t shard = blockIdx.x % QUEUE_SHARDS;   // blocks b and b+8 share an XCD (observed dispatch order; speed only)
+  uint32_t tries = 0, loc_next = 0, loc_end = 0;
+  Fetches fx;
+  unsigned nrays = 0, nhit = 0;
+
+  // (re)start the lane's traversal at the TLAS root with the world ray in (ox..dz)
+  auto start_ray = [&](float tmax_, bool any_) {
+    wix = 1.0f / dx; wiy = 1.0f / dy; wiz = 1.0f / dz;
+    cox = ox; coy = oy; coz = oz; cdx = dx; cdy = dy; cdz = dz; cix = wix; ciy = wiy; ciz = wiz;
+    lane_fast = (wix - wix == 0.0f) && (wiy - wiy == 0.0f) && (wiz - wiz == 0.0f) &&
+                (ox - ox == 0.0f) && (oy - oy == 0.0f) && (oz - oz == 0.0f);
+    hitd = tmax_; hbx = 0; hby = 0; hbz = 0; hblas = 0; htri = 0; found = false; anyhit = any_;
+    blasIdx = 0; cur_a = sc.tlas_root.x; cur_b = sc.tlas_root.y; path_m = -__builtin_inff(); sp = 0; iters = 0;
+    nrays++;
+  };
+  // next pending work item of this lane, or KIND_DONE when its stack is exhausted
+  auto pop_next = [&]() {
+    cur_b = KIND_DONE;
+    while (sp > 0) {
+      --sp;
+      const float m = stk_m[sp];
+      if (m < hitd) { cur_a = stk_a[sp]; cur_b = stk_b[sp]; path_m = m; break; }
+    }
+  };
+
+  for (;;) {
+    // ================= fetch: hand new jobs to idle lanes =================
+    // Jobs are reserved per wavefront in chunks from one of 8 queue shards (one global atomic per
+    // RT_CHUNK jobs: a single device-scope counter saturates near 90 dequeues/us on MI355X, far below
+    // what per-lane refills would need); lanes then draw from the wavefront's private range.
+    {
+      const unsigned long long idle = __ballot(cur_b == KIND_IDLE);
+      if (!queue_empty && idle != 0ull && (idle == ~0ull || __popcll(idle) >= RT_REFILL_MIN)) {
+        if (loc_next == loc_end) {   // wave-uniform: reserve the next chunk, stealing from other shards when the home shard is dry
+          while (tries < QUEUE_SHARDS) {
+            const uint32_t s_lo = shard * A.per_shard;
+            const uint32_t s_n = s_lo < A.total ? min(A.per_shard, A.total - s_lo) : 0u;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(A.queue + shard * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
+            base = __shfl(base, 0);
+            if (base < s_n) { loc_next = s_lo + base; loc_end = s_lo + min(base + (uint32_t)RT_CHUNK, s_n); break; }
+            shard = (shard + 1u) % QUEUE_SHARDS;
+            ++tries;
+          }
+          if (tries >= QUEUE_SHARDS) queue_empty = true;
+        }
+        const uint32_t avail = loc_end - loc_next;
+        if (avail != 0u && cur_b == KIND_IDLE) {
+          const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+          if (rank < avail) {
+            const uint32_t r = loc_next + rank;
+            job = r;
+            shadow_phase = false;
+            if (JOB == JOB_TRACE) {
+              const float* rp = A.rays + (size_t)r * 6;
+              ox = rp[0]; oy = rp[1]; oz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5];
+              start_ray(A.tmax ? A.tmax[r] : RT_LARGE_FLOAT, A.any_hit != 0);
+            } else {
+              const uint32_t tile = r >> 6, l = r & 63u;
+              const uint32_t x = (tile % A.tiles_x) * 8u + (l & 7u), y = A.y0 + (tile / A.tiles_x) * 8u + (l >> 3);
+              if (x < A.W && y < A.y1) {   // kernel.cpp:62,101
+                generate_ray(x, y, A.W, A.H, ox, oy, oz, dx, dy, dz);
+                start_ray(RT_LARGE_FLOAT, false);
+              }
+            }
+          }
+        }
+        loc_next += min(avail, (uint32_t)__popcll(idle));
+      }
+      if (__ballot(cur_b != KIND_IDLE) == 0ull) {
+        if (queue_empty && loc_next == loc_end) break;
+        continue;
+      }
+    }
+
+    // ================= traverse (while-while) =================
+    for (;;) {
+      // ---- all lanes that hold an internal node ----
+#if RT_WHILE_WHILE
+      while (__any(cur_b == 0u)) {
+#else
+      {
+#endif
+        if (cur_b == 0u) {
+          const bool top = (cur_a & TLAS_FLAG) != 0u;
+          const uint4* np = top ? sc.tlas_w + (size_t)(cur_a & ~TLAS_FLAG) * (WIDE_DWORDS / 4) : sc.bvh_w + (size_t)cur_a * (WIDE_DWORDS / 4);
+          if (STATS) fx.node++;
+          const float rox = top ? ox : cox, roy = top ? oy : coy, roz = top ? oz : coz;
+          const float rix = top ? wix : cix, riy = top ? wiy : ciy, riz = top ? wiz : ciz;
+          Cand c[4];
+          if (__all(lane_fast)) eval_children<false>(np, rox, roy, roz, rix, riy, riz, hitd, c);
+          else                  eval_children<true>(np, rox, roy, roz, rix, riy, riz, hitd, c);
+          int n = (c[0].d < __builtin_inff()) + (c[1].d < __builtin_inff()) + (c[2].d < __builtin_inff()) + (c[3].d < __builtin_inff());
+          cmpx(c[0], c[1]); cmpx(c[2], c[3]); cmpx(c[0], c[2]); cmpx(c[1], c[3]); cmpx(c[1], c[2]);
+          if (n > 0) {
+            if (sp + 3 > RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
+            if (n > 3) { stk_a[sp] = c[3].a; stk_b[sp] = c[3].b; stk_m[sp] = fmaxf(path_m, c[3].d); ++sp; }
+            if (n > 2) { stk_a[sp] = c[2].a; stk_b[sp] = c[2].b; stk_m[sp] = fmaxf(path_m, c[2].d); ++sp; }
+            if (n > 1) { stk_a[sp] = c[1].a; stk_b[sp] = c[1].b; stk_m[sp] = fmaxf(path_m, c[1].d); ++sp; }
+            cur_a = c[0].a; cur_b = c[0].b;
+            path_m = fmaxf(path_m, c[0].d);
+          } else {
+            pop_next();
+          }
+          if (++iters > ITER_LIMIT) { atomicOr(A.status, STATUS_ITER_LIMIT); cur_b = KIND_DONE; }
+        }
+      }
+      // ---- instance records (TLAS leaves, rt_traversal.cpp:109-121) ----
+      if (__any(cur_b == KIND_INSTANCE)) {
+        if (cur_b == KIND_INSTANCE) {
+          blasIdx = cur_a;
+          const uint32_t* bp = sc.blas + (size_t)blasIdx * (RT_BLAS_STRIDE / 4);
+          uint32_t bw[13];
+#pragma unroll
+          for (int i = 0; i < 13; ++i) bw[i] = bp[i];
+          if (STATS) { fx.node++; fx.inst++; }
+          const float m00 = __uint_as_float(bw[1]), m01 = __uint_as_float(bw[2]), m02 = __uint_as_float(bw[3]), m03 = __uint_as_float(bw[4]);
+          const float m10 = __uint_as_float(bw[5]), m11 = __uint_as_float(bw[6]), m12 = __uint_as_float(bw[7]), m13 = __uint_as_float(bw[8]);
+          const float m20 = __uint_as_float(bw[9]), m21 = __uint_as_float(bw[10]), m22 = __uint_as_float(bw[11]), m23 = __uint_as_float(bw[12]);
+          cox = m00 * ox + m01 * oy + m02 * oz + m03;   // :231-261
+          coy = m10 * ox + m11 * oy + m12 * oz + m13;
+          coz = m20 * ox + m21 * oy + m22 * oz + m23;
+          cdx = m00 * dx + m01 * dy + m02 * dz;
+          cdy = m10 * dx + m11 * dy + m12 * dz;
+          cdz = m20 * dx + m21 * dy + m22 * dz;
+          cix = 1.0f / cdx; ciy = 1.0f / cdy; ciz = 1.0f / cdz;
+          const bool s2 = (cix - cix == 0.0f) && (ciy - ciy == 0.0f) && (ciz - ciz == 0.0f) &&
+                          (cox - cox == 0.0f) && (coy - coy == 0.0f) && (coz - coz == 0.0f);
+          lane_fast = lane_fast && s2;
+          const uint2 r = sc.blas_root[blasIdx];   // BLAS root: same level, path_m unchanged
+          cur_a = r.x; cur_b = r.y;
+        }
+#if RT_WHILE_WHILE
+        continue;   // the BLAS roots are usually internal nodes: back to the node loop
+#endif
+      }
+      // ---- all lanes that hold a leaf (:123-161) ----
+      if (__any(is_leaf_kind(cur_b))) {
+        if (is_leaf_kind(cur_b)) {
+          if (STATS) fx.node++;
+          const uint32_t leftFirst = cur_a, triCount = cur_b;
+          bool stop = false;
+          for (uint32_t i = 0; i < triCount; ++i) {
+            const uint32_t triIdx = leftFirst + i;
+            const float4* tp = sc.tri_w + (size_t)triIdx * 3;
+            const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            if (STATS) fx.tri++;
+            float bx, by, bz;
+            const float d = ray_tri(cox, coy, coz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
+            if (d < hitd) {
+              hitd = d; hbx = bx; hby = by; hbz = bz; hblas = blasIdx; htri = triIdx;
+              found = true;
+              if (anyhit) { stop = true; break; }
+              if (!(path_m < hitd)) break;   // reference re-descent abandons this subtree
+            }
+          }
+          if (stop) { sp = 0; cur_b = KIND_DONE; }
+          else pop_next();
+          if (++iters > ITER_LIMIT) { atomicOr(A.status, STATUS_ITER_LIMIT); cur_b = KIND_DONE; }
+        }
+      }
+      const unsigned long long work = __ballot(is_work_kind(cur_b));
+      const unsigned long long done = __ballot(cur_b == KIND_DONE);
+      if (work == 0ull || __popcll(done) >= RT_FINISH_MIN) break;
+    }
+
+    // ================= finish: rays whose traversal ended =================
+    if (cur_b == KIND_DONE) {
+      if (!found) hitd = RT_LARGE_FLOAT;
+      if (JOB == JOB_TRACE) {
+        HitRec h; h.dist = hitd; h.bx = hbx; h.by = hby; h.bz = hbz; h.blasIdx = hblas; h.triIdx = htri;
+        if (!found) { h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0; }
+        A.hits[job] = h;
+        cur_b = KIND_IDLE;
+      } else {
+        // deferred shading: the traversal kernel only leaves hit records behind (24 B per pixel in
+        // A.hits, occlusion in bit 31 of blasIdx); rt_shade_kernel turns them into pixels in one
+        // coherent pass.  Finishing a ray therefore costs one store, not a chain of dependent loads.
+        const uint32_t tile = job >> 6, l = job & 63u;
+        const uint32_t x = (tile % A.tiles_x) * 8u + (l & 7u), y = A.y0 + (tile / A.tiles_x) * 8u + (l >> 3);
+        const size_t idx = (size_t)x + (size_t)y * A.W;
+        if (!shadow_phase) {
+          HitRec h; h.dist = hitd; h.bx = hbx; h.by = hby; h.bz = hbz; h.blasIdx = hblas; h.triIdx = htri;
+          if (!found) { h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0; }
+          A.hits[idx] = h;
+          if (STATS && found) nhit++;
+          if (JOB == JOB_RENDER_SHADOW && found) {
+            // continue this lane with the pixel's occlusion ray
+            float sox, soy, soz, sdx, sdy, sdz, sdist;
+            shadow_ray(p, ox, oy, oz, dx, dy, dz, hitd, sox, soy, soz, sdx, sdy, sdz, sdist);
+            ox = sox; oy = soy; oz = soz; dx = sdx; dy = sdy; dz = sdz;
+            shadow_phase = true;
+            start_ray(sdist, true);
+          } else {
+            cur_b = KIND_IDLE;
+          }
+        } else {
+          if (found) atomicOr(&A.hits[idx].blasIdx, 0x80000000u);   // occluded
+          cur_b = KIND_IDLE;
+        }
+      }
+    }
+  }
+
+  if (A.counters) {
+    unsigned v[5] = {nrays, fx.node, fx.inst, fx.tri, nhit};
+#pragma unroll
+    for (int k = 0; k < (STATS ? 5 : 1); ++k) {
+      unsigned s = v[k];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+      if (lane == 0 && s) atomicAdd(A.counters + k, (unsigned long long)s);
+    }
+  }
+}
+
+// Deferred shading pass of the persistent path: one thread per pixel of rows [y0,y1), x fastest, so
+// hit records are read and pixels written fully coalesced.
+template <bool STATS>
+__global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams p, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+                                                      const HitRec* __restrict__ hb, uint32_t* __restrict__ dst,
+                                                      HitRec* __restrict__ hits, float* __restrict__ colors,
+                                                      unsigned long long* counters) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  const uint64_t n = (uint64_t)W * (y1 - y0);
+  unsigned ntex = 0, npix = 0;
+  if (t < n) {
+    const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
+    const size_t idx = (size_t)x + (size_t)y * W;
+    HitRec h = hb[idx];
+    const bool occ = (h.blasIdx & 0x80000000u) != 0u;
+    h.blasIdx &= 0x7fffffffu;
+    const bool found = h.dist != RT_LARGE_FLOAT;
+    float ox, oy, oz, dx, dy, dz;
+    generate_ray(x, y, W, H, ox, oy, oz, dx, dy, dz);
+    float r, g, b;
+    shade_eval<STATS>(sc, p, ox, oy, oz, dx, dy, dz, h, found, occ, r, g, b, &ntex);
+    dst[idx] = pack_rgb8(r, g, b);
+    if (hits) hits[idx] = h;
+    if (colors) { colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b; }
+    npix = 1;
+  }
+  if (STATS && counters) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned v[2] = {ntex, npix};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      unsigned s = v[k];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+      if (lane == 0 && s) atomicAdd(counters + 5 + k, (unsigned long long)s);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,6 +879,9 @@ __global__ void accel_roots_kernel(const uint32_t* __restrict__ tlas, const uint
 // host entry points (C ABI, include/vortex_hip.h level 2)
 // ---------------------------------------------------------------------------------------------
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 static uint32_t* g_status[16] = {nullptr};
@@ -551,16 +896,57 @@ static uint32_t* status_word() {
   return g_status[dev];
 }
 
+// job-queue counters of the persistent kernels: a ring so that launches in flight on different
+// streams never share a counter (a slot is reused after 64 launches)
+#define QUEUE_RING 64
+static uint32_t* g_queue[16] = {nullptr};
+static unsigned g_queue_next[16] = {0};
+
+static uint32_t* queue_slot(hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!g_queue[dev]) {
+    if (hipMalloc((void**)&g_queue[dev], (size_t)QUEUE_RING * QUEUE_SHARDS * QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess) return nullptr;
+  }
+  uint32_t* q = g_queue[dev] + (size_t)(g_queue_next[dev]++ % QUEUE_RING) * QUEUE_SHARDS * QUEUE_STRIDE;
+  if (hipMemsetAsync(q, 0, (size_t)QUEUE_SHARDS * QUEUE_STRIDE * sizeof(uint32_t), s) != hipSuccess) return nullptr;
+  return q;
+}
+
+// 0 = persistent while-while kernel (default), 1 = one-tile-per-wave kernel (kept for A/B and as a
+// second implementation the tests cross-check)
+static int kernel_choice() {
+  static int c = -1;
+  if (c < 0) { const char* e = getenv("VXRT_KERNEL"); c = (e && !strcmp(e, "simple")) ? 1 : 0; }
+  return c;
+}
+
+template <class K>
+static uint32_t persistent_grid(K kernel, uint64_t jobs) {
+  int dev = 0, per_cu = 0, cus = 0;
+  (void)hipGetDevice(&dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  uint64_t g = (uint64_t)per_cu * (uint64_t)cus;
+  const uint64_t need = (jobs + 255) / 256;
+  if (g > need) g = need;
+  if (getenv("VXRT_DEBUG")) fprintf(stderr, "[vxrt] persistent grid: %d blocks/CU x %d CUs -> %llu blocks for %llu jobs\n", per_cu, cus, (unsigned long long)g, (unsigned long long)jobs);
+  return (uint32_t)(g ? g : 1);
+}
+
 struct vxrt_accel {
   SceneDev dev{};
   vxrt_scene_t ref{};
   void* tlas_w = nullptr; void* bvh_w = nullptr; void* tri_w = nullptr; void* blas_root = nullptr;
+  void* hitbuf = nullptr;      // W*H hit records between the traversal and the shading pass
+  uint64_t hitbuf_pixels = 0;
   int device = 0;
 };
 
 static void accel_free(vxrt_accel* a) {
   if (!a) return;
   (void)hipFree(a->tlas_w); (void)hipFree(a->bvh_w); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
+  (void)hipFree(a->hitbuf);
   delete a;
 }
 
@@ -643,7 +1029,7 @@ uint64_t vxrt_accel_bytes(const vxrt_accel_t* a) {
          (uint64_t)a->ref.n_tris * WTRI_FLOATS * 4 + (uint64_t)a->ref.n_blas * 8;
 }
 
-static int render_common(const vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits, float* colors,
                          unsigned long long* counters, bool stats, void* stream, unsigned long long* tile_clock = nullptr) {
   if (!a || !params || !dst) return -1;
@@ -666,6 +1052,33 @@ static int render_common(const vxrt_accel_t* a, uint32_t width, uint32_t height,
   dim3 grid((n_tiles + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
   const SceneDev& sc = a->dev;
+  if (kernel_choice() == 0 && !tile_clock) {
+    if (n_tiles > 0x1ffffffu) return -1;
+    // hit-record buffer between the two passes (one render in flight per accel)
+    const uint64_t pixels = (uint64_t)width * height;
+    if (a->hitbuf_pixels < pixels) {
+      if (hipStreamSynchronize(s) != hipSuccess) return -1;
+      (void)hipFree(a->hitbuf);
+      a->hitbuf = nullptr; a->hitbuf_pixels = 0;
+      if (hipMalloc(&a->hitbuf, pixels * sizeof(HitRec)) != hipSuccess) return -1;
+      a->hitbuf_pixels = pixels;
+    }
+    PersistArgs A{};
+    A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.total = n_tiles * 64u;
+    A.dst = dst; A.hits = (HitRec*)a->hitbuf; A.colors = nullptr; A.counters = counters; A.status = st;
+    A.queue = queue_slot(s);
+    if (!A.queue) return -1;
+    A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
+#define LAUNCH_P(J, ST) hipLaunchKernelGGL((rt_persistent_kernel<J, ST>), dim3(persistent_grid(rt_persistent_kernel<J, ST>, A.total)), block, 0, s, sc, p, A)
+    if (stats) { if (shadow) LAUNCH_P(JOB_RENDER_SHADOW, true); else LAUNCH_P(JOB_RENDER, true); }
+    else       { if (shadow) LAUNCH_P(JOB_RENDER_SHADOW, false); else LAUNCH_P(JOB_RENDER, false); }
+#undef LAUNCH_P
+    const uint64_t npx = (uint64_t)width * (y1 - y0);
+    dim3 sgrid((uint32_t)((npx + 255) / 256));
+    if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
+    else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
 #define LAUNCH_RENDER(SH, ST) hipLaunchKernelGGL((rt_render_kernel<SH, ST>), grid, block, 0, s, sc, p, width, height, y0, tiles_x, n_tiles, y1, \
                                                  dst, (HitRec*)hits, colors, counters, st, tile_clock)
   if (stats) { if (shadow) LAUNCH_RENDER(true, true); else LAUNCH_RENDER(false, true); }
@@ -674,7 +1087,7 @@ static int render_common(const vxrt_accel_t* a, uint32_t width, uint32_t height,
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int vxrt_render(const vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+int vxrt_render(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                 const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits,
                 float* colors, unsigned long long* rays_traced, void* stream) {
   return render_common(accel, width, height, y0, y1, params, shadow, dst, hits, colors, rays_traced, false, stream);
@@ -683,7 +1096,7 @@ int vxrt_render(const vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
 // Same launch as vxrt_render with the fetch counters compiled in (slower; never the timed path).
 // counters: device u64[7] = rays, node fetches, instance fetches, triangle fetches, shaded hits,
 // textured hits, pixels written -- the inputs of the algorithmic-bytes formula.
-int vxrt_render_stats(const vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                       const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                       unsigned long long* counters, unsigned long long* tile_clock, void* stream) {
   return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream, tile_clock);
@@ -699,6 +1112,17 @@ int vxrt_trace(const vxrt_accel_t* a, const float* rays, uint64_t n, const float
   if (!st) return -1;
   dim3 grid((uint32_t)((n + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (kernel_choice() == 0) {
+    if (n > 0x7fffffffull) return -1;
+    PersistArgs A{};
+    A.total = (uint32_t)n; A.hits = (HitRec*)hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
+    A.status = st; A.queue = queue_slot(s);
+    if (!A.queue) return -1;
+    A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
+    ShadeParams p{};
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false>, n)), block, 0, s, a->dev, p, A);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   if (mode == VXRT_MODE_ANY)
     hipLaunchKernelGGL(rt_trace_kernel<true>, grid, block, 0, s, a->dev, rays, n, tmax, (HitRec*)hits, st);
   else
