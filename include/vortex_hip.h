@@ -178,7 +178,7 @@ typedef struct {
 #define VXRT_MODE_ANY 1     /* occlusion: stop at first accepted candidate (extension) */
 
 /* Device-side acceleration layout built ONCE per scene from the reference-format buffers above
- * (decoded child boxes, inlined leaf descriptors, edge-form triangles).  The build
+ * (compact 64-byte nodes with inlined leaf / instance descriptors, edge-form triangles).  The build
  * validates every index the traversal can follow and fails (-1) on a malformed tree instead of
  * letting a kernel fault.  The vxrt_scene_t buffers must stay alive and unchanged while the accel
  * is in use (shading reads blas/triEx/mat/tex from them).  Synchronous with respect to `stream`. */
@@ -202,12 +202,10 @@ int vxrt_render(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y
 /* vxrt_render with the fetch counters compiled in (diagnostic build of the same kernel, never
  * timed): counters = device u64[7]: rays, node fetches, instance fetches, triangle fetches,
  * shaded hits, textured hits, pixels written.  Counts are what the reference logs per ray in
- * RT_mem_accesses (rt_traversal.cpp:54,116,148,158) without its restart re-reads.
- * tile_clock (optional): device u64[2 * tiles]: constant-rate (100 MHz) clock at begin / end of
- * every 8x8 tile's wavefront, to study load balance. */
+ * RT_mem_accesses (rt_traversal.cpp:54,116,148,158) without its restart re-reads. */
 int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                       const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
-                      unsigned long long* counters, unsigned long long* tile_clock, void* stream);
+                      unsigned long long* counters, void* stream);
 
 /* Trace n rays (6 floats each: origin, direction) read from HBM, write n hit records.
  * tmax: optional per-ray upper bound (NULL = 1e30). */

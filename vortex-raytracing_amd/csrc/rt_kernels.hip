@@ -1,10 +1,10 @@
 // HIP kernels of the ray-tracing hot path for gfx950 (MI355X): 4-wide quantized-BVH traversal
-// (TLAS -> BLAS), Moller-Trumbore, Lambert shade, RGB8 pack.  Hand-written for CDNA4 wave64:
-// one 8x8 pixel tile (the reference's block, kernel.cpp:128-133) == one wavefront.
+// (TLAS -> BLAS), Moller-Trumbore, Lambert shade, RGB8 pack.  Hand-written for CDNA4 wave64.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off   (contraction OFF is part of the
 // contract: SURVEY.md s7 "FP contraction"; division and sqrt are the correctly rounded forms,
-// hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).
+// hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).  The only fused operation is the
+// explicit fma in the child-box decode, where the product is exact (see eval_children).
 //
 // Semantics restated from the reference (paths relative to the reference repo):
 //   traversal     sim/simx/rt_traversal.cpp:26-213 + sim/simx/rt_unit.cpp:98-116,199-202
@@ -20,41 +20,57 @@
 #include "rt_types.h"
 #include "../../include/vortex_hip.h"
 
-#define TLAS_FLAG 0x80000000u
 #define STATUS_STACK_OVERFLOW 1u
 #define STATUS_ITER_LIMIT 2u
 #define STATUS_BAD_SCENE 4u
+#define STATUS_FMA_DECODE_DIFFERS 8u   // build-time only: selects the ldexp decode for the scene
 
 // ---------------------------------------------------------------------------------------------
-// Device-side acceleration layout, derived once per scene from the reference-format buffers by
-// accel_* kernels below (the reference bytes stay the source of truth):
+// Device-side acceleration layout, derived once per scene from the reference-format buffers by the
+// accel_* kernels below (the reference bytes stay the source of truth).
 //
-//  wide node, 128 B, one per INTERNAL node i of the tlas / bvh buffer (same index i):
-//     float box[4][6]   child k: min.xyz, max.xyz, already decoded with the reference's formula
-//                       origin + ldexp(float(q), e)  (rt_traversal.cpp:61-67) -> bit-identical slabs
-//     uint32 a[4], b[4] child descriptor:
-//        b == 0              internal child, a = node index (bit31 set for TLAS nodes; BLAS
-//                            indices are absolute: bvh_offset of the owning instance added)
-//        1 <= b < 2^31       BLAS leaf child: a = first triangle, b = triangle count
-//        b == 0x80000000     TLAS leaf child (instance): a = blasIdx
-//        b == 0xFFFFFFFF     no child (meta == 0)
-//     -> a leaf never costs a node fetch of its own, and the 4 box tests need no byte unpacking.
-//  wide triangle, 48 B: v0, edge1 = v1 - v0, edge2 = v2 - v0 (the subtractions of
-//     rt_traversal.cpp:272-278 done once), padded so that a triangle is three aligned 16-B loads.
-//  roots: descriptor (a, b) of the TLAS root and of every BLAS root.
+// Work descriptor, 32 bit: [31:30] kind, [29:0] payload
+//     kind 0  TLAS internal node   payload = node index in the TLAS buffer
+//     kind 1  BLAS internal node   payload = node index in the bvh buffer (absolute)
+//     kind 2  BLAS leaf            payload = count<<26 | firstTriangle   (count 1..15; count 0:
+//                                  payload = index of the reference leaf node, range read from it)
+//     kind 3  instance (TLAS leaf) payload = blasIdx
+//
+// Compact node, 64 B = half a cache line, one per INTERNAL node (same index as the reference node):
+//     q0 = origin.xyz, ex | ey<<8 | ez<<16 | kinds<<24     kinds: 2 bits per child (0 none,
+//                                                            1 internal, 2 leaf, 3 instance)
+//     q1 = leftFirst (index of child 0's node), qb0, qb1, qb2   qb0..5 = the 24 quantised box bytes
+//     q2 = qb3, qb4, qb5, pay0                                  pay k = descriptor payload of a leaf
+//     q3 = pay1, pay2, pay3, 0                                          or instance child k
+//   -> a node visit is four 16-byte loads per lane (the vector-memory return path, not HBM, is what
+//      saturates first on MI355X for this access pattern: profiles/r01_b_*), a leaf or instance never
+//      costs a node fetch of its own, and stack entries are 2 dwords.
+// Wide triangle, 48 B: v0, edge1 = v1 - v0, edge2 = v2 - v0 (the subtractions of
+//     rt_traversal.cpp:272-278 done once), three aligned 16-byte loads.
 // ---------------------------------------------------------------------------------------------
-#define KIND_INSTANCE 0x80000000u
-#define KIND_NONE 0xFFFFFFFFu
-#define WIDE_DWORDS 32
+#define DK_TLAS 0u
+#define DK_BLAS 1u
+#define DK_LEAF 2u
+#define DK_INST 3u
+#define DESC(kind, payload) (((kind) << 30) | (payload))
+#define DESC_DONE 0xFFFFFFFEu   // traversal of the lane's ray has ended
+#define DESC_IDLE 0xFFFFFFFDu   // lane has no ray
+#define PAYLOAD_MASK 0x3FFFFFFFu
+#define LEAF_FIRST_BITS 26
+#define LEAF_FIRST_MASK 0x03FFFFFFu
+#define LEAF_MAX_INLINE 15u
+#define CNODE_VEC4 4
 #define WTRI_FLOATS 12
 
 struct SceneDev {
-  const uint4* tlas_w;      // wide TLAS nodes
-  const uint4* bvh_w;       // wide BLAS nodes
-  const float4* tri_w;      // wide triangles
-  const uint2* blas_root;   // per instance record: root descriptor
-  uint2 tlas_root;
-  const uint32_t* blas;     // reference blas_node_t records (40 dwords each)
+  const uint4* tlas_c;       // compact TLAS nodes
+  const uint4* bvh_c;        // compact BLAS nodes
+  const float4* tri_w;       // wide triangles
+  const uint32_t* blas_root; // per instance record: descriptor of its BLAS root
+  uint32_t tlas_root;        // descriptor of the TLAS root
+  uint32_t exact_decode;     // 1: decode child boxes with ldexp instead of the exact-product fma
+  const uint32_t* ref_bvh;   // reference bvh nodes (13 dwords each): ranges of leaves > 15 triangles
+  const uint32_t* blas;      // reference blas_node_t records (40 dwords each)
   const rt_triex_t* triEx;
   const rt_material_t* mat;
   const uint8_t* tex;
@@ -84,7 +100,7 @@ __device__ __forceinline__ float ray_box(float ox, float oy, float oz, float ix,
     tmin = std_max(tmin, std_min(tz1, tz2));
     tmax = std_min(tmax, std_max(tz1, tz2));
   } else {
-    tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));   // v_min, v_min, v_min, v_max3
+    tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));   // v_min x3, v_max3
     tmax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
   }
   return (tmax < tmin || tmax <= 0) ? RT_LARGE_FLOAT : tmin;
@@ -118,35 +134,54 @@ __device__ __forceinline__ float ray_tri(float ox, float oy, float oz, float dx,
   return tf;
 }
 
-struct Cand { float d; uint32_t a, b, idx; };
+struct Cand { float d; uint32_t desc, idx; };
 // visit order: nearer first; equal distance -> higher child index first (stable far->near sort of
 // rt_traversal.cpp:76-78 read from the back).  Filtered children carry d = +inf.
 __device__ __forceinline__ void cmpx(Cand& x, Cand& y) {
   const bool sw = (y.d < x.d) || (y.d == x.d && y.idx > x.idx);
   const Cand tx = x, ty = y;
-  x.d = sw ? ty.d : tx.d; x.a = sw ? ty.a : tx.a; x.b = sw ? ty.b : tx.b; x.idx = sw ? ty.idx : tx.idx;
-  y.d = sw ? tx.d : ty.d; y.a = sw ? tx.a : ty.a; y.b = sw ? tx.b : ty.b; y.idx = sw ? tx.idx : ty.idx;
+  x.d = sw ? ty.d : tx.d; x.desc = sw ? ty.desc : tx.desc; x.idx = sw ? ty.idx : tx.idx;
+  y.d = sw ? tx.d : ty.d; y.desc = sw ? tx.desc : ty.desc; y.idx = sw ? tx.idx : ty.idx;
 }
 
-// Box tests of the <=4 children of an internal node (rt_traversal.cpp:59-74) on decoded boxes.
+__device__ __forceinline__ float qbyte(const uint32_t* qb, int byte_off) {   // v_cvt_f32_ubyteN
+  return (float)((qb[byte_off >> 2] >> ((byte_off & 3) * 8)) & 0xffu);
+}
+
+// Box tests of the <=4 children of an internal node (rt_traversal.cpp:59-74).
+// Decode: the reference computes origin + ldexp(float(q), e) (:61-67).  float(q) * 2^e is exact for
+// an 8-bit q whenever 2^e is representable, so fma(float(q), 2^e, origin) rounds the same exact sum
+// once and yields the identical float with one instruction less per coordinate; the accel build
+// verifies this per scene and sets exact_decode otherwise.
 template <bool EXACT>
-__device__ __forceinline__ void eval_children(const uint4* __restrict__ w, float rox, float roy, float roz,
-                                              float rix, float riy, float riz, float hit_dist, Cand* c) {
-  // w[0..5] = 24 box floats (child-major), w[6] = a[4], w[7] = b[4]
-  const uint4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3], q4 = w[4], q5 = w[5], qa = w[6], qb = w[7];
-  const float f[24] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w),
-                       __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w),
-                       __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w),
-                       __uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z), __uint_as_float(q3.w),
-                       __uint_as_float(q4.x), __uint_as_float(q4.y), __uint_as_float(q4.z), __uint_as_float(q4.w),
-                       __uint_as_float(q5.x), __uint_as_float(q5.y), __uint_as_float(q5.z), __uint_as_float(q5.w)};
-  const uint32_t ca[4] = {qa.x, qa.y, qa.z, qa.w}, cb[4] = {qb.x, qb.y, qb.z, qb.w};
+__device__ __forceinline__ void eval_children(const uint4* __restrict__ np, bool is_tlas, bool ldexp_decode,
+                                              float rox, float roy, float roz, float rix, float riy, float riz,
+                                              float hit_dist, Cand* c) {
+  const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+  const float px = __uint_as_float(q0.x), py = __uint_as_float(q0.y), pz = __uint_as_float(q0.z);
+  const int ex = (int)(int8_t)(q0.w & 0xff), ey = (int)(int8_t)((q0.w >> 8) & 0xff), ez = (int)(int8_t)((q0.w >> 16) & 0xff);
+  const uint32_t kinds = q0.w >> 24, leftFirst = q1.x;
+  const uint32_t qb[6] = {q1.y, q1.z, q1.w, q2.x, q2.y, q2.z};
+  const uint32_t pay[4] = {q2.w, q3.x, q3.y, q3.z};
+  const float sx = ldexpf(1.0f, ex), sy = ldexpf(1.0f, ey), sz = ldexpf(1.0f, ez);
+  const uint32_t node_kind = is_tlas ? DK_TLAS : DK_BLAS;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float d = ray_box<EXACT>(rox, roy, roz, rix, riy, riz, f[6 * k], f[6 * k + 1], f[6 * k + 2], f[6 * k + 3], f[6 * k + 4], f[6 * k + 5]);
-    const bool ok = (cb[k] != KIND_NONE) && (d < hit_dist);     // :60, :71
+    const int b = 6 * k;
+    float mnx, mny, mnz, mxx, mxy, mxz;
+    if (ldexp_decode) {
+      mnx = px + ldexpf(qbyte(qb, b + 0), ex); mny = py + ldexpf(qbyte(qb, b + 1), ey); mnz = pz + ldexpf(qbyte(qb, b + 2), ez);
+      mxx = px + ldexpf(qbyte(qb, b + 3), ex); mxy = py + ldexpf(qbyte(qb, b + 4), ey); mxz = pz + ldexpf(qbyte(qb, b + 5), ez);
+    } else {
+      mnx = __fmaf_rn(qbyte(qb, b + 0), sx, px); mny = __fmaf_rn(qbyte(qb, b + 1), sy, py); mnz = __fmaf_rn(qbyte(qb, b + 2), sz, pz);
+      mxx = __fmaf_rn(qbyte(qb, b + 3), sx, px); mxy = __fmaf_rn(qbyte(qb, b + 4), sy, py); mxz = __fmaf_rn(qbyte(qb, b + 5), sz, pz);
+    }
+    const float d = ray_box<EXACT>(rox, roy, roz, rix, riy, riz, mnx, mny, mnz, mxx, mxy, mxz);
+    const uint32_t ck = (kinds >> (2 * k)) & 3u;
+    const bool ok = (ck != 0u) && (d < hit_dist);     // :60, :71
     c[k].d = ok ? d : __builtin_inff();
-    c[k].a = ca[k]; c[k].b = cb[k]; c[k].idx = (uint32_t)k;
+    c[k].desc = ck == 1u ? DESC(node_kind, leftFirst + (uint32_t)k) : DESC(ck, pay[k]);   // ck 2 -> leaf, 3 -> instance
+    c[k].idx = (uint32_t)k;
   }
 }
 
@@ -155,118 +190,7 @@ __device__ __forceinline__ void eval_children(const uint4* __restrict__ w, float
 // A leaf or instance child still counts as one 52-byte node fetch: the reference reads that node.
 struct Fetches { unsigned node = 0, inst = 0, tri = 0; };
 
-#define ITER_LIMIT (1u << 22)   // exit condition every lane reaches even on a cyclic (corrupt) tree
-
-// One closest-hit (or any-hit) query.  Returns true if a candidate was accepted.
-template <bool ANY_HIT, bool STATS = false>
-__device__ bool trace_ray(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
-                          float tmax, HitRec& hit, uint32_t* status, Fetches* fx = nullptr) {
-  // world-space ray (TLAS nodes) and object-space ray (BLAS nodes), with reciprocals
-  const float wix = 1.0f / dx, wiy = 1.0f / dy, wiz = 1.0f / dz;
-  float cox = ox, coy = oy, coz = oz, cdx = dx, cdy = dy, cdz = dz;
-  float cix = wix, ciy = wiy, ciz = wiz;
-
-  // a lane may use v_min/v_max only if no slab product can be NaN
-  bool lane_fast = (wix - wix == 0.0f) && (wiy - wiy == 0.0f) && (wiz - wiz == 0.0f) &&
-                   (ox - ox == 0.0f) && (oy - oy == 0.0f) && (oz - oz == 0.0f);
-
-  uint32_t stk_a[RT_STACK_ENTRIES], stk_b[RT_STACK_ENTRIES];
-  float stk_m[RT_STACK_ENTRIES];
-  int sp = 0;
-
-  hit.dist = tmax; hit.bx = 0; hit.by = 0; hit.bz = 0; hit.blasIdx = 0; hit.triIdx = 0;
-  bool found = false;
-  uint32_t blasIdx = 0;
-  uint32_t cur_a = sc.tlas_root.x, cur_b = sc.tlas_root.y;   // TLAS root (rt_traversal.cpp:39-40)
-  float path_m = -__builtin_inff();
-  uint32_t iters = 0;
-
-  for (;;) {
-    bool next = false;   // true: (cur_a, cur_b) holds the next work item of this lane
-    if (cur_b == 0u) {
-      // ---- internal node: 4 box tests, order, push the far ones, continue with the nearest ----
-      const bool top = (cur_a & TLAS_FLAG) != 0u;
-      const uint4* np = top ? sc.tlas_w + (size_t)(cur_a & ~TLAS_FLAG) * (WIDE_DWORDS / 4) : sc.bvh_w + (size_t)cur_a * (WIDE_DWORDS / 4);
-      if (STATS) fx->node++;
-      const float rox = top ? ox : cox, roy = top ? oy : coy, roz = top ? oz : coz;
-      const float rix = top ? wix : cix, riy = top ? wiy : ciy, riz = top ? wiz : ciz;
-      Cand c[4];
-      // wave-uniform choice: v_min/v_max slabs unless some active lane could see a NaN product
-      if (__all(lane_fast)) eval_children<false>(np, rox, roy, roz, rix, riy, riz, hit.dist, c);
-      else                  eval_children<true>(np, rox, roy, roz, rix, riy, riz, hit.dist, c);
-      int n = (c[0].d < __builtin_inff()) + (c[1].d < __builtin_inff()) + (c[2].d < __builtin_inff()) + (c[3].d < __builtin_inff());
-      cmpx(c[0], c[1]); cmpx(c[2], c[3]); cmpx(c[0], c[2]); cmpx(c[1], c[3]); cmpx(c[1], c[2]);
-      if (n > 0) {
-        if (sp + 3 > RT_STACK_ENTRIES) { atomicOr(status, STATUS_STACK_OVERFLOW); n = 1; }
-        // far first so that the nearest pending sibling is on top (:98-103)
-        if (n > 3) { stk_a[sp] = c[3].a; stk_b[sp] = c[3].b; stk_m[sp] = fmaxf(path_m, c[3].d); ++sp; }
-        if (n > 2) { stk_a[sp] = c[2].a; stk_b[sp] = c[2].b; stk_m[sp] = fmaxf(path_m, c[2].d); ++sp; }
-        if (n > 1) { stk_a[sp] = c[1].a; stk_b[sp] = c[1].b; stk_m[sp] = fmaxf(path_m, c[1].d); ++sp; }
-        cur_a = c[0].a; cur_b = c[0].b;
-        path_m = fmaxf(path_m, c[0].d);
-        next = true;
-      }
-    } else if (cur_b == KIND_INSTANCE) {
-      // ---- TLAS leaf (:109-121): fetch the instance record, move the ray to object space ----
-      blasIdx = cur_a;
-      const uint32_t* bp = sc.blas + (size_t)blasIdx * (RT_BLAS_STRIDE / 4);
-      uint32_t bw[13];
-#pragma unroll
-      for (int i = 0; i < 13; ++i) bw[i] = bp[i];
-      if (STATS) { fx->node++; fx->inst++; }
-      const float m00 = __uint_as_float(bw[1]), m01 = __uint_as_float(bw[2]), m02 = __uint_as_float(bw[3]), m03 = __uint_as_float(bw[4]);
-      const float m10 = __uint_as_float(bw[5]), m11 = __uint_as_float(bw[6]), m12 = __uint_as_float(bw[7]), m13 = __uint_as_float(bw[8]);
-      const float m20 = __uint_as_float(bw[9]), m21 = __uint_as_float(bw[10]), m22 = __uint_as_float(bw[11]), m23 = __uint_as_float(bw[12]);
-      cox = m00 * ox + m01 * oy + m02 * oz + m03;   // :231-261
-      coy = m10 * ox + m11 * oy + m12 * oz + m13;
-      coz = m20 * ox + m21 * oy + m22 * oz + m23;
-      cdx = m00 * dx + m01 * dy + m02 * dz;
-      cdy = m10 * dx + m11 * dy + m12 * dz;
-      cdz = m20 * dx + m21 * dy + m22 * dz;
-      cix = 1.0f / cdx; ciy = 1.0f / cdy; ciz = 1.0f / cdz;
-      const bool s2 = (cix - cix == 0.0f) && (ciy - ciy == 0.0f) && (ciz - ciz == 0.0f) &&
-                      (cox - cox == 0.0f) && (coy - coy == 0.0f) && (coz - coz == 0.0f);
-      lane_fast = lane_fast && s2;
-      const uint2 r = sc.blas_root[blasIdx];   // BLAS root; same level, path_m unchanged
-      cur_a = r.x; cur_b = r.y;
-      next = true;
-    } else {
-      // ---- BLAS leaf (:123-161): triangles in index order, strict '<' ----
-      if (STATS) fx->node++;
-      const uint32_t leftFirst = cur_a, triCount = cur_b;
-      for (uint32_t i = 0; i < triCount; ++i) {
-        const uint32_t triIdx = leftFirst + i;
-        const float4* tp = sc.tri_w + (size_t)triIdx * 3;
-        const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-        if (STATS) fx->tri++;
-        float bx, by, bz;
-        const float d = ray_tri(cox, coy, coz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
-        if (d < hit.dist) {
-          hit.dist = d; hit.bx = bx; hit.by = by; hit.bz = bz;
-          hit.blasIdx = blasIdx; hit.triIdx = triIdx;
-          found = true;
-          if (ANY_HIT) break;
-          // the reference re-descends from the root with the shrunken hit.dist; if any box on the
-          // current path no longer passes `d < hit.dist` it abandons this subtree
-          if (!(path_m < hit.dist)) break;
-        }
-      }
-      if (ANY_HIT && found) break;
-    }
-
-    if (!next) {
-      while (sp > 0) {
-        --sp;
-        const float m = stk_m[sp];
-        if (m < hit.dist) { cur_a = stk_a[sp]; cur_b = stk_b[sp]; path_m = m; next = true; break; }
-      }
-      if (!next) break;
-    }
-    if (++iters > ITER_LIMIT) { atomicOr(status, STATUS_ITER_LIMIT); break; }
-  }
-  if (!found) hit.dist = RT_LARGE_FLOAT;
-  return found;
-}
+#define ITER_LIMIT (1u << 22)   // backstop; accepted trees are acyclic (children stored after parents)
 
 // ---------------------------------------------------------------------------------------------
 // shading (closest.cpp:57-127 / miss.cpp:9-14)
@@ -354,23 +278,6 @@ __device__ void shade_eval(const SceneDev& sc, const ShadeParams& p, float ox, f
   b = b + p.bg[2] * thr;
 }
 
-// shade of the one-tile-per-wave kernel: occlusion query traced inline
-template <bool SHADOW, bool STATS = false>
-__device__ void shade(const SceneDev& sc, const ShadeParams& p, float ox, float oy, float oz,
-                      float dx, float dy, float dz, const HitRec& hit, bool found,
-                      float& r, float& g, float& b, uint32_t* status, unsigned& extra_rays,
-                      Fetches* fx = nullptr, unsigned* textured = nullptr) {
-  bool occ = false;
-  if (SHADOW && found) {
-    float sox, soy, soz, sdx, sdy, sdz, sdist;
-    shadow_ray(p, ox, oy, oz, dx, dy, dz, hit.dist, sox, soy, soz, sdx, sdy, sdz, sdist);
-    HitRec sh;
-    occ = trace_ray<true, STATS>(sc, sox, soy, soz, sdx, sdy, sdz, sdist, sh, status, fx);
-    extra_rays += 1;
-  }
-  shade_eval<STATS>(sc, p, ox, oy, oz, dx, dy, dz, hit, found, occ, r, g, b, textured);
-}
-
 __device__ __forceinline__ uint32_t pack_rgb8(float r, float g, float b) {  // common.h:149-154
   int ir = (int)(std_min(r, 1.f) * 255);
   int ig = (int)(std_min(g, 1.f) * 255);
@@ -395,99 +302,40 @@ __device__ __forceinline__ void generate_ray(uint32_t x, uint32_t y, uint32_t W,
   dx = vx * inv; dy = vy * inv; dz = vz * inv;
 }
 
-// One wavefront == one 8x8 tile (block of the reference grid); 4 tiles per 256-thread workgroup.
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4
 #endif
-template <bool SHADOW, bool STATS = false>
-__global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_render_kernel(SceneDev sc, ShadeParams p, uint32_t W, uint32_t H,
-                                                        uint32_t y0, uint32_t tiles_x, uint32_t n_tiles,
-                                                        uint32_t y1, uint32_t* __restrict__ dst,
-                                                        HitRec* __restrict__ hits, float* __restrict__ colors,
-                                                        unsigned long long* rays_traced, uint32_t* status,
-                                                        unsigned long long* tile_clock = nullptr) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (tile >= n_tiles) return;
-  const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-  const uint32_t x = tx * 8u + (lane & 7u);
-  const uint32_t y = y0 + ty * 8u + (lane >> 3);
-  const bool active = (x < W) && (y < y1);   // kernel.cpp:62,101
-  unsigned long long t_begin = 0;
-  if (STATS && tile_clock) t_begin = wall_clock64();
-  unsigned nrays = 0, nhit = 0, ntex = 0;
-  Fetches fx;
-  if (active) {
-    float ox, oy, oz, dx, dy, dz;
-    generate_ray(x, y, W, H, ox, oy, oz, dx, dy, dz);
-    HitRec hit;
-    bool found = trace_ray<false, STATS>(sc, ox, oy, oz, dx, dy, dz, RT_LARGE_FLOAT, hit, status, &fx);
-    nrays = 1;
-    nhit = found ? 1u : 0u;
-    float r, g, b;
-    shade<SHADOW, STATS>(sc, p, ox, oy, oz, dx, dy, dz, hit, found, r, g, b, status, nrays, &fx, &ntex);
-    const size_t idx = (size_t)x + (size_t)y * W;
-    dst[idx] = pack_rgb8(r, g, b);
-    if (hits) hits[idx] = hit;
-    if (colors) { colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b; }
-  }
-  if (STATS && tile_clock && lane == 0) { tile_clock[2 * (size_t)tile] = t_begin; tile_clock[2 * (size_t)tile + 1] = wall_clock64(); }
-  if (rays_traced) {
-    // wave-level reduction, one atomic per wavefront and counter.  STATS build: rays_traced[0..6] =
-    // rays, node fetches, instance fetches, triangle fetches, shaded hits, textured hits, pixels
-    unsigned v[7] = {nrays, fx.node, fx.inst, fx.tri, nhit, ntex, active ? 1u : 0u};
-#pragma unroll
-    for (int k = 0; k < (STATS ? 7 : 1); ++k) {
-      unsigned s = v[k];
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-      if (lane == 0 && s) atomicAdd(rays_traced + k, (unsigned long long)s);
-    }
-  }
-}
-
-template <bool ANY_HIT>
-__global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_trace_kernel(SceneDev sc, const float* __restrict__ rays, uint64_t n,
-                                                       const float* __restrict__ tmax, HitRec* __restrict__ hits,
-                                                       uint32_t* status) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const float* rp = rays + i * 6;
-  float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
-  HitRec hit;
-  trace_ray<ANY_HIT>(sc, ox, oy, oz, dx, dy, dz, tmax ? tmax[i] : RT_LARGE_FLOAT, hit, status);
-  hits[i] = hit;
-}
 
 // ---------------------------------------------------------------------------------------------
-// Persistent while-while kernel with per-lane dynamic ray fetch.
+// Persistent traversal kernel.
 //
-// The one-tile-per-wave kernel above is bounded by its slowest lane (rocprof + per-tile clocks: 1 % of
-// the wavefronts live 4x the mean and the second half of a frame runs at half occupancy).  Here a
-// fixed grid of wavefronts pulls rays from one global queue; a lane that finishes its ray takes the
-// next job, so wavefronts stay full and the launch ends within one ray of the last job.  Inside,
-// traversal is "while-while": all lanes with an internal node step together, then all lanes with a
-// leaf, so the two bodies are not serialised for every mixed wavefront.  Primary and occlusion rays
-// of different pixels share a wavefront (any-hit is a per-lane flag).  Per-ray semantics -- and
-// therefore results -- are exactly those of trace_ray; only the schedule differs.
+// A fixed grid of wavefronts pulls jobs (pixels of 8x8 tiles, or rays of a ray buffer) from a
+// sharded queue, so the launch ends within one job batch of the last job instead of within the
+// slowest tile of a static tile->wavefront map (per-tile clocks showed half-empty CUs for the
+// second half of a frame).  Lanes that finish a ray take the next job once RT_REFILL_MIN lanes are
+// idle: 64 (whole tiles) for rendering, because coherent camera rays lose more from sharing a
+// wavefront with another tile than they gain from refilled lanes; fewer for incoherent ray buffers.
+// Primary and occlusion rays of different pixels share a wavefront (any-hit is a per-lane flag).
+// Rendering is deferred: this kernel leaves 24-byte hit records, rt_shade_kernel makes pixels.
+// Per-ray semantics -- and therefore results -- do not depend on the schedule.
 // ---------------------------------------------------------------------------------------------
-#define KIND_DONE 0xFFFFFFFEu
-#define KIND_IDLE 0xFFFFFFFDu
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 64    // fetch new jobs once this many lanes are idle (64 = whole tiles: coherent primary rays
-                            // lose more from mixed tiles than they gain from refilled lanes; measured)
+#define RT_REFILL_MIN 64    // render jobs: fetch once this many lanes are idle (64 = whole tiles)
 #endif
 #ifndef RT_FINISH_MIN
-#define RT_FINISH_MIN 64    // leave the traversal loop once this many lanes have a finished ray
+#define RT_FINISH_MIN 64    // render jobs: leave the traversal loop once this many lanes have finished
 #endif
-#ifndef RT_WHILE_WHILE
-#define RT_WHILE_WHILE 0    // 1: node steps loop until no lane holds a node before leaves are tested
+#ifndef RT_TRACE_REFILL_MIN
+#define RT_TRACE_REFILL_MIN 16   // ray-buffer jobs (incoherent): refill early, measured +7 %
 #endif
-
+#ifndef RT_TRACE_FINISH_MIN
+#define RT_TRACE_FINISH_MIN 16
+#endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 64         // jobs reserved per global atomic (one 8x8 tile)
 #endif
 #ifndef QUEUE_SHARDS
-#define QUEUE_SHARDS 8u
+#define QUEUE_SHARDS 8u     // one device-scope counter saturates near 90 dequeues/us
 #endif
 #define QUEUE_STRIDE 32u    // one 128-byte line per shard counter
 
@@ -496,34 +344,39 @@ enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2 };
 struct PersistArgs {
   uint32_t W, H, y0, y1, tiles_x;
   uint32_t total;                 // number of jobs (tiles*64 pixels, or rays)
-  uint32_t* dst; HitRec* hits; float* colors;          // render outputs (hits / colors optional)
+  HitRec* hits;                   // render: W*H hit records (occlusion in bit 31 of blasIdx); trace: n records
   const float* rays; const float* tmax; int any_hit;   // trace inputs
-  unsigned long long* counters;   // [0] rays (+ STATS: [1..6])
+  unsigned long long* counters;   // [0] rays (+ STATS: [1..4])
   uint32_t* status;
   uint32_t* queue;                // QUEUE_SHARDS counters (QUEUE_STRIDE dwords apart), zeroed by the host before the launch
   uint32_t per_shard;             // jobs per shard (multiple of 64)
 };
 
-__device__ __forceinline__ bool is_leaf_kind(uint32_t b) { return b - 1u < 0x7fffffffu; }
-__device__ __forceinline__ bool is_work_kind(uint32_t b) { return b <= KIND_INSTANCE; }   // node, leaf or instance
+__device__ __forceinline__ bool is_node_desc(uint32_t d) { return d < 0x80000000u; }
+__device__ __forceinline__ bool is_leaf_desc(uint32_t d) { return (d >> 30) == DK_LEAF; }
+__device__ __forceinline__ bool is_inst_desc(uint32_t d) { return d >= 0xC0000000u && d < DESC_IDLE; }
+__device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE; }
 
 template <int JOB, bool STATS>
 __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+  constexpr uint32_t REFILL_MIN = JOB == JOB_TRACE ? RT_TRACE_REFILL_MIN : RT_REFILL_MIN;
+  constexpr uint32_t FINISH_MIN = JOB == JOB_TRACE ? RT_TRACE_FINISH_MIN : RT_FINISH_MIN;
   const uint32_t lane = threadIdx.x & 63u;
 
   // ---- per-lane ray state ----
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, wix = 0, wiy = 0, wiz = 0;          // world ray
   float cox = 0, coy = 0, coz = 0, cdx = 0, cdy = 0, cdz = 0, cix = 0, ciy = 0, ciz = 0;    // object-space ray
   float hitd = 0, hbx = 0, hby = 0, hbz = 0, path_m = 0;
-  uint32_t hblas = 0, htri = 0, blasIdx = 0, cur_a = 0, cur_b = KIND_IDLE, job = 0, iters = 0;
+  uint32_t hblas = 0, htri = 0, blasIdx = 0, cur = DESC_IDLE, job = 0, iters = 0;
   bool found = false, anyhit = false, lane_fast = true, shadow_phase = false;
-  uint32_t stk_a[RT_STACK_ENTRIES], stk_b[RT_STACK_ENTRIES];
+  uint32_t stk_d[RT_STACK_ENTRIES];
   float stk_m[RT_STACK_ENTRIES];
   int sp = 0;
   // wave-uniform job-queue state
   bool queue_empty = false;
   uint32_t shard = blockIdx.x % QUEUE_SHARDS;   // blocks b and b+8 share an XCD (observed dispatch order; speed only)
   uint32_t tries = 0, loc_next = 0, loc_end = 0;
+  const bool ldexp_decode = sc.exact_decode != 0u;
   Fetches fx;
   unsigned nrays = 0, nhit = 0;
 
@@ -531,30 +384,31 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
   auto start_ray = [&](float tmax_, bool any_) {
     wix = 1.0f / dx; wiy = 1.0f / dy; wiz = 1.0f / dz;
     cox = ox; coy = oy; coz = oz; cdx = dx; cdy = dy; cdz = dz; cix = wix; ciy = wiy; ciz = wiz;
+    // a lane may use v_min/v_max only if no slab product can be NaN
     lane_fast = (wix - wix == 0.0f) && (wiy - wiy == 0.0f) && (wiz - wiz == 0.0f) &&
                 (ox - ox == 0.0f) && (oy - oy == 0.0f) && (oz - oz == 0.0f);
     hitd = tmax_; hbx = 0; hby = 0; hbz = 0; hblas = 0; htri = 0; found = false; anyhit = any_;
-    blasIdx = 0; cur_a = sc.tlas_root.x; cur_b = sc.tlas_root.y; path_m = -__builtin_inff(); sp = 0; iters = 0;
+    blasIdx = 0; cur = sc.tlas_root; path_m = -__builtin_inff(); sp = 0; iters = 0;   // rt_traversal.cpp:39-40
     nrays++;
   };
-  // next pending work item of this lane, or KIND_DONE when its stack is exhausted
+  // next pending work item of this lane (m < hit.dist: the reference's re-filtering),
+  // or DESC_DONE when its stack is exhausted
   auto pop_next = [&]() {
-    cur_b = KIND_DONE;
+    cur = DESC_DONE;
     while (sp > 0) {
       --sp;
       const float m = stk_m[sp];
-      if (m < hitd) { cur_a = stk_a[sp]; cur_b = stk_b[sp]; path_m = m; break; }
+      if (m < hitd) { cur = stk_d[sp]; path_m = m; break; }
     }
   };
 
   for (;;) {
     // ================= fetch: hand new jobs to idle lanes =================
-    // Jobs are reserved per wavefront in chunks from one of 8 queue shards (one global atomic per
-    // RT_CHUNK jobs: a single device-scope counter saturates near 90 dequeues/us on MI355X, far below
-    // what per-lane refills would need); lanes then draw from the wavefront's private range.
+    // Jobs are reserved per wavefront in chunks from one of the queue shards (one global atomic per
+    // RT_CHUNK jobs); lanes then draw from the wavefront's private range.
     {
-      const unsigned long long idle = __ballot(cur_b == KIND_IDLE);
-      if (!queue_empty && idle != 0ull && (idle == ~0ull || __popcll(idle) >= RT_REFILL_MIN)) {
+      const unsigned long long idle = __ballot(cur == DESC_IDLE);
+      if (!queue_empty && idle != 0ull && (idle == ~0ull || (uint32_t)__popcll(idle) >= REFILL_MIN)) {
         if (loc_next == loc_end) {   // wave-uniform: reserve the next chunk, stealing from other shards when the home shard is dry
           while (tries < QUEUE_SHARDS) {
             const uint32_t s_lo = shard * A.per_shard;
@@ -569,7 +423,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
           if (tries >= QUEUE_SHARDS) queue_empty = true;
         }
         const uint32_t avail = loc_end - loc_next;
-        if (avail != 0u && cur_b == KIND_IDLE) {
+        if (avail != 0u && cur == DESC_IDLE) {
           const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
           if (rank < avail) {
             const uint32_t r = loc_next + rank;
@@ -591,48 +445,44 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
         }
         loc_next += min(avail, (uint32_t)__popcll(idle));
       }
-      if (__ballot(cur_b != KIND_IDLE) == 0ull) {
+      if (__ballot(cur != DESC_IDLE) == 0ull) {
         if (queue_empty && loc_next == loc_end) break;
         continue;
       }
     }
 
-    // ================= traverse (while-while) =================
+    // ================= traverse: one step of whatever each lane holds, per iteration =================
     for (;;) {
-      // ---- all lanes that hold an internal node ----
-#if RT_WHILE_WHILE
-      while (__any(cur_b == 0u)) {
-#else
-      {
-#endif
-        if (cur_b == 0u) {
-          const bool top = (cur_a & TLAS_FLAG) != 0u;
-          const uint4* np = top ? sc.tlas_w + (size_t)(cur_a & ~TLAS_FLAG) * (WIDE_DWORDS / 4) : sc.bvh_w + (size_t)cur_a * (WIDE_DWORDS / 4);
-          if (STATS) fx.node++;
-          const float rox = top ? ox : cox, roy = top ? oy : coy, roz = top ? oz : coz;
-          const float rix = top ? wix : cix, riy = top ? wiy : ciy, riz = top ? wiz : ciz;
-          Cand c[4];
-          if (__all(lane_fast)) eval_children<false>(np, rox, roy, roz, rix, riy, riz, hitd, c);
-          else                  eval_children<true>(np, rox, roy, roz, rix, riy, riz, hitd, c);
-          int n = (c[0].d < __builtin_inff()) + (c[1].d < __builtin_inff()) + (c[2].d < __builtin_inff()) + (c[3].d < __builtin_inff());
-          cmpx(c[0], c[1]); cmpx(c[2], c[3]); cmpx(c[0], c[2]); cmpx(c[1], c[3]); cmpx(c[1], c[2]);
-          if (n > 0) {
-            if (sp + 3 > RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
-            if (n > 3) { stk_a[sp] = c[3].a; stk_b[sp] = c[3].b; stk_m[sp] = fmaxf(path_m, c[3].d); ++sp; }
-            if (n > 2) { stk_a[sp] = c[2].a; stk_b[sp] = c[2].b; stk_m[sp] = fmaxf(path_m, c[2].d); ++sp; }
-            if (n > 1) { stk_a[sp] = c[1].a; stk_b[sp] = c[1].b; stk_m[sp] = fmaxf(path_m, c[1].d); ++sp; }
-            cur_a = c[0].a; cur_b = c[0].b;
-            path_m = fmaxf(path_m, c[0].d);
-          } else {
-            pop_next();
-          }
-          if (++iters > ITER_LIMIT) { atomicOr(A.status, STATUS_ITER_LIMIT); cur_b = KIND_DONE; }
+      if (is_node_desc(cur)) {
+        // ---- internal node: 4 box tests, order, push the far ones, continue with the nearest ----
+        const bool top = (cur >> 30) == DK_TLAS;
+        const uint4* np = (top ? sc.tlas_c : sc.bvh_c) + (size_t)(cur & PAYLOAD_MASK) * CNODE_VEC4;
+        if (STATS) fx.node++;
+        const float rox = top ? ox : cox, roy = top ? oy : coy, roz = top ? oz : coz;
+        const float rix = top ? wix : cix, riy = top ? wiy : ciy, riz = top ? wiz : ciz;
+        Cand c[4];
+        // wave-uniform choice: v_min/v_max slabs unless some active lane could see a NaN product
+        if (__all(lane_fast)) eval_children<false>(np, top, ldexp_decode, rox, roy, roz, rix, riy, riz, hitd, c);
+        else                  eval_children<true>(np, top, ldexp_decode, rox, roy, roz, rix, riy, riz, hitd, c);
+        int n = (c[0].d < __builtin_inff()) + (c[1].d < __builtin_inff()) + (c[2].d < __builtin_inff()) + (c[3].d < __builtin_inff());
+        cmpx(c[0], c[1]); cmpx(c[2], c[3]); cmpx(c[0], c[2]); cmpx(c[1], c[3]); cmpx(c[1], c[2]);
+        if (n > 0) {
+          if (sp + 3 > RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
+          // far first so that the nearest pending sibling is on top (:98-103)
+          if (n > 3) { stk_d[sp] = c[3].desc; stk_m[sp] = fmaxf(path_m, c[3].d); ++sp; }
+          if (n > 2) { stk_d[sp] = c[2].desc; stk_m[sp] = fmaxf(path_m, c[2].d); ++sp; }
+          if (n > 1) { stk_d[sp] = c[1].desc; stk_m[sp] = fmaxf(path_m, c[1].d); ++sp; }
+          cur = c[0].desc;
+          path_m = fmaxf(path_m, c[0].d);
+        } else {
+          pop_next();
         }
+        if (++iters > ITER_LIMIT) { atomicOr(A.status, STATUS_ITER_LIMIT); cur = DESC_DONE; }
       }
-      // ---- instance records (TLAS leaves, rt_traversal.cpp:109-121) ----
-      if (__any(cur_b == KIND_INSTANCE)) {
-        if (cur_b == KIND_INSTANCE) {
-          blasIdx = cur_a;
+      if (__any(is_inst_desc(cur))) {
+        // ---- TLAS leaf (:109-121): fetch the instance record, move the ray to object space ----
+        if (is_inst_desc(cur)) {
+          blasIdx = cur & PAYLOAD_MASK;
           const uint32_t* bp = sc.blas + (size_t)blasIdx * (RT_BLAS_STRIDE / 4);
           uint32_t bw[13];
 #pragma unroll
@@ -651,18 +501,18 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
           const bool s2 = (cix - cix == 0.0f) && (ciy - ciy == 0.0f) && (ciz - ciz == 0.0f) &&
                           (cox - cox == 0.0f) && (coy - coy == 0.0f) && (coz - coz == 0.0f);
           lane_fast = lane_fast && s2;
-          const uint2 r = sc.blas_root[blasIdx];   // BLAS root: same level, path_m unchanged
-          cur_a = r.x; cur_b = r.y;
+          cur = sc.blas_root[blasIdx];   // BLAS root: same level, path_m unchanged
         }
-#if RT_WHILE_WHILE
-        continue;   // the BLAS roots are usually internal nodes: back to the node loop
-#endif
       }
-      // ---- all lanes that hold a leaf (:123-161) ----
-      if (__any(is_leaf_kind(cur_b))) {
-        if (is_leaf_kind(cur_b)) {
+      if (__any(is_leaf_desc(cur))) {
+        // ---- BLAS leaf (:123-161): triangles in index order, strict '<' ----
+        if (is_leaf_desc(cur)) {
           if (STATS) fx.node++;
-          const uint32_t leftFirst = cur_a, triCount = cur_b;
+          uint32_t leftFirst = cur & LEAF_FIRST_MASK, triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
+          if (triCount == 0u) {   // leaf with more than 15 triangles: range kept in the reference node
+            const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS;
+            leftFirst = rn[4]; triCount = rn[5];
+          }
           bool stop = false;
           for (uint32_t i = 0; i < triCount; ++i) {
             const uint32_t triIdx = leftFirst + i;
@@ -675,37 +525,35 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
               hitd = d; hbx = bx; hby = by; hbz = bz; hblas = blasIdx; htri = triIdx;
               found = true;
               if (anyhit) { stop = true; break; }
-              if (!(path_m < hitd)) break;   // reference re-descent abandons this subtree
+              // the reference re-descends from the root with the shrunken hit.dist; if any box on the
+              // current path no longer passes `d < hit.dist` it abandons this subtree
+              if (!(path_m < hitd)) break;
             }
           }
-          if (stop) { sp = 0; cur_b = KIND_DONE; }
+          if (stop) { sp = 0; cur = DESC_DONE; }
           else pop_next();
-          if (++iters > ITER_LIMIT) { atomicOr(A.status, STATUS_ITER_LIMIT); cur_b = KIND_DONE; }
+          if (++iters > ITER_LIMIT) { atomicOr(A.status, STATUS_ITER_LIMIT); cur = DESC_DONE; }
         }
       }
-      const unsigned long long work = __ballot(is_work_kind(cur_b));
-      const unsigned long long done = __ballot(cur_b == KIND_DONE);
-      if (work == 0ull || __popcll(done) >= RT_FINISH_MIN) break;
+      const unsigned long long work = __ballot(is_work_desc(cur));
+      const unsigned long long done = __ballot(cur == DESC_DONE);
+      if (work == 0ull || (uint32_t)__popcll(done) >= FINISH_MIN) break;
     }
 
     // ================= finish: rays whose traversal ended =================
-    if (cur_b == KIND_DONE) {
+    if (cur == DESC_DONE) {
       if (!found) hitd = RT_LARGE_FLOAT;
+      HitRec h; h.dist = hitd; h.bx = hbx; h.by = hby; h.bz = hbz; h.blasIdx = hblas; h.triIdx = htri;
+      if (!found) { h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0; }
       if (JOB == JOB_TRACE) {
-        HitRec h; h.dist = hitd; h.bx = hbx; h.by = hby; h.bz = hbz; h.blasIdx = hblas; h.triIdx = htri;
-        if (!found) { h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0; }
         A.hits[job] = h;
-        cur_b = KIND_IDLE;
+        cur = DESC_IDLE;
       } else {
-        // deferred shading: the traversal kernel only leaves hit records behind (24 B per pixel in
-        // A.hits, occlusion in bit 31 of blasIdx); rt_shade_kernel turns them into pixels in one
-        // coherent pass.  Finishing a ray therefore costs one store, not a chain of dependent loads.
+        // deferred shading: finishing a ray costs one store, not a chain of dependent loads
         const uint32_t tile = job >> 6, l = job & 63u;
         const uint32_t x = (tile % A.tiles_x) * 8u + (l & 7u), y = A.y0 + (tile / A.tiles_x) * 8u + (l >> 3);
         const size_t idx = (size_t)x + (size_t)y * A.W;
         if (!shadow_phase) {
-          HitRec h; h.dist = hitd; h.bx = hbx; h.by = hby; h.bz = hbz; h.blasIdx = hblas; h.triIdx = htri;
-          if (!found) { h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0; }
           A.hits[idx] = h;
           if (STATS && found) nhit++;
           if (JOB == JOB_RENDER_SHADOW && found) {
@@ -716,11 +564,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
             shadow_phase = true;
             start_ray(sdist, true);
           } else {
-            cur_b = KIND_IDLE;
+            cur = DESC_IDLE;
           }
         } else {
           if (found) atomicOr(&A.hits[idx].blasIdx, 0x80000000u);   // occluded
-          cur_b = KIND_IDLE;
+          cur = DESC_IDLE;
         }
       }
     }
@@ -737,8 +585,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
   }
 }
 
-// Deferred shading pass of the persistent path: one thread per pixel of rows [y0,y1), x fastest, so
-// hit records are read and pixels written fully coalesced.
+// Deferred shading pass: one thread per pixel of rows [y0,y1), x fastest, so hit records are read
+// and pixels written fully coalesced.
 template <bool STATS>
 __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams p, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
                                                       const HitRec* __restrict__ hb, uint32_t* __restrict__ dst,
@@ -776,14 +624,11 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
 }
 
 // ---------------------------------------------------------------------------------------------
-// acceleration-layout build (one pass over the reference-format buffers, validates every index
-// the traversal will follow so that a malformed scene is rejected on the host side instead of
-// faulting the GPU)
+// acceleration-layout build (one pass over the reference-format buffers; validates every index the
+// traversal will follow so that a malformed scene is rejected on the host instead of faulting the GPU)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float q_decode(float origin, uint32_t q, int e) { return origin + ldexpf((float)q, e); }  // rt_traversal.cpp:61-67
-
 // one thread per reference node of one buffer.  bases/ends: sorted BLAS node ranges (nb of them).
-__global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_nodes, uint4* __restrict__ wide, int is_tlas,
+__global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_nodes, uint4* __restrict__ out, int is_tlas,
                                    const uint32_t* __restrict__ bases, const uint32_t* __restrict__ ends, uint32_t nb,
                                    uint32_t n_tris, uint32_t n_blas, uint32_t* status) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -796,46 +641,56 @@ __global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_
     for (uint32_t j = 0; j < nb; ++j) if (i >= bases[j] && i < ends[j]) { base = bases[j]; end = ends[j]; in = true; }
     if (!in) return;   // node outside every instance's range: unreachable, leave untouched
   }
-  if (imask != (is_tlas ? 1u : 0u)) return;   // not a node of this kind (e.g. unused tail of the buffer): only reachable nodes are checked, via their parent
+  if (imask != (is_tlas ? 1u : 0u)) return;   // not a node of this kind (e.g. unused tail): reachable nodes are checked via their parent
   const bool leaf = is_tlas ? (leafData != 0xffffffffu) : (leafData != 0u);
   if (leaf) return;
   const float px = __uint_as_float(w[0]), py = __uint_as_float(w[1]), pz = __uint_as_float(w[2]);
-  const int ex = (int)(int8_t)(w[3] & 0xff), ey = (int)(int8_t)((w[3] >> 8) & 0xff), ez = (int)(int8_t)((w[3] >> 16) & 0xff);
-  float box[24];
-  uint32_t ca[4], cb[4];
+  const float po[3] = {px, py, pz};
+  const int ev[3] = {(int)(int8_t)(w[3] & 0xff), (int)(int8_t)((w[3] >> 8) & 0xff), (int)(int8_t)((w[3] >> 16) & 0xff)};
   const uint8_t* bytes = (const uint8_t*)w;
+  uint32_t kinds = 0, pay[4] = {0, 0, 0, 0};
+  uint8_t qb[24];
   for (int k = 0; k < 4; ++k) {
     const uint8_t* c = bytes + 24 + 7 * k;
-    for (int j = 0; j < 6; ++j) box[6 * k + j] = 0.0f;
-    ca[k] = 0; cb[k] = KIND_NONE;
+    for (int j = 0; j < 6; ++j) qb[6 * k + j] = c[1 + j];
     if (c[0] == 0) continue;   // meta (rt_traversal.cpp:60)
-    box[6 * k + 0] = q_decode(px, c[1], ex); box[6 * k + 1] = q_decode(py, c[2], ey); box[6 * k + 2] = q_decode(pz, c[3], ez);
-    box[6 * k + 3] = q_decode(px, c[4], ex); box[6 * k + 4] = q_decode(py, c[5], ey); box[6 * k + 5] = q_decode(pz, c[6], ez);
+    // fma decode must reproduce origin + ldexp(float(q), e) bit for bit (eval_children)
+    for (int j = 0; j < 6; ++j) {
+      const float q = (float)c[1 + j];
+      const float a = po[j % 3] + ldexpf(q, ev[j % 3]);
+      const float b = __fmaf_rn(q, ldexpf(1.0f, ev[j % 3]), po[j % 3]);
+      if (__float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b)) atomicOr(status, STATUS_FMA_DECODE_DIFFERS);
+    }
     const uint64_t ci64 = (uint64_t)base + leftFirst + (uint32_t)k;   // calcNodePtr(base_ptr, leftFirst + childIdx), :91-92
     // children are allocated after their parent by the builders (bvh.cpp:94-97, 371-402): requiring
     // that makes every accepted tree acyclic, so traversal terminates
-    if (ci64 >= end || ci64 <= i) { atomicOr(status, STATUS_BAD_SCENE); continue; }
+    if (ci64 >= end || ci64 <= i || ci64 > PAYLOAD_MASK) { atomicOr(status, STATUS_BAD_SCENE); continue; }
     const uint32_t ci = (uint32_t)ci64;
     const uint32_t* cw = ref + (size_t)ci * RT_NODE_DWORDS;
     const uint32_t c_imask = cw[3] >> 24, c_lf = cw[4], c_ld = cw[5];
     if (c_imask != (is_tlas ? 1u : 0u)) { atomicOr(status, STATUS_BAD_SCENE); continue; }
     if (is_tlas) {
       if (c_ld != 0xffffffffu) {
-        if (c_ld >= n_blas) { atomicOr(status, STATUS_BAD_SCENE); continue; }
-        ca[k] = c_ld; cb[k] = KIND_INSTANCE;
-      } else { ca[k] = TLAS_FLAG | ci; cb[k] = 0u; }
+        if (c_ld >= n_blas || c_ld >= 0x3FFFFFF0u) { atomicOr(status, STATUS_BAD_SCENE); continue; }
+        kinds |= 3u << (2 * k); pay[k] = c_ld;
+      } else kinds |= 1u << (2 * k);
     } else {
       if (c_ld != 0u) {
-        if (c_ld >= 0x80000000u || (uint64_t)c_lf + c_ld > n_tris) { atomicOr(status, STATUS_BAD_SCENE); continue; }
-        ca[k] = c_lf; cb[k] = c_ld;
-      } else { ca[k] = ci; cb[k] = 0u; }
+        if ((uint64_t)c_lf + c_ld > n_tris) { atomicOr(status, STATUS_BAD_SCENE); continue; }
+        kinds |= 2u << (2 * k);
+        pay[k] = (c_ld <= LEAF_MAX_INLINE && c_lf <= LEAF_FIRST_MASK) ? ((c_ld << LEAF_FIRST_BITS) | c_lf) : ci;   // else by reference
+        if (!(c_ld <= LEAF_MAX_INLINE && c_lf <= LEAF_FIRST_MASK) && ci > LEAF_FIRST_MASK) atomicOr(status, STATUS_BAD_SCENE);
+      } else kinds |= 1u << (2 * k);
     }
   }
-  uint4* o = wide + (size_t)i * (WIDE_DWORDS / 4);
-  for (int v = 0; v < 6; ++v)
-    o[v] = make_uint4(__float_as_uint(box[4 * v]), __float_as_uint(box[4 * v + 1]), __float_as_uint(box[4 * v + 2]), __float_as_uint(box[4 * v + 3]));
-  o[6] = make_uint4(ca[0], ca[1], ca[2], ca[3]);
-  o[7] = make_uint4(cb[0], cb[1], cb[2], cb[3]);
+  const uint64_t first64 = (uint64_t)base + leftFirst;
+  uint32_t qw[6];
+  for (int v = 0; v < 6; ++v) qw[v] = (uint32_t)qb[4 * v] | ((uint32_t)qb[4 * v + 1] << 8) | ((uint32_t)qb[4 * v + 2] << 16) | ((uint32_t)qb[4 * v + 3] << 24);
+  uint4* o = out + (size_t)i * CNODE_VEC4;
+  o[0] = make_uint4(w[0], w[1], w[2], (w[3] & 0x00ffffffu) | (kinds << 24));
+  o[1] = make_uint4((uint32_t)first64, qw[0], qw[1], qw[2]);
+  o[2] = make_uint4(qw[3], qw[4], qw[5], pay[0]);
+  o[3] = make_uint4(pay[1], pay[2], pay[3], 0u);
 }
 
 __global__ void accel_tris_kernel(const float* __restrict__ tri, uint32_t n, float4* __restrict__ out) {
@@ -851,27 +706,29 @@ __global__ void accel_tris_kernel(const float* __restrict__ tri, uint32_t n, flo
 
 // root descriptors: thread 0 -> TLAS root, thread 1+j -> BLAS root of instance record j
 __global__ void accel_roots_kernel(const uint32_t* __restrict__ tlas, const uint32_t* __restrict__ bvh, const uint32_t* __restrict__ blas,
-                                   uint32_t n_tlas, uint32_t n_bvh, uint32_t n_blas, uint32_t n_tris, uint2* tlas_root, uint2* blas_root,
+                                   uint32_t n_tlas, uint32_t n_bvh, uint32_t n_blas, uint32_t n_tris, uint32_t* tlas_root, uint32_t* blas_root,
                                    uint32_t* status) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t == 0) {
     const uint32_t imask = tlas[3] >> 24, ld = tlas[5];
-    if (imask != 1u) { atomicOr(status, STATUS_BAD_SCENE); *tlas_root = make_uint2(0u, KIND_NONE); }
+    *tlas_root = DESC_DONE;
+    if (imask != 1u) atomicOr(status, STATUS_BAD_SCENE);
     else if (ld != 0xffffffffu) {
-      if (ld >= n_blas) { atomicOr(status, STATUS_BAD_SCENE); *tlas_root = make_uint2(0u, KIND_NONE); }
-      else *tlas_root = make_uint2(ld, KIND_INSTANCE);
-    } else *tlas_root = make_uint2(TLAS_FLAG | 0u, 0u);
+      if (ld >= n_blas || ld >= 0x3FFFFFF0u) atomicOr(status, STATUS_BAD_SCENE);
+      else *tlas_root = DESC(DK_INST, ld);
+    } else *tlas_root = DESC(DK_TLAS, 0u);
   } else if (t - 1 < n_blas) {
     const uint32_t j = t - 1;
     const uint32_t off = blas[(size_t)j * (RT_BLAS_STRIDE / 4)];
-    if (off >= n_bvh) { atomicOr(status, STATUS_BAD_SCENE); blas_root[j] = make_uint2(0u, KIND_NONE); return; }
+    blas_root[j] = DESC_DONE;
+    if (off >= n_bvh || off > LEAF_FIRST_MASK) { atomicOr(status, STATUS_BAD_SCENE); return; }
     const uint32_t* w = bvh + (size_t)off * RT_NODE_DWORDS;
     const uint32_t imask = w[3] >> 24, lf = w[4], ld = w[5];
-    if (imask != 0u) { atomicOr(status, STATUS_BAD_SCENE); blas_root[j] = make_uint2(0u, KIND_NONE); }
+    if (imask != 0u) atomicOr(status, STATUS_BAD_SCENE);
     else if (ld != 0u) {
-      if (ld >= 0x80000000u || (uint64_t)lf + ld > n_tris) { atomicOr(status, STATUS_BAD_SCENE); blas_root[j] = make_uint2(0u, KIND_NONE); }
-      else blas_root[j] = make_uint2(lf, ld);
-    } else blas_root[j] = make_uint2(off, 0u);
+      if ((uint64_t)lf + ld > n_tris) atomicOr(status, STATUS_BAD_SCENE);
+      else blas_root[j] = DESC(DK_LEAF, (ld <= LEAF_MAX_INLINE && lf <= LEAF_FIRST_MASK) ? ((ld << LEAF_FIRST_BITS) | lf) : off);
+    } else blas_root[j] = DESC(DK_BLAS, off);
   }
 }
 
@@ -913,14 +770,6 @@ static uint32_t* queue_slot(hipStream_t s) {
   return q;
 }
 
-// 0 = persistent while-while kernel (default), 1 = one-tile-per-wave kernel (kept for A/B and as a
-// second implementation the tests cross-check)
-static int kernel_choice() {
-  static int c = -1;
-  if (c < 0) { const char* e = getenv("VXRT_KERNEL"); c = (e && !strcmp(e, "simple")) ? 1 : 0; }
-  return c;
-}
-
 template <class K>
 static uint32_t persistent_grid(K kernel, uint64_t jobs) {
   int dev = 0, per_cu = 0, cus = 0;
@@ -937,7 +786,7 @@ static uint32_t persistent_grid(K kernel, uint64_t jobs) {
 struct vxrt_accel {
   SceneDev dev{};
   vxrt_scene_t ref{};
-  void* tlas_w = nullptr; void* bvh_w = nullptr; void* tri_w = nullptr; void* blas_root = nullptr;
+  void* tlas_c = nullptr; void* bvh_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr;
   void* hitbuf = nullptr;      // W*H hit records between the traversal and the shading pass
   uint64_t hitbuf_pixels = 0;
   int device = 0;
@@ -945,19 +794,19 @@ struct vxrt_accel {
 
 static void accel_free(vxrt_accel* a) {
   if (!a) return;
-  (void)hipFree(a->tlas_w); (void)hipFree(a->bvh_w); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
+  (void)hipFree(a->tlas_c); (void)hipFree(a->bvh_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
   (void)hipFree(a->hitbuf);
   delete a;
 }
 
 extern "C" {
 
-const char* vxrt_version(void) { return "vortex-rt-mi355x 0.2 (gfx950, wide-node layout)"; }
+const char* vxrt_version(void) { return "vortex-rt-mi355x 0.3 (gfx950, compact 64-byte nodes, persistent wavefronts)"; }
 
 int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   if (!s || !out || !s->tlas || !s->blas || !s->bvh || !s->tri) return -1;
   if (s->n_tlas_nodes == 0 || s->n_blas == 0 || s->n_bvh_nodes == 0 || s->n_tris == 0) return -1;
-  if (s->n_tlas_nodes >= 0x7fffffffu || s->n_bvh_nodes >= 0x7fffffffu || s->n_tris >= 0x7fffffffu) return -1;
+  if (s->n_tlas_nodes > PAYLOAD_MASK || s->n_bvh_nodes > PAYLOAD_MASK || s->n_tris >= 0x7fffffffu) return -1;
   hipStream_t st = (hipStream_t)stream;
   // instance node ranges (host side, n_blas is small): sorted unique bvh_offsets
   std::vector<uint32_t> recs((size_t)s->n_blas * (RT_BLAS_STRIDE / 4));
@@ -980,15 +829,14 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   (void)hipGetDevice(&a->device);
   uint32_t* d_ranges = nullptr;
   uint32_t* d_status = nullptr;
-  uint2* d_troot = nullptr;
-  bool ok = hipMalloc(&a->tlas_w, (size_t)s->n_tlas_nodes * WIDE_DWORDS * 4) == hipSuccess &&
-            hipMalloc(&a->bvh_w, (size_t)s->n_bvh_nodes * WIDE_DWORDS * 4) == hipSuccess &&
+  uint32_t* d_troot = nullptr;
+  bool ok = hipMalloc(&a->tlas_c, (size_t)s->n_tlas_nodes * CNODE_VEC4 * 16) == hipSuccess &&
+            hipMalloc(&a->bvh_c, (size_t)s->n_bvh_nodes * CNODE_VEC4 * 16) == hipSuccess &&
             hipMalloc(&a->tri_w, (size_t)s->n_tris * WTRI_FLOATS * 4) == hipSuccess &&
-            hipMalloc(&a->blas_root, (size_t)s->n_blas * sizeof(uint2)) == hipSuccess &&
+            hipMalloc(&a->blas_root, (size_t)s->n_blas * sizeof(uint32_t)) == hipSuccess &&
             hipMalloc((void**)&d_ranges, bases.size() * 8) == hipSuccess &&
-            hipMalloc((void**)&d_status, 4) == hipSuccess && hipMalloc((void**)&d_troot, sizeof(uint2)) == hipSuccess;
-  uint32_t hstatus = 0;
-  uint2 troot = make_uint2(0u, KIND_NONE);
+            hipMalloc((void**)&d_status, 4) == hipSuccess && hipMalloc((void**)&d_troot, 4) == hipSuccess;
+  uint32_t hstatus = 0, troot = DESC_DONE;
   if (ok) {
     ok = hipMemcpy(d_ranges, bases.data(), bases.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(d_ranges + bases.size(), ends.data(), ends.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -997,20 +845,22 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   if (ok) {
     const uint32_t nb = (uint32_t)bases.size();
     hipLaunchKernelGGL(accel_nodes_kernel, dim3((s->n_tlas_nodes + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->tlas, s->n_tlas_nodes,
-                       (uint4*)a->tlas_w, 1, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, s->n_tris, s->n_blas, d_status);
+                       (uint4*)a->tlas_c, 1, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, s->n_tris, s->n_blas, d_status);
     hipLaunchKernelGGL(accel_nodes_kernel, dim3((s->n_bvh_nodes + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->bvh, s->n_bvh_nodes,
-                       (uint4*)a->bvh_w, 0, d_ranges, d_ranges + nb, nb, s->n_tris, s->n_blas, d_status);
+                       (uint4*)a->bvh_c, 0, d_ranges, d_ranges + nb, nb, s->n_tris, s->n_blas, d_status);
     hipLaunchKernelGGL(accel_tris_kernel, dim3((s->n_tris + 255) / 256), dim3(256), 0, st, (const float*)s->tri, s->n_tris, (float4*)a->tri_w);
     hipLaunchKernelGGL(accel_roots_kernel, dim3((s->n_blas + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->tlas, (const uint32_t*)s->bvh,
-                       (const uint32_t*)s->blas, s->n_tlas_nodes, s->n_bvh_nodes, s->n_blas, s->n_tris, d_troot, (uint2*)a->blas_root, d_status);
+                       (const uint32_t*)s->blas, s->n_tlas_nodes, s->n_bvh_nodes, s->n_blas, s->n_tris, d_troot, (uint32_t*)a->blas_root, d_status);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
          hipMemcpy(&hstatus, d_status, 4, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(&troot, d_troot, sizeof troot, hipMemcpyDeviceToHost) == hipSuccess;
+         hipMemcpy(&troot, d_troot, 4, hipMemcpyDeviceToHost) == hipSuccess;
   }
   (void)hipFree(d_ranges); (void)hipFree(d_status); (void)hipFree(d_troot);
-  if (!ok || hstatus != 0) { accel_free(a); return -1; }   // malformed tree: rejected before any traversal
-  a->dev.tlas_w = (const uint4*)a->tlas_w; a->dev.bvh_w = (const uint4*)a->bvh_w; a->dev.tri_w = (const float4*)a->tri_w;
-  a->dev.blas_root = (const uint2*)a->blas_root; a->dev.tlas_root = troot;
+  if (!ok || (hstatus & STATUS_BAD_SCENE) != 0) { accel_free(a); return -1; }   // malformed tree: rejected before any traversal
+  a->dev.tlas_c = (const uint4*)a->tlas_c; a->dev.bvh_c = (const uint4*)a->bvh_c; a->dev.tri_w = (const float4*)a->tri_w;
+  a->dev.blas_root = (const uint32_t*)a->blas_root; a->dev.tlas_root = troot;
+  a->dev.exact_decode = (hstatus & STATUS_FMA_DECODE_DIFFERS) ? 1u : 0u;
+  a->dev.ref_bvh = (const uint32_t*)s->bvh;
   a->dev.blas = (const uint32_t*)s->blas; a->dev.triEx = (const rt_triex_t*)s->triEx;
   a->dev.mat = (const rt_material_t*)s->mat; a->dev.tex = (const uint8_t*)s->tex;
   *out = a;
@@ -1025,13 +875,13 @@ int vxrt_accel_destroy(vxrt_accel_t* a) {
 
 uint64_t vxrt_accel_bytes(const vxrt_accel_t* a) {
   if (!a) return 0;
-  return (uint64_t)a->ref.n_tlas_nodes * WIDE_DWORDS * 4 + (uint64_t)a->ref.n_bvh_nodes * WIDE_DWORDS * 4 +
-         (uint64_t)a->ref.n_tris * WTRI_FLOATS * 4 + (uint64_t)a->ref.n_blas * 8;
+  return (uint64_t)a->ref.n_tlas_nodes * CNODE_VEC4 * 16 + (uint64_t)a->ref.n_bvh_nodes * CNODE_VEC4 * 16 +
+         (uint64_t)a->ref.n_tris * WTRI_FLOATS * 4 + (uint64_t)a->ref.n_blas * 4;
 }
 
 static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits, float* colors,
-                         unsigned long long* counters, bool stats, void* stream, unsigned long long* tile_clock = nullptr) {
+                         unsigned long long* counters, bool stats, void* stream) {
   if (!a || !params || !dst) return -1;
   if (!a->ref.triEx || !a->ref.mat || a->ref.n_mats == 0) return -1;  // shading needs them (closest.cpp:52-55)
   if (width == 0 || height == 0 || y0 > y1 || y1 > height) return -1;
@@ -1047,43 +897,34 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   p.max_depth = params->max_depth;
   const uint32_t tiles_x = (width + 7) / 8, tiles_y = (y1 - y0 + 7) / 8;
   const uint64_t n_tiles64 = (uint64_t)tiles_x * tiles_y;
-  if (n_tiles64 > 0x7fffffffull) return -1;
+  if (n_tiles64 > 0x1ffffffull) return -1;
   const uint32_t n_tiles = (uint32_t)n_tiles64;
-  dim3 grid((n_tiles + 3) / 4), block(256);
+  dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   const SceneDev& sc = a->dev;
-  if (kernel_choice() == 0 && !tile_clock) {
-    if (n_tiles > 0x1ffffffu) return -1;
-    // hit-record buffer between the two passes (one render in flight per accel)
-    const uint64_t pixels = (uint64_t)width * height;
-    if (a->hitbuf_pixels < pixels) {
-      if (hipStreamSynchronize(s) != hipSuccess) return -1;
-      (void)hipFree(a->hitbuf);
-      a->hitbuf = nullptr; a->hitbuf_pixels = 0;
-      if (hipMalloc(&a->hitbuf, pixels * sizeof(HitRec)) != hipSuccess) return -1;
-      a->hitbuf_pixels = pixels;
-    }
-    PersistArgs A{};
-    A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.total = n_tiles * 64u;
-    A.dst = dst; A.hits = (HitRec*)a->hitbuf; A.colors = nullptr; A.counters = counters; A.status = st;
-    A.queue = queue_slot(s);
-    if (!A.queue) return -1;
-    A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
-#define LAUNCH_P(J, ST) hipLaunchKernelGGL((rt_persistent_kernel<J, ST>), dim3(persistent_grid(rt_persistent_kernel<J, ST>, A.total)), block, 0, s, sc, p, A)
-    if (stats) { if (shadow) LAUNCH_P(JOB_RENDER_SHADOW, true); else LAUNCH_P(JOB_RENDER, true); }
-    else       { if (shadow) LAUNCH_P(JOB_RENDER_SHADOW, false); else LAUNCH_P(JOB_RENDER, false); }
-#undef LAUNCH_P
-    const uint64_t npx = (uint64_t)width * (y1 - y0);
-    dim3 sgrid((uint32_t)((npx + 255) / 256));
-    if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
-    else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+  // hit-record buffer between the two passes (one render in flight per accel)
+  const uint64_t pixels = (uint64_t)width * height;
+  if (a->hitbuf_pixels < pixels) {
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    (void)hipFree(a->hitbuf);
+    a->hitbuf = nullptr; a->hitbuf_pixels = 0;
+    if (hipMalloc(&a->hitbuf, pixels * sizeof(HitRec)) != hipSuccess) return -1;
+    a->hitbuf_pixels = pixels;
   }
-#define LAUNCH_RENDER(SH, ST) hipLaunchKernelGGL((rt_render_kernel<SH, ST>), grid, block, 0, s, sc, p, width, height, y0, tiles_x, n_tiles, y1, \
-                                                 dst, (HitRec*)hits, colors, counters, st, tile_clock)
-  if (stats) { if (shadow) LAUNCH_RENDER(true, true); else LAUNCH_RENDER(false, true); }
-  else       { if (shadow) LAUNCH_RENDER(true, false); else LAUNCH_RENDER(false, false); }
-#undef LAUNCH_RENDER
+  PersistArgs A{};
+  A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.total = n_tiles * 64u;
+  A.hits = (HitRec*)a->hitbuf; A.counters = counters; A.status = st;
+  A.queue = queue_slot(s);
+  if (!A.queue) return -1;
+  A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
+#define LAUNCH_P(J, ST) hipLaunchKernelGGL((rt_persistent_kernel<J, ST>), dim3(persistent_grid(rt_persistent_kernel<J, ST>, A.total)), block, 0, s, sc, p, A)
+  if (stats) { if (shadow) LAUNCH_P(JOB_RENDER_SHADOW, true); else LAUNCH_P(JOB_RENDER, true); }
+  else       { if (shadow) LAUNCH_P(JOB_RENDER_SHADOW, false); else LAUNCH_P(JOB_RENDER, false); }
+#undef LAUNCH_P
+  const uint64_t npx = (uint64_t)width * (y1 - y0);
+  dim3 sgrid((uint32_t)((npx + 255) / 256));
+  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
+  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1093,13 +934,13 @@ int vxrt_render(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y
   return render_common(accel, width, height, y0, y1, params, shadow, dst, hits, colors, rays_traced, false, stream);
 }
 
-// Same launch as vxrt_render with the fetch counters compiled in (slower; never the timed path).
+// Same launches as vxrt_render with the fetch counters compiled in (slower; never the timed path).
 // counters: device u64[7] = rays, node fetches, instance fetches, triangle fetches, shaded hits,
 // textured hits, pixels written -- the inputs of the algorithmic-bytes formula.
 int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                       const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
-                      unsigned long long* counters, unsigned long long* tile_clock, void* stream) {
-  return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream, tile_clock);
+                      unsigned long long* counters, void* stream) {
+  return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream);
 }
 
 int vxrt_trace(const vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax,
@@ -1107,26 +948,17 @@ int vxrt_trace(const vxrt_accel_t* a, const float* rays, uint64_t n, const float
   if (!a || (n && (!rays || !hits))) return -1;
   if (mode != VXRT_MODE_CLOSEST && mode != VXRT_MODE_ANY) return -1;
   if (n == 0) return 0;
-  if ((n + 255) / 256 > 0x7fffffffull) return -1;
+  if (n > 0x7fffffffull) return -1;
   uint32_t* st = status_word();
   if (!st) return -1;
-  dim3 grid((uint32_t)((n + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (kernel_choice() == 0) {
-    if (n > 0x7fffffffull) return -1;
-    PersistArgs A{};
-    A.total = (uint32_t)n; A.hits = (HitRec*)hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
-    A.status = st; A.queue = queue_slot(s);
-    if (!A.queue) return -1;
-    A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
-    ShadeParams p{};
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false>, n)), block, 0, s, a->dev, p, A);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-  }
-  if (mode == VXRT_MODE_ANY)
-    hipLaunchKernelGGL(rt_trace_kernel<true>, grid, block, 0, s, a->dev, rays, n, tmax, (HitRec*)hits, st);
-  else
-    hipLaunchKernelGGL(rt_trace_kernel<false>, grid, block, 0, s, a->dev, rays, n, tmax, (HitRec*)hits, st);
+  PersistArgs A{};
+  A.total = (uint32_t)n; A.hits = (HitRec*)hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
+  A.status = st; A.queue = queue_slot(s);
+  if (!A.queue) return -1;
+  A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
+  ShadeParams p{};
+  hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false>, n)), dim3(256), 0, s, a->dev, p, A);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -49,7 +49,7 @@ def _lib():
                                   C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vxrt_render_stats.restype = C.c_int
         L.vxrt_render_stats.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                        C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                        C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vxrt_trace.restype = C.c_int
         L.vxrt_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.vxrt_status.restype = C.c_int
@@ -92,21 +92,15 @@ def algorithmic_bytes(c):
             + (64 + 88) * c["shaded_hits"] + 4 * c["textured_hits"] + 4 * c["pixels"])
 
 
-def render_stats(accel, width, height, y0, y1, params, dst_ptr, shadow=0, stream=None, tile_clock=False):
-    """Runs the counting build of the render kernel once; returns the counters + algorithmic bytes
-    (and, with tile_clock=True, the [tiles, 2] begin/end 100 MHz clock of every tile's wavefront)."""
+def render_stats(accel, width, height, y0, y1, params, dst_ptr, shadow=0, stream=None):
+    """Runs the counting build of the render kernels once; returns the counters + algorithmic bytes."""
     import torch
-    dev = "cuda:%d" % torch.cuda.current_device()
-    cnt = torch.zeros(8, dtype=torch.int64, device=dev)
-    n_tiles = ((width + 7) // 8) * ((y1 - y0 + 7) // 8)
-    clk = torch.zeros((n_tiles, 2), dtype=torch.int64, device=dev) if tile_clock else None
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda:%d" % torch.cuda.current_device())
     check(_lib().vxrt_render_stats(accel, width, height, y0, y1, C.byref(params), int(shadow), dst_ptr,
-                                   cnt.data_ptr(), clk.data_ptr() if tile_clock else None, stream), "vxrt_render_stats")
+                                   cnt.data_ptr(), stream), "vxrt_render_stats")
     torch.cuda.synchronize()
     c = dict(zip(STAT_KEYS, [int(v) for v in cnt[:7].tolist()]))
     c["bytes"] = algorithmic_bytes(c)
-    if tile_clock:
-        c["tile_clock"] = clk.cpu().numpy()
     return c
 
 
