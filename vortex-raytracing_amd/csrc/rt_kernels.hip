@@ -338,6 +338,9 @@ __device__ __forceinline__ void generate_ray(uint32_t x, uint32_t y, uint32_t W,
 #define QUEUE_SHARDS 8u     // one device-scope counter saturates near 90 dequeues/us
 #endif
 #define QUEUE_STRIDE 32u    // one 128-byte line per shard counter
+#ifndef LDS_STACK
+#define LDS_STACK 16        // stack levels kept in LDS per lane (8 KiB per wavefront)
+#endif
 
 enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2 };
 
@@ -369,9 +372,17 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
   float hitd = 0, hbx = 0, hby = 0, hbz = 0, path_m = 0;
   uint32_t hblas = 0, htri = 0, blasIdx = 0, cur = DESC_IDLE, job = 0, iters = 0;
   bool found = false, anyhit = false, lane_fast = true, shadow_phase = false;
-  uint32_t stk_d[RT_STACK_ENTRIES];
-  float stk_m[RT_STACK_ENTRIES];
-  int sp = 0;
+  // Traversal stack: the newest pending entry lives in registers (tos_*), the next LDS_STACK in LDS
+  // (one 64-lane row of 8-byte entries per level: conflict-free ds_write_b64/ds_read_b64), deeper ones
+  // in scratch.  A pop therefore never waits on memory: it takes the register copy and the refill
+  // from LDS overlaps the next node's box tests.  The scenes of SURVEY.md s8d never go deeper than 14.
+  __shared__ uint2 s_stk[4][LDS_STACK][64];
+  uint2* const lstk = &s_stk[threadIdx.x >> 6][0][lane];
+  uint32_t ovf_d[RT_STACK_ENTRIES];
+  float ovf_m[RT_STACK_ENTRIES];
+  uint32_t tos_d = DESC_DONE;   // DESC_DONE = no pending entry
+  float tos_m = 0;
+  int sp = 0;                   // entries below the register top (in LDS / scratch)
   // wave-uniform job-queue state
   bool queue_empty = false;
   uint32_t shard = blockIdx.x % QUEUE_SHARDS;   // blocks b and b+8 share an XCD (observed dispatch order; speed only)
@@ -388,17 +399,32 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
     lane_fast = (wix - wix == 0.0f) && (wiy - wiy == 0.0f) && (wiz - wiz == 0.0f) &&
                 (ox - ox == 0.0f) && (oy - oy == 0.0f) && (oz - oz == 0.0f);
     hitd = tmax_; hbx = 0; hby = 0; hbz = 0; hblas = 0; htri = 0; found = false; anyhit = any_;
-    blasIdx = 0; cur = sc.tlas_root; path_m = -__builtin_inff(); sp = 0; iters = 0;   // rt_traversal.cpp:39-40
+    blasIdx = 0; cur = sc.tlas_root; path_m = -__builtin_inff(); sp = 0; tos_d = DESC_DONE; iters = 0;   // rt_traversal.cpp:39-40
     nrays++;
   };
   // next pending work item of this lane (m < hit.dist: the reference's re-filtering),
   // or DESC_DONE when its stack is exhausted
+  auto push = [&](uint32_t d, float m) {
+    if (tos_d != DESC_DONE) {
+      if (sp < LDS_STACK) lstk[sp * 64] = make_uint2(tos_d, __float_as_uint(tos_m));
+      else { ovf_d[sp - LDS_STACK] = tos_d; ovf_m[sp - LDS_STACK] = tos_m; }
+      ++sp;
+    }
+    tos_d = d; tos_m = m;
+  };
   auto pop_next = [&]() {
     cur = DESC_DONE;
-    while (sp > 0) {
-      --sp;
-      const float m = stk_m[sp];
-      if (m < hitd) { cur = stk_d[sp]; path_m = m; break; }
+    while (tos_d != DESC_DONE) {
+      const uint32_t d = tos_d;
+      const float m = tos_m;
+      if (sp > 0) {
+        --sp;
+        if (sp < LDS_STACK) { const uint2 e = lstk[sp * 64]; tos_d = e.x; tos_m = __uint_as_float(e.y); }
+        else { tos_d = ovf_d[sp - LDS_STACK]; tos_m = ovf_m[sp - LDS_STACK]; }
+      } else {
+        tos_d = DESC_DONE;
+      }
+      if (m < hitd) { cur = d; path_m = m; break; }
     }
   };
 
@@ -467,11 +493,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
         int n = (c[0].d < __builtin_inff()) + (c[1].d < __builtin_inff()) + (c[2].d < __builtin_inff()) + (c[3].d < __builtin_inff());
         cmpx(c[0], c[1]); cmpx(c[2], c[3]); cmpx(c[0], c[2]); cmpx(c[1], c[3]); cmpx(c[1], c[2]);
         if (n > 0) {
-          if (sp + 3 > RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
+          if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
           // far first so that the nearest pending sibling is on top (:98-103)
-          if (n > 3) { stk_d[sp] = c[3].desc; stk_m[sp] = fmaxf(path_m, c[3].d); ++sp; }
-          if (n > 2) { stk_d[sp] = c[2].desc; stk_m[sp] = fmaxf(path_m, c[2].d); ++sp; }
-          if (n > 1) { stk_d[sp] = c[1].desc; stk_m[sp] = fmaxf(path_m, c[1].d); ++sp; }
+          if (n > 3) push(c[3].desc, fmaxf(path_m, c[3].d));
+          if (n > 2) push(c[2].desc, fmaxf(path_m, c[2].d));
+          if (n > 1) push(c[1].desc, fmaxf(path_m, c[1].d));
           cur = c[0].desc;
           path_m = fmaxf(path_m, c[0].d);
         } else {
@@ -530,7 +556,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
               if (!(path_m < hitd)) break;
             }
           }
-          if (stop) { sp = 0; cur = DESC_DONE; }
+          if (stop) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
           else pop_next();
           if (++iters > ITER_LIMIT) { atomicOr(A.status, STATUS_ITER_LIMIT); cur = DESC_DONE; }
         }
