@@ -209,7 +209,7 @@ int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
 
 /* Trace n rays (6 floats each: origin, direction) read from HBM, write n hit records.
  * tmax: optional per-ray upper bound (NULL = 1e30). */
-int vxrt_trace(const vxrt_accel_t* accel, const float* rays, uint64_t n, const float* tmax,
+int vxrt_trace(vxrt_accel_t* accel, const float* rays, uint64_t n, const float* tmax,
                vxrt_hit_t* hits, int mode, void* stream);
 
 /* Status word of the last launches on this device: 0 = ok, bit0 = traversal stack overflow

@@ -153,8 +153,8 @@ __device__ __forceinline__ float qbyte(const uint32_t* qb, int byte_off) {   // 
 // an 8-bit q whenever 2^e is representable, so fma(float(q), 2^e, origin) rounds the same exact sum
 // once and yields the identical float with one instruction less per coordinate; the accel build
 // verifies this per scene and sets exact_decode otherwise.
-template <bool EXACT>
-__device__ __forceinline__ void eval_children(const uint4* __restrict__ np, bool is_tlas, bool ldexp_decode,
+template <bool EXACT, bool LDEXP>
+__device__ __forceinline__ void eval_children(const uint4* __restrict__ np, bool is_tlas,
                                               float rox, float roy, float roz, float rix, float riy, float riz,
                                               float hit_dist, Cand* c) {
   const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
@@ -169,7 +169,7 @@ __device__ __forceinline__ void eval_children(const uint4* __restrict__ np, bool
   for (int k = 0; k < 4; ++k) {
     const int b = 6 * k;
     float mnx, mny, mnz, mxx, mxy, mxz;
-    if (ldexp_decode) {
+    if (LDEXP) {
       mnx = px + ldexpf(qbyte(qb, b + 0), ex); mny = py + ldexpf(qbyte(qb, b + 1), ey); mnz = pz + ldexpf(qbyte(qb, b + 2), ez);
       mxx = px + ldexpf(qbyte(qb, b + 3), ex); mxy = py + ldexpf(qbyte(qb, b + 4), ey); mxz = pz + ldexpf(qbyte(qb, b + 5), ez);
     } else {
@@ -182,6 +182,11 @@ __device__ __forceinline__ void eval_children(const uint4* __restrict__ np, bool
     c[k].d = ok ? d : __builtin_inff();
     c[k].desc = ck == 1u ? DESC(node_kind, leftFirst + (uint32_t)k) : DESC(ck, pay[k]);   // ck 2 -> leaf, 3 -> instance
     c[k].idx = (uint32_t)k;
+#if RT_SERIAL_CHILDREN
+    // keep the four box tests from being interleaved: their ~12 temporaries each would otherwise be
+    // live together and cost a wave of occupancy (other waves, not ILP, hide the latency here)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 
@@ -285,11 +290,12 @@ __device__ __forceinline__ uint32_t pack_rgb8(float r, float g, float b) {  // c
   return (uint32_t)((ir << 16) + (ig << 8) + ib);
 }
 
-// kernel.cpp:28-39 -- u and v are evaluated in double, then rounded to f32
-__device__ __forceinline__ void generate_ray(uint32_t x, uint32_t y, uint32_t W, uint32_t H,
+// kernel.cpp:28-39.  u = (x*2.0 - W)/H and v = (y*2.0 - H)/H are evaluated in double and rounded to
+// f32 there; they depend on x (resp. y) only, so the host evaluates exactly that expression once per
+// column / row (IEEE double division is correctly rounded on both sides) and the kernels read the
+// two small tables instead of running an f64 divide per ray.
+__device__ __forceinline__ void generate_ray(float u, float v,
                                              float& ox, float& oy, float& oz, float& dx, float& dy, float& dz) {
-  const float u = (float)(((double)x * 2.0 - (double)W) / (double)H);
-  const float v = (float)(((double)y * 2.0 - (double)H) / (double)H);
   // front=(1,0,0); right=cross(front,(0,1,0))=(0,0,1); up=cross(right,front)=(0,1,0)
   const float rx = 0.0f * 0.0f - 0.0f * 1.0f, ry = 0.0f * 0.0f - 1.0f * 0.0f, rz = 1.0f * 1.0f - 0.0f * 0.0f;
   const float ux = ry * 0.0f - rz * 0.0f, uy = rz * 1.0f - rx * 0.0f, uz = rx * 0.0f - ry * 1.0f;
@@ -303,7 +309,10 @@ __device__ __forceinline__ void generate_ray(uint32_t x, uint32_t y, uint32_t W,
 }
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 4
+#define RT_WAVES_PER_EU 6
+#endif
+#ifndef RT_SERIAL_CHILDREN
+#define RT_SERIAL_CHILDREN 1
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -319,17 +328,11 @@ __device__ __forceinline__ void generate_ray(uint32_t x, uint32_t y, uint32_t W,
 // Rendering is deferred: this kernel leaves 24-byte hit records, rt_shade_kernel makes pixels.
 // Per-ray semantics -- and therefore results -- do not depend on the schedule.
 // ---------------------------------------------------------------------------------------------
-#ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 64    // render jobs: fetch once this many lanes are idle (64 = whole tiles)
-#endif
-#ifndef RT_FINISH_MIN
-#define RT_FINISH_MIN 64    // render jobs: leave the traversal loop once this many lanes have finished
-#endif
-#ifndef RT_TRACE_REFILL_MIN
-#define RT_TRACE_REFILL_MIN 16   // ray-buffer jobs (incoherent): refill early, measured +7 %
-#endif
-#ifndef RT_TRACE_FINISH_MIN
-#define RT_TRACE_FINISH_MIN 16
+#ifndef RT_DEAD_MAX
+#define RT_DEAD_MAX 64      // render jobs: leave the traversal loop (finish rays, fetch jobs) once this many lanes
+#endif                      // are not traversing (finished or idle); 64 = whole-tile batches
+#ifndef RT_TRACE_DEAD_MAX
+#define RT_TRACE_DEAD_MAX 16   // ray-buffer jobs (incoherent rays): refill early
 #endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 64         // jobs reserved per global atomic (one 8x8 tile)
@@ -339,7 +342,7 @@ __device__ __forceinline__ void generate_ray(uint32_t x, uint32_t y, uint32_t W,
 #endif
 #define QUEUE_STRIDE 32u    // one 128-byte line per shard counter
 #ifndef LDS_STACK
-#define LDS_STACK 16        // stack levels kept in LDS per lane (8 KiB per wavefront)
+#define LDS_STACK 8         // stack levels kept in LDS per lane (4 KiB per wavefront); deeper ones go to scratch
 #endif
 
 enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2 };
@@ -353,6 +356,11 @@ struct PersistArgs {
   uint32_t* status;
   uint32_t* queue;                // QUEUE_SHARDS counters (QUEUE_STRIDE dwords apart), zeroed by the host before the launch
   uint32_t per_shard;             // jobs per shard (multiple of 64)
+  const float* utab; const float* vtab;   // camera u per column, v per row (see generate_ray)
+  // rays whose slab products can be NaN (a zero / non-finite direction component) are not traced by
+  // the main launch: their job id (bit 31 = occlusion phase) is appended here and a second, small
+  // launch of the EXACT variant (libstdc++ min/max forms) traces them
+  uint32_t* defer_count; uint32_t* defer_list; uint32_t defer_cap;
 };
 
 __device__ __forceinline__ bool is_node_desc(uint32_t d) { return d < 0x80000000u; }
@@ -360,50 +368,124 @@ __device__ __forceinline__ bool is_leaf_desc(uint32_t d) { return (d >> 30) == D
 __device__ __forceinline__ bool is_inst_desc(uint32_t d) { return d >= 0xC0000000u && d < DESC_IDLE; }
 __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE; }
 
-template <int JOB, bool STATS>
-__global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
-  constexpr uint32_t REFILL_MIN = JOB == JOB_TRACE ? RT_TRACE_REFILL_MIN : RT_REFILL_MIN;
-  constexpr uint32_t FINISH_MIN = JOB == JOB_TRACE ? RT_TRACE_FINISH_MIN : RT_FINISH_MIN;
-  const uint32_t lane = threadIdx.x & 63u;
+// per-lane flag bits
+#define F_FOUND 1u
+#define F_ANYHIT 2u
+#define F_SHADOW 8u      // render job is in its occlusion-ray phase
+#define F_WORLD 16u      // the active ray registers hold the world-space ray (TLAS level)
 
-  // ---- per-lane ray state ----
-  float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, wix = 0, wiy = 0, wiz = 0;          // world ray
-  float cox = 0, coy = 0, coz = 0, cdx = 0, cdy = 0, cdz = 0, cix = 0, ciy = 0, ciz = 0;    // object-space ray
-  float hitd = 0, hbx = 0, hby = 0, hbz = 0, path_m = 0;
-  uint32_t hblas = 0, htri = 0, blasIdx = 0, cur = DESC_IDLE, job = 0, iters = 0;
-  bool found = false, anyhit = false, lane_fast = true, shadow_phase = false;
-  // Traversal stack: the newest pending entry lives in registers (tos_*), the next LDS_STACK in LDS
-  // (one 64-lane row of 8-byte entries per level: conflict-free ds_write_b64/ds_read_b64), deeper ones
-  // in scratch.  A pop therefore never waits on memory: it takes the register copy and the refill
-  // from LDS overlaps the next node's box tests.  The scenes of SURVEY.md s8d never go deeper than 14.
-  __shared__ uint2 s_stk[4][LDS_STACK][64];
+// Register budget is the lever here (profiles/r01_c_*: at 4 waves/SIMD the VALU pipe idles 58 % of
+// the time waiting on dependent loads), so a lane keeps in VGPRs only what every step touches: the
+// ACTIVE ray (origin + reciprocal direction; world space at TLAS level, object space inside an
+// instance), hit distance, path_m, the current work item and the register-cached stack top.  The ray
+// direction (triangle tests only), barycentrics / indices of the best hit and blasIdx live in LDS
+// next to the stack; the world ray is not stored at all - it is re-derived from the job (ray buffer,
+// camera tables, or the pixel's primary hit record) on the rare TLAS-level steps.
+template <int JOB, bool STATS, bool LDEXP, bool EXACT>
+__global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+  constexpr uint32_t DEAD_MAX = JOB == JOB_TRACE ? RT_TRACE_DEAD_MAX : RT_DEAD_MAX;
+  const uint32_t lane = threadIdx.x & 63u;
+  // EXACT launch: the jobs are the entries of the deferral list the main launch left behind
+  const uint32_t n_jobs = EXACT ? min(*A.defer_count, A.defer_cap) : A.total;
+  const uint32_t per_shard = EXACT ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
+
+  __shared__ uint2 s_stk[4][LDS_STACK][64];   // stack levels below the register top, 8 B entries, conflict-free rows
+  __shared__ uint32_t s_ctx[4][9][64];        // 0-2 active dir, 3-5 hit bx/by/bz, 6 hit blasIdx, 7 hit triIdx, 8 blasIdx
   uint2* const lstk = &s_stk[threadIdx.x >> 6][0][lane];
+  uint32_t* const ctx = &s_ctx[threadIdx.x >> 6][0][lane];
+#define CTX(i) ctx[(i) * 64]
+
+  // ---- per-lane ray state in registers ----
+  float arx = 0, ary = 0, arz = 0, aix = 0, aiy = 0, aiz = 0;   // active ray: origin, 1/direction
+  float hitd = 0, path_m = 0, tos_m = 0;
+  uint32_t cur = DESC_IDLE, tos_d = DESC_DONE, job = 0, flags = 0;
+  int sp = 0;                     // entries below the register top (LDS, then scratch)
   uint32_t ovf_d[RT_STACK_ENTRIES];
   float ovf_m[RT_STACK_ENTRIES];
-  uint32_t tos_d = DESC_DONE;   // DESC_DONE = no pending entry
-  float tos_m = 0;
-  int sp = 0;                   // entries below the register top (in LDS / scratch)
   // wave-uniform job-queue state
   bool queue_empty = false;
   uint32_t shard = blockIdx.x % QUEUE_SHARDS;   // blocks b and b+8 share an XCD (observed dispatch order; speed only)
   uint32_t tries = 0, loc_next = 0, loc_end = 0;
-  const bool ldexp_decode = sc.exact_decode != 0u;
   Fetches fx;
   unsigned nrays = 0, nhit = 0;
 
-  // (re)start the lane's traversal at the TLAS root with the world ray in (ox..dz)
-  auto start_ray = [&](float tmax_, bool any_) {
-    wix = 1.0f / dx; wiy = 1.0f / dy; wiz = 1.0f / dz;
-    cox = ox; coy = oy; coz = oz; cdx = dx; cdy = dy; cdz = dz; cix = wix; ciy = wiy; ciz = wiz;
-    // a lane may use v_min/v_max only if no slab product can be NaN
-    lane_fast = (wix - wix == 0.0f) && (wiy - wiy == 0.0f) && (wiz - wiz == 0.0f) &&
-                (ox - ox == 0.0f) && (oy - oy == 0.0f) && (oz - oz == 0.0f);
-    hitd = tmax_; hbx = 0; hby = 0; hbz = 0; hblas = 0; htri = 0; found = false; anyhit = any_;
-    blasIdx = 0; cur = sc.tlas_root; path_m = -__builtin_inff(); sp = 0; tos_d = DESC_DONE; iters = 0;   // rt_traversal.cpp:39-40
-    nrays++;
+  auto pixel_of = [&](uint32_t r, uint32_t& x, uint32_t& y) {
+    const uint32_t tile = r >> 6, l = r & 63u;
+    x = (tile % A.tiles_x) * 8u + (l & 7u);
+    y = A.y0 + (tile / A.tiles_x) * 8u + (l >> 3);
   };
-  // next pending work item of this lane (m < hit.dist: the reference's re-filtering, DESIGN.md s3),
-  // or DESC_DONE when its stack is exhausted
+  // the lane's world-space ray, re-derived from its job (deterministic: same bits every time)
+  auto world_ray = [&](float& ox, float& oy, float& oz, float& dx, float& dy, float& dz, float& tmax_) {
+    tmax_ = RT_LARGE_FLOAT;
+    if (JOB == JOB_TRACE) {
+      const float* rp = A.rays + (size_t)job * 6;
+      ox = rp[0]; oy = rp[1]; oz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5];
+      if (A.tmax) tmax_ = A.tmax[job];
+    } else {
+      uint32_t x, y;
+      pixel_of(job, x, y);
+      generate_ray(A.utab[x], A.vtab[y], ox, oy, oz, dx, dy, dz);
+      if (JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW)) {
+        const float pd = A.hits[(size_t)x + (size_t)y * A.W].dist;   // primary hit of this pixel, written before the occlusion ray started
+        float sox, soy, soz, sdx, sdy, sdz, sdist;
+        shadow_ray(p, ox, oy, oz, dx, dy, dz, pd, sox, soy, soz, sdx, sdy, sdz, sdist);
+        ox = sox; oy = soy; oz = soz; dx = sdx; dy = sdy; dz = sdz;
+        tmax_ = sdist;
+      }
+    }
+  };
+  // main launch only: hand this lane's ray (in its current phase) over to the EXACT launch
+  auto defer = [&]() {
+    const uint32_t slot = atomicAdd(A.defer_count, 1u);
+    if (slot < A.defer_cap) A.defer_list[slot] = job | ((flags & F_SHADOW) ? 0x80000000u : 0u);
+    cur = DESC_IDLE;
+  };
+  // TLAS leaf (rt_traversal.cpp:109-121): fetch the instance record, move the ray to object space
+  auto enter_instance = [&](uint32_t blasIdx, float ox, float oy, float oz, float dx, float dy, float dz) {
+    const uint32_t* bp = sc.blas + (size_t)blasIdx * (RT_BLAS_STRIDE / 4);
+    uint32_t bw[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) bw[i] = bp[i];
+    if (STATS) { fx.node++; fx.inst++; }
+    const float m00 = __uint_as_float(bw[1]), m01 = __uint_as_float(bw[2]), m02 = __uint_as_float(bw[3]), m03 = __uint_as_float(bw[4]);
+    const float m10 = __uint_as_float(bw[5]), m11 = __uint_as_float(bw[6]), m12 = __uint_as_float(bw[7]), m13 = __uint_as_float(bw[8]);
+    const float m20 = __uint_as_float(bw[9]), m21 = __uint_as_float(bw[10]), m22 = __uint_as_float(bw[11]), m23 = __uint_as_float(bw[12]);
+    arx = m00 * ox + m01 * oy + m02 * oz + m03;   // :231-261
+    ary = m10 * ox + m11 * oy + m12 * oz + m13;
+    arz = m20 * ox + m21 * oy + m22 * oz + m23;
+    const float cdx = m00 * dx + m01 * dy + m02 * dz;
+    const float cdy = m10 * dx + m11 * dy + m12 * dz;
+    const float cdz = m20 * dx + m21 * dy + m22 * dz;
+    aix = 1.0f / cdx; aiy = 1.0f / cdy; aiz = 1.0f / cdz;
+    const bool s2 = (aix - aix == 0.0f) && (aiy - aiy == 0.0f) && (aiz - aiz == 0.0f) &&
+                    (arx - arx == 0.0f) && (ary - ary == 0.0f) && (arz - arz == 0.0f);
+    if (!EXACT && !s2) { defer(); return; }   // object-space ray can produce NaN slabs: restart it in the EXACT launch
+    flags &= ~F_WORLD;
+    CTX(0) = __float_as_uint(cdx); CTX(1) = __float_as_uint(cdy); CTX(2) = __float_as_uint(cdz);
+    CTX(8) = blasIdx;
+    cur = sc.blas_root[blasIdx];   // BLAS root: same level, path_m unchanged
+  };
+  // (re)start the lane's traversal at the TLAS root (rt_traversal.cpp:39-40) with world ray (o, d)
+  auto start_ray = [&](float ox, float oy, float oz, float dx, float dy, float dz, float tmax_, bool any_) {
+    arx = ox; ary = oy; arz = oz;
+    aix = 1.0f / dx; aiy = 1.0f / dy; aiz = 1.0f / dz;
+    // v_min/v_max slabs are exact only if no slab product can be NaN
+    const bool safe = (aix - aix == 0.0f) && (aiy - aiy == 0.0f) && (aiz - aiz == 0.0f) &&
+                      (ox - ox == 0.0f) && (oy - oy == 0.0f) && (oz - oz == 0.0f);
+    flags = (flags & F_SHADOW) | F_WORLD | (any_ ? F_ANYHIT : 0u);
+    if (!EXACT && !safe) {
+      // camera rays with a zero direction component are known before the launch (u == 0 or v == 0): the
+      // host lists them and a concurrent EXACT launch traces them; everything else is deferred
+      if (JOB != JOB_TRACE && !(flags & F_SHADOW)) cur = DESC_IDLE; else defer();
+      return;
+    }
+    hitd = tmax_; path_m = -__builtin_inff(); sp = 0; tos_d = DESC_DONE;
+    cur = sc.tlas_root;
+    nrays++;
+    // single-instance scenes (the reference's default): the TLAS root is the instance leaf, enter it
+    // right away with the ray at hand instead of re-deriving it in the instance step
+    if (is_inst_desc(sc.tlas_root)) enter_instance(sc.tlas_root & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz);
+  };
   auto push = [&](uint32_t d, float m) {
     if (tos_d != DESC_DONE) {
       if (sp < LDS_STACK) lstk[sp * 64] = make_uint2(tos_d, __float_as_uint(tos_m));
@@ -412,6 +494,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
     }
     tos_d = d; tos_m = m;
   };
+  // next pending work item of this lane (m < hit.dist: the reference's re-filtering, DESIGN.md s3),
+  // or DESC_DONE when its stack is exhausted.  The refill of the register top from LDS is not waited for.
   auto pop_next = [&]() {
     cur = DESC_DONE;
     while (tos_d != DESC_DONE) {
@@ -434,11 +518,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
     // RT_CHUNK jobs); lanes then draw from the wavefront's private range.
     {
       const unsigned long long idle = __ballot(cur == DESC_IDLE);
-      if (!queue_empty && idle != 0ull && (idle == ~0ull || (uint32_t)__popcll(idle) >= REFILL_MIN)) {
+      if (!queue_empty && idle != 0ull) {
         if (loc_next == loc_end) {   // wave-uniform: reserve the next chunk, stealing from other shards when the home shard is dry
           while (tries < QUEUE_SHARDS) {
-            const uint32_t s_lo = shard * A.per_shard;
-            const uint32_t s_n = s_lo < A.total ? min(A.per_shard, A.total - s_lo) : 0u;
+            const uint32_t s_lo = shard * per_shard;
+            const uint32_t s_n = s_lo < n_jobs ? min(per_shard, n_jobs - s_lo) : 0u;
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(A.queue + shard * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
             base = __shfl(base, 0);
@@ -452,19 +536,19 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
         if (avail != 0u && cur == DESC_IDLE) {
           const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
           if (rank < avail) {
-            const uint32_t r = loc_next + rank;
-            job = r;
-            shadow_phase = false;
+            job = loc_next + rank;
+            flags = 0;
+            if (EXACT) { const uint32_t wd = A.defer_list[job]; job = wd & 0x7fffffffu; if (wd >> 31) flags = F_SHADOW; }
+            float ox, oy, oz, dx, dy, dz, tm;
             if (JOB == JOB_TRACE) {
-              const float* rp = A.rays + (size_t)r * 6;
-              ox = rp[0]; oy = rp[1]; oz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5];
-              start_ray(A.tmax ? A.tmax[r] : RT_LARGE_FLOAT, A.any_hit != 0);
+              world_ray(ox, oy, oz, dx, dy, dz, tm);
+              start_ray(ox, oy, oz, dx, dy, dz, tm, A.any_hit != 0);
             } else {
-              const uint32_t tile = r >> 6, l = r & 63u;
-              const uint32_t x = (tile % A.tiles_x) * 8u + (l & 7u), y = A.y0 + (tile / A.tiles_x) * 8u + (l >> 3);
+              uint32_t x, y;
+              pixel_of(job, x, y);
               if (x < A.W && y < A.y1) {   // kernel.cpp:62,101
-                generate_ray(x, y, A.W, A.H, ox, oy, oz, dx, dy, dz);
-                start_ray(RT_LARGE_FLOAT, false);
+                world_ray(ox, oy, oz, dx, dy, dz, tm);
+                start_ray(ox, oy, oz, dx, dy, dz, tm, (flags & F_SHADOW) != 0u);
               }
             }
           }
@@ -482,14 +566,16 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
       if (is_node_desc(cur)) {
         // ---- internal node: 4 box tests, order, push the far ones, continue with the nearest ----
         const bool top = (cur >> 30) == DK_TLAS;
+        if (top && !(flags & F_WORLD)) {   // back at TLAS level after an instance (multi-instance scenes only)
+          float ox, oy, oz, dx, dy, dz, tm;
+          world_ray(ox, oy, oz, dx, dy, dz, tm);
+          arx = ox; ary = oy; arz = oz; aix = 1.0f / dx; aiy = 1.0f / dy; aiz = 1.0f / dz;
+          flags |= F_WORLD;
+        }
         const uint4* np = (top ? sc.tlas_c : sc.bvh_c) + (size_t)(cur & PAYLOAD_MASK) * CNODE_VEC4;
         if (STATS) fx.node++;
-        const float rox = top ? ox : cox, roy = top ? oy : coy, roz = top ? oz : coz;
-        const float rix = top ? wix : cix, riy = top ? wiy : ciy, riz = top ? wiz : ciz;
         Cand c[4];
-        // wave-uniform choice: v_min/v_max slabs unless some active lane could see a NaN product
-        if (__all(lane_fast)) eval_children<false>(np, top, ldexp_decode, rox, roy, roz, rix, riy, riz, hitd, c);
-        else                  eval_children<true>(np, top, ldexp_decode, rox, roy, roz, rix, riy, riz, hitd, c);
+        eval_children<EXACT, LDEXP>(np, top, arx, ary, arz, aix, aiy, aiz, hitd, c);
         int n = (c[0].d < __builtin_inff()) + (c[1].d < __builtin_inff()) + (c[2].d < __builtin_inff()) + (c[3].d < __builtin_inff());
         cmpx(c[0], c[1]); cmpx(c[2], c[3]); cmpx(c[0], c[2]); cmpx(c[1], c[3]); cmpx(c[1], c[2]);
         if (n > 0) {
@@ -503,31 +589,12 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
         } else {
           pop_next();
         }
-        if (++iters > ITER_LIMIT) { atomicOr(A.status, STATUS_ITER_LIMIT); cur = DESC_DONE; }
       }
       if (__any(is_inst_desc(cur))) {
-        // ---- TLAS leaf (:109-121): fetch the instance record, move the ray to object space ----
         if (is_inst_desc(cur)) {
-          blasIdx = cur & PAYLOAD_MASK;
-          const uint32_t* bp = sc.blas + (size_t)blasIdx * (RT_BLAS_STRIDE / 4);
-          uint32_t bw[13];
-#pragma unroll
-          for (int i = 0; i < 13; ++i) bw[i] = bp[i];
-          if (STATS) { fx.node++; fx.inst++; }
-          const float m00 = __uint_as_float(bw[1]), m01 = __uint_as_float(bw[2]), m02 = __uint_as_float(bw[3]), m03 = __uint_as_float(bw[4]);
-          const float m10 = __uint_as_float(bw[5]), m11 = __uint_as_float(bw[6]), m12 = __uint_as_float(bw[7]), m13 = __uint_as_float(bw[8]);
-          const float m20 = __uint_as_float(bw[9]), m21 = __uint_as_float(bw[10]), m22 = __uint_as_float(bw[11]), m23 = __uint_as_float(bw[12]);
-          cox = m00 * ox + m01 * oy + m02 * oz + m03;   // :231-261
-          coy = m10 * ox + m11 * oy + m12 * oz + m13;
-          coz = m20 * ox + m21 * oy + m22 * oz + m23;
-          cdx = m00 * dx + m01 * dy + m02 * dz;
-          cdy = m10 * dx + m11 * dy + m12 * dz;
-          cdz = m20 * dx + m21 * dy + m22 * dz;
-          cix = 1.0f / cdx; ciy = 1.0f / cdy; ciz = 1.0f / cdz;
-          const bool s2 = (cix - cix == 0.0f) && (ciy - ciy == 0.0f) && (ciz - ciz == 0.0f) &&
-                          (cox - cox == 0.0f) && (coy - coy == 0.0f) && (coz - coz == 0.0f);
-          lane_fast = lane_fast && s2;
-          cur = sc.blas_root[blasIdx];   // BLAS root: same level, path_m unchanged
+          float ox, oy, oz, dx, dy, dz, tm;
+          world_ray(ox, oy, oz, dx, dy, dz, tm);
+          enter_instance(cur & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz);
         }
       }
       if (__any(is_leaf_desc(cur))) {
@@ -539,6 +606,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
             const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS;
             leftFirst = rn[4]; triCount = rn[5];
           }
+          const float cdx = __uint_as_float(CTX(0)), cdy = __uint_as_float(CTX(1)), cdz = __uint_as_float(CTX(2));
           bool stop = false;
           for (uint32_t i = 0; i < triCount; ++i) {
             const uint32_t triIdx = leftFirst + i;
@@ -546,11 +614,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
             const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
             if (STATS) fx.tri++;
             float bx, by, bz;
-            const float d = ray_tri(cox, coy, coz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
+            const float d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
             if (d < hitd) {
-              hitd = d; hbx = bx; hby = by; hbz = bz; hblas = blasIdx; htri = triIdx;
-              found = true;
-              if (anyhit) { stop = true; break; }
+              hitd = d;
+              CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(5) = __float_as_uint(bz);
+              CTX(6) = CTX(8); CTX(7) = triIdx;
+              flags |= F_FOUND;
+              if (flags & F_ANYHIT) { stop = true; break; }
               // the reference re-descends from the root with the shrunken hit.dist; if any box on the
               // current path no longer passes `d < hit.dist` it abandons this subtree
               if (!(path_m < hitd)) break;
@@ -558,37 +628,43 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
           }
           if (stop) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
           else pop_next();
-          if (++iters > ITER_LIMIT) { atomicOr(A.status, STATUS_ITER_LIMIT); cur = DESC_DONE; }
         }
       }
+      // leave when nothing traverses any more, or when enough lanes are dead weight AND leaving can
+      // revive them (finished rays to retire, or idle lanes while jobs remain)
       const unsigned long long work = __ballot(is_work_desc(cur));
+      if (work == 0ull) break;
       const unsigned long long done = __ballot(cur == DESC_DONE);
-      if (work == 0ull || (uint32_t)__popcll(done) >= FINISH_MIN) break;
+      const uint32_t revivable = (uint32_t)__popcll(done) + (queue_empty && loc_next == loc_end ? 0u : 64u - (uint32_t)__popcll(work | done));
+      if (revivable >= DEAD_MAX) break;
     }
 
     // ================= finish: rays whose traversal ended =================
     if (cur == DESC_DONE) {
-      if (!found) hitd = RT_LARGE_FLOAT;
-      HitRec h; h.dist = hitd; h.bx = hbx; h.by = hby; h.bz = hbz; h.blasIdx = hblas; h.triIdx = htri;
-      if (!found) { h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0; }
+      const bool found = (flags & F_FOUND) != 0u;
+      HitRec h; h.dist = RT_LARGE_FLOAT; h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0;
+      if (found) {
+        h.dist = hitd; h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = __uint_as_float(CTX(5));
+        h.blasIdx = CTX(6); h.triIdx = CTX(7);
+      }
       if (JOB == JOB_TRACE) {
         A.hits[job] = h;
         cur = DESC_IDLE;
       } else {
         // deferred shading: finishing a ray costs one store, not a chain of dependent loads
-        const uint32_t tile = job >> 6, l = job & 63u;
-        const uint32_t x = (tile % A.tiles_x) * 8u + (l & 7u), y = A.y0 + (tile / A.tiles_x) * 8u + (l >> 3);
+        uint32_t x, y;
+        pixel_of(job, x, y);
         const size_t idx = (size_t)x + (size_t)y * A.W;
-        if (!shadow_phase) {
+        if (!(flags & F_SHADOW)) {
           A.hits[idx] = h;
           if (STATS && found) nhit++;
           if (JOB == JOB_RENDER_SHADOW && found) {
             // continue this lane with the pixel's occlusion ray
-            float sox, soy, soz, sdx, sdy, sdz, sdist;
+            float ox, oy, oz, dx, dy, dz, sox, soy, soz, sdx, sdy, sdz, sdist;
+            generate_ray(A.utab[x], A.vtab[y], ox, oy, oz, dx, dy, dz);
             shadow_ray(p, ox, oy, oz, dx, dy, dz, hitd, sox, soy, soz, sdx, sdy, sdz, sdist);
-            ox = sox; oy = soy; oz = soz; dx = sdx; dy = sdy; dz = sdz;
-            shadow_phase = true;
-            start_ray(sdist, true);
+            flags = F_SHADOW;
+            start_ray(sox, soy, soz, sdx, sdy, sdz, sdist, true);
           } else {
             cur = DESC_IDLE;
           }
@@ -599,6 +675,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
       }
     }
   }
+#undef CTX
 
   if (A.counters) {
     unsigned v[5] = {nrays, fx.node, fx.inst, fx.tri, nhit};
@@ -615,6 +692,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_EU) void rt_persistent_kernel(Sce
 // and pixels written fully coalesced.
 template <bool STATS>
 __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams p, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+                                                      const float* __restrict__ utab, const float* __restrict__ vtab,
                                                       const HitRec* __restrict__ hb, uint32_t* __restrict__ dst,
                                                       HitRec* __restrict__ hits, float* __restrict__ colors,
                                                       unsigned long long* counters) {
@@ -629,7 +707,7 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
     h.blasIdx &= 0x7fffffffu;
     const bool found = h.dist != RT_LARGE_FLOAT;
     float ox, oy, oz, dx, dy, dz;
-    generate_ray(x, y, W, H, ox, oy, oz, dx, dy, dz);
+    generate_ray(utab[x], vtab[y], ox, oy, oz, dx, dy, dz);
     float r, g, b;
     shade_eval<STATS>(sc, p, ox, oy, oz, dx, dy, dz, h, found, occ, r, g, b, &ntex);
     dst[idx] = pack_rgb8(r, g, b);
@@ -782,6 +860,7 @@ static uint32_t* status_word() {
 // job-queue counters of the persistent kernels: a ring so that launches in flight on different
 // streams never share a counter (a slot is reused after 64 launches)
 #define QUEUE_RING 64
+#define EXACT_GRID 128   // workgroups of the EXACT launch (it sees a fraction of a percent of the rays)
 static uint32_t* g_queue[16] = {nullptr};
 static unsigned g_queue_next[16] = {0};
 
@@ -815,13 +894,27 @@ struct vxrt_accel {
   void* tlas_c = nullptr; void* bvh_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr;
   void* hitbuf = nullptr;      // W*H hit records between the traversal and the shading pass
   uint64_t hitbuf_pixels = 0;
+  float* uvtab = nullptr;      // camera tables: u[W] then v[H]
+  uint32_t uv_w = 0, uv_h = 0;
+  uint32_t* defer = nullptr;   // [0] count, [1..] job list of the EXACT launch
+  uint64_t defer_cap = 0;
+  // camera pixels whose primary ray has a zero direction component (u == 0 or v == 0): listed on the
+  // host per (W, H, y0, y1) and traced by an EXACT launch on a side stream, concurrently with the main one
+  uint32_t* apriori = nullptr; // [0] count, [1..] job ids
+  uint32_t ap_count = 0, ap_key[4] = {0, 0, 0, 0};
+  uint64_t ap_cap = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_in = nullptr, ev_side = nullptr;
   int device = 0;
 };
 
 static void accel_free(vxrt_accel* a) {
   if (!a) return;
   (void)hipFree(a->tlas_c); (void)hipFree(a->bvh_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
-  (void)hipFree(a->hitbuf);
+  (void)hipFree(a->hitbuf); (void)hipFree(a->uvtab); (void)hipFree(a->defer); (void)hipFree(a->apriori);
+  if (a->side) { (void)hipStreamSynchronize(a->side); (void)hipStreamDestroy(a->side); }
+  if (a->ev_in) (void)hipEventDestroy(a->ev_in);
+  if (a->ev_side) (void)hipEventDestroy(a->ev_side);
   delete a;
 }
 
@@ -905,6 +998,16 @@ uint64_t vxrt_accel_bytes(const vxrt_accel_t* a) {
          (uint64_t)a->ref.n_tris * WTRI_FLOATS * 4 + (uint64_t)a->ref.n_blas * 4;
 }
 
+static int ensure_defer(vxrt_accel_t* a, uint64_t jobs, hipStream_t s) {
+  if (a->defer_cap >= jobs) return 0;
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  (void)hipFree(a->defer);
+  a->defer = nullptr; a->defer_cap = 0;
+  if (hipMalloc((void**)&a->defer, (jobs + 1) * sizeof(uint32_t)) != hipSuccess) return -1;
+  a->defer_cap = jobs;
+  return 0;
+}
+
 static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits, float* colors,
                          unsigned long long* counters, bool stats, void* stream) {
@@ -937,20 +1040,86 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     if (hipMalloc(&a->hitbuf, pixels * sizeof(HitRec)) != hipSuccess) return -1;
     a->hitbuf_pixels = pixels;
   }
+  if (a->uv_w != width || a->uv_h != height) {
+    // kernel.cpp:32-33 evaluated on the host in double, once per column and row
+    std::vector<float> tab((size_t)width + height);
+    for (uint32_t x = 0; x < width; ++x) tab[x] = (float)(((double)x * 2.0 - (double)width) / (double)height);
+    for (uint32_t y = 0; y < height; ++y) tab[width + y] = (float)(((double)y * 2.0 - (double)height) / (double)height);
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    (void)hipFree(a->uvtab);
+    a->uvtab = nullptr; a->uv_w = a->uv_h = 0;
+    if (hipMalloc((void**)&a->uvtab, tab.size() * sizeof(float)) != hipSuccess) return -1;
+    if (hipMemcpy(a->uvtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    a->uv_w = width; a->uv_h = height;
+  }
   PersistArgs A{};
   A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.total = n_tiles * 64u;
   A.hits = (HitRec*)a->hitbuf; A.counters = counters; A.status = st;
+  A.utab = a->uvtab; A.vtab = a->uvtab + width;
+  if (ensure_defer(a, A.total, s) != 0) return -1;
+  A.defer_count = a->defer; A.defer_list = a->defer + 1; A.defer_cap = A.total;
+  if (hipMemsetAsync(a->defer, 0, sizeof(uint32_t), s) != hipSuccess) return -1;
   A.queue = queue_slot(s);
   if (!A.queue) return -1;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
-#define LAUNCH_P(J, ST) hipLaunchKernelGGL((rt_persistent_kernel<J, ST>), dim3(persistent_grid(rt_persistent_kernel<J, ST>, A.total)), block, 0, s, sc, p, A)
-  if (stats) { if (shadow) LAUNCH_P(JOB_RENDER_SHADOW, true); else LAUNCH_P(JOB_RENDER, true); }
-  else       { if (shadow) LAUNCH_P(JOB_RENDER_SHADOW, false); else LAUNCH_P(JOB_RENDER, false); }
+  // a-priori EXACT list (camera rays with u == 0 or v == 0), rebuilt only when the window changes
+  if (!a->side) {
+    if (hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess) return -1;
+    if (hipEventCreateWithFlags(&a->ev_in, hipEventDisableTiming) != hipSuccess) return -1;
+    if (hipEventCreateWithFlags(&a->ev_side, hipEventDisableTiming) != hipSuccess) return -1;
+  }
+  if (a->ap_key[0] != width || a->ap_key[1] != height || a->ap_key[2] != y0 || a->ap_key[3] != y1 || !a->apriori) {
+    std::vector<uint32_t> list(1, 0u);
+    for (uint32_t t = 0; t < n_tiles; ++t)
+      for (uint32_t l = 0; l < 64; ++l) {
+        const uint32_t x = (t % tiles_x) * 8u + (l & 7u), y = y0 + (t / tiles_x) * 8u + (l >> 3);
+        if (x >= width || y >= y1) continue;
+        const float u = (float)(((double)x * 2.0 - (double)width) / (double)height);
+        const float v = (float)(((double)y * 2.0 - (double)height) / (double)height);
+        if (u == 0.0f || v == 0.0f) list.push_back(t * 64u + l);
+      }
+    list[0] = (uint32_t)(list.size() - 1);
+    if (hipStreamSynchronize(s) != hipSuccess || hipStreamSynchronize(a->side) != hipSuccess) return -1;
+    if (a->ap_cap < list.size()) {
+      (void)hipFree(a->apriori);
+      a->apriori = nullptr; a->ap_cap = 0;
+      if (hipMalloc((void**)&a->apriori, list.size() * sizeof(uint32_t)) != hipSuccess) return -1;
+      a->ap_cap = list.size();
+    }
+    if (hipMemcpy(a->apriori, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    a->ap_count = list[0];
+    a->ap_key[0] = width; a->ap_key[1] = height; a->ap_key[2] = y0; a->ap_key[3] = y1;
+  }
+  // EXACT launch over the a-priori list on the side stream (ordered after everything already queued on
+  // `s`: it writes hit records the previous frame's shading pass may still be reading), concurrent with
+  // the main launch; then the main launch and the EXACT launch over whatever the main one deferred
+  PersistArgs X = A, X0 = A;
+  X.queue = queue_slot(s);
+  if (!X.queue) return -1;
+  const bool side_launch = a->ap_count != 0;
+  hipStream_t side = a->side;
+  if (side_launch) {
+    if (hipEventRecord(a->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, a->ev_in, 0) != hipSuccess) return -1;
+    X0.queue = queue_slot(side);
+    if (!X0.queue) return -1;
+    X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = a->ap_count;
+  }
+#define LAUNCH_P(J, ST, LD) do { \
+    if (side_launch) hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, side, sc, p, X0); \
+    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<J, ST, LD, false>, A.total)), block, 0, s, sc, p, A); \
+    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, s, sc, p, X); } while (0)
+#define LAUNCH_PD(J, ST) do { if (sc.exact_decode) LAUNCH_P(J, ST, true); else LAUNCH_P(J, ST, false); } while (0)
+  if (stats) { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, true); else LAUNCH_PD(JOB_RENDER, true); }
+  else       { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, false); else LAUNCH_PD(JOB_RENDER, false); }
+#undef LAUNCH_PD
 #undef LAUNCH_P
+  if (side_launch) {
+    if (hipEventRecord(a->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, a->ev_side, 0) != hipSuccess) return -1;
+  }
   const uint64_t npx = (uint64_t)width * (y1 - y0);
   dim3 sgrid((uint32_t)((npx + 255) / 256));
-  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
-  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
+  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
+  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -969,7 +1138,7 @@ int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
   return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream);
 }
 
-int vxrt_trace(const vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax,
+int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax,
                vxrt_hit_t* hits, int mode, void* stream) {
   if (!a || (n && (!rays || !hits))) return -1;
   if (mode != VXRT_MODE_CLOSEST && mode != VXRT_MODE_ANY) return -1;
@@ -983,8 +1152,20 @@ int vxrt_trace(const vxrt_accel_t* a, const float* rays, uint64_t n, const float
   A.status = st; A.queue = queue_slot(s);
   if (!A.queue) return -1;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
+  if (ensure_defer(a, A.total, s) != 0) return -1;
+  A.defer_count = a->defer; A.defer_list = a->defer + 1; A.defer_cap = A.total;
+  if (hipMemsetAsync(a->defer, 0, sizeof(uint32_t), s) != hipSuccess) return -1;
+  PersistArgs X = A;
+  X.queue = queue_slot(s);
+  if (!X.queue) return -1;
   ShadeParams p{};
-  hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false>, n)), dim3(256), 0, s, a->dev, p, A);
+  if (a->dev.exact_decode) {
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, true, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, true, false>, n)), dim3(256), 0, s, a->dev, p, A);
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, true, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X);
+  } else {
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, false, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, false, false>, n)), dim3(256), 0, s, a->dev, p, A);
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, false, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
