@@ -1,0 +1,27 @@
+"""profiles/hbm_traffic.json from a tools/pmc_passes2.sh summary: HBM-side bytes of one bench step.
+
+FETCH_SIZE / WRITE_SIZE are in KiB and come from separate --pmc passes.  On gfx950 FETCH_SIZE reports
+half of the bytes of a wide (16 B/lane) read stream (MI355X_MICROARCH.md, HBM section), which is
+the access shape of every load in these kernels, so reads are doubled; WRITE_SIZE is exact."""
+import json
+import re
+import sys
+
+summary, out = sys.argv[1], sys.argv[2]
+cur, data = None, {}
+for line in open(summary):
+    if line.startswith("void ") or line.startswith("accel_"):
+        cur = line.strip()
+        data.setdefault(cur, {})
+    else:
+        m = re.match(r"\s+(\S+)\s+n=(\d+)\s+mean=(\S+)", line)
+        if m and cur:
+            data[cur][m.group(1)] = float(m.group(3))
+step = {k: v for k, v in data.items() if ("rt_persistent_kernel<1, false" in k or "rt_shade_kernel<false>" in k)}
+rd = sum(2.0 * v.get("FETCH_SIZE", 0.0) * 1024 for v in step.values())
+wr = sum(v.get("WRITE_SIZE", 0.0) * 1024 for v in step.values())
+json.dump({"bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
+           "kernels": {k: {"FETCH_SIZE_KiB": v.get("FETCH_SIZE"), "WRITE_SIZE_KiB": v.get("WRITE_SIZE")} for k, v in step.items()},
+           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; reads x2 (gfx950 FETCH_SIZE counts 64 B per 128-B request), per bench step = main traversal + EXACT launches + shading",
+           "source": summary}, open(out, "w"), indent=1)
+print(open(out).read())

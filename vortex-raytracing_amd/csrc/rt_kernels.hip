@@ -331,6 +331,9 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #ifndef RT_DEAD_MAX
 #define RT_DEAD_MAX 64      // render jobs: leave the traversal loop (finish rays, fetch jobs) once this many lanes
 #endif                      // are not traversing (finished or idle); 64 = whole-tile batches
+#ifndef RT_SHADOW_FINISH_MIN
+#define RT_SHADOW_FINISH_MIN 65   // > 64: off
+#endif
 #ifndef RT_TRACE_DEAD_MAX
 #define RT_TRACE_DEAD_MAX 16   // ray-buffer jobs (incoherent rays): refill early
 #endif
@@ -384,6 +387,9 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 template <int JOB, bool STATS, bool LDEXP, bool EXACT>
 __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
   constexpr uint32_t DEAD_MAX = JOB == JOB_TRACE ? RT_TRACE_DEAD_MAX : RT_DEAD_MAX;
+  // render-with-shadow jobs: retire finished primary rays (their lanes continue with the occlusion ray
+  // of the same pixel - same traversal code, so no phase mixing) before the whole tile is done
+  constexpr uint32_t FINISH_MIN = JOB == JOB_RENDER_SHADOW ? RT_SHADOW_FINISH_MIN : 65u;
   const uint32_t lane = threadIdx.x & 63u;
   // EXACT launch: the jobs are the entries of the deferral list the main launch left behind
   const uint32_t n_jobs = EXACT ? min(*A.defer_count, A.defer_cap) : A.total;
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
     // RT_CHUNK jobs); lanes then draw from the wavefront's private range.
     {
       const unsigned long long idle = __ballot(cur == DESC_IDLE);
-      if (!queue_empty && idle != 0ull) {
+      if (!queue_empty && idle != 0ull && (JOB == JOB_TRACE || FINISH_MIN > 64u || idle == ~0ull || RT_DEAD_MAX < 64)) {
         if (loc_next == loc_end) {   // wave-uniform: reserve the next chunk, stealing from other shards when the home shard is dry
           while (tries < QUEUE_SHARDS) {
             const uint32_t s_lo = shard * per_shard;
@@ -635,8 +641,9 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
       const unsigned long long work = __ballot(is_work_desc(cur));
       if (work == 0ull) break;
       const unsigned long long done = __ballot(cur == DESC_DONE);
-      const uint32_t revivable = (uint32_t)__popcll(done) + (queue_empty && loc_next == loc_end ? 0u : 64u - (uint32_t)__popcll(work | done));
-      if (revivable >= DEAD_MAX) break;
+      const uint32_t n_done = (uint32_t)__popcll(done);
+      const uint32_t n_idle = queue_empty && loc_next == loc_end ? 0u : 64u - (uint32_t)__popcll(work | done);
+      if (n_done + n_idle >= DEAD_MAX || n_done >= FINISH_MIN) break;
     }
 
     // ================= finish: rays whose traversal ended =================
