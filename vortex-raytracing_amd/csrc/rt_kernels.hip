@@ -331,6 +331,9 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #ifndef RT_DEAD_MAX
 #define RT_DEAD_MAX 64      // render jobs: leave the traversal loop (finish rays, fetch jobs) once this many lanes
 #endif                      // are not traversing (finished or idle); 64 = whole-tile batches
+#ifndef RT_UNORDERED_OCCLUSION
+#define RT_UNORDERED_OCCLUSION 1
+#endif
 #ifndef RT_SHADOW_FINISH_MIN
 #define RT_SHADOW_FINISH_MIN 65   // > 64: off
 #endif
@@ -583,17 +586,36 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
         Cand c[4];
         eval_children<EXACT, LDEXP>(np, top, arx, ary, arz, aix, aiy, aiz, hitd, c);
         int n = (c[0].d < __builtin_inff()) + (c[1].d < __builtin_inff()) + (c[2].d < __builtin_inff()) + (c[3].d < __builtin_inff());
-        cmpx(c[0], c[1]); cmpx(c[2], c[3]); cmpx(c[0], c[2]); cmpx(c[1], c[3]); cmpx(c[1], c[2]);
-        if (n > 0) {
-          if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
-          // far first so that the nearest pending sibling is on top (:98-103)
-          if (n > 3) push(c[3].desc, fmaxf(path_m, c[3].d));
-          if (n > 2) push(c[2].desc, fmaxf(path_m, c[2].d));
-          if (n > 1) push(c[1].desc, fmaxf(path_m, c[1].d));
-          cur = c[0].desc;
-          path_m = fmaxf(path_m, c[0].d);
+        if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && !STATS && __all((flags & F_ANYHIT) != 0u)) {   // STATS keeps the reference's order, hence its fetch counts
+          // occlusion rays of a frame only feed a boolean (is anything hit before the light?): the set
+          // of triangles an any-hit traversal can reach does not depend on the visiting order, so the
+          // ordering network and the path_m bookkeeping are skipped (vxrt_trace's MODE_ANY, which
+          // returns the reference's FIRST accepted candidate, keeps the ordered path)
+          const bool v0 = c[0].d < __builtin_inff(), v1 = c[1].d < __builtin_inff(), v2 = c[2].d < __builtin_inff(), v3 = c[3].d < __builtin_inff();
+          if (n > 0) {
+            if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
+            cur = v0 ? c[0].desc : (v1 ? c[1].desc : (v2 ? c[2].desc : c[3].desc));
+            if (n > 1) {
+              if (v1 && v0) push(c[1].desc, c[1].d);
+              if (v2 && (v0 || v1)) push(c[2].desc, c[2].d);
+              if (v3 && (v0 || v1 || v2)) push(c[3].desc, c[3].d);
+            }
+          } else {
+            pop_next();
+          }
         } else {
-          pop_next();
+          cmpx(c[0], c[1]); cmpx(c[2], c[3]); cmpx(c[0], c[2]); cmpx(c[1], c[3]); cmpx(c[1], c[2]);
+          if (n > 0) {
+            if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
+            // far first so that the nearest pending sibling is on top (:98-103)
+            if (n > 3) push(c[3].desc, fmaxf(path_m, c[3].d));
+            if (n > 2) push(c[2].desc, fmaxf(path_m, c[2].d));
+            if (n > 1) push(c[1].desc, fmaxf(path_m, c[1].d));
+            cur = c[0].desc;
+            path_m = fmaxf(path_m, c[0].d);
+          } else {
+            pop_next();
+          }
         }
       }
       if (__any(is_inst_desc(cur))) {
