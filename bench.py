@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-shadow", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-seconds of host work for cpu_baseline")
+    ap.add_argument("--frames-in-flight", type=int, default=4,
+                    help="frames kept in flight on as many HIP streams (vxrt_accel_frames_in_flight); 1 = strictly serial frames")
     ap.add_argument("--random-rays", type=int, default=0, help="also time N incoherent random rays (vxrt_trace), reported under extras")
     return ap.parse_args()
 
@@ -133,11 +135,14 @@ def main():
         y0, y1 = 0, H
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
-    frames = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(2)]
+    nfl = max(1, min(8, a.frames_in_flight))
+    # frame i goes to stream i % nfl and framebuffer i % nfl; the accel keeps nfl frame contexts
+    streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(nfl - 1)]
+    frames = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(max(2, nfl))]
     counters = torch.zeros(8, dtype=torch.int64, device=dev)
 
-    def launch(buf, count_ptr=None):
-        rtapi.render(ds.accel, W, H, y0, y1, params, buf.data_ptr(), shadow, None, None, count_ptr, sptr)
+    def launch(buf, count_ptr=None, st=None):
+        rtapi.render(ds.accel, W, H, y0, y1, params, buf.data_ptr(), shadow, None, None, count_ptr, (st or stream).cuda_stream)
 
     # rays per step on this rank (primary + shadow), counted once by the kernel itself
     launch(frames[0], counters.data_ptr())
@@ -148,22 +153,24 @@ def main():
     if hasattr(rtapi, "render_stats"):
         algo = rtapi.render_stats(ds.accel, W, H, y0, y1, params, frames[0].data_ptr(), shadow, sptr)
 
+    rtapi.accel_frames_in_flight(ds.accel, nfl)
     gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    gdone = [None, None]   # per framebuffer: event of the last gather that read it
+    gdone = [None] * len(frames)   # per framebuffer: event of the last gather that read it
 
     def step(i, ev=None):
-        b = i & 1
+        b = i % len(frames)
         buf = frames[b]
+        st = streams[i % nfl]
         if gdone[b] is not None:
-            stream.wait_event(gdone[b])        # do not overwrite a frame that is still being gathered
+            st.wait_event(gdone[b])            # do not overwrite a frame that is still being gathered
         if ev is not None:
-            ev[0].record(stream)
-        launch(buf)
+            ev[0].record(st)
+        launch(buf, st=st)
         if ev is not None:
-            ev[1].record(stream)
+            ev[1].record(st)
         if world > 1:
             # image assembly overlaps the next step's traversal: the gather runs on its own stream
-            gather_stream.wait_stream(stream)
+            gather_stream.wait_stream(st)
             with torch.cuda.stream(gather_stream):
                 if a.shard == "rows":
                     sharding.gather_frame(buf[y0:y1], H, W, rank, world)
@@ -173,9 +180,19 @@ def main():
                 gdone[b] = torch.cuda.Event()
                 gdone[b].record(gather_stream)
 
+    # isolated duration of one step's launches (nothing else on the GPU): HIP events on the launch stream
+    iso = []
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    for i in range(min(10, max(3, a.steps))):
+        e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        e[0].record(stream)
+        launch(frames[0])
+        e[1].record(stream)
+        torch.cuda.synchronize()
+        iso.append(e[0].elapsed_time(e[1]))
+    iso_ms = sum(iso) / len(iso)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -183,8 +200,6 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, evs[i])
-    if gather_stream is not None:
-        stream.wait_stream(gather_stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -200,7 +215,13 @@ def main():
     else:
         rays_all = rays_rank
     assert rtapi.status(sptr) == 0
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps   # HIP events on the launch stream
+    # HIP events on the launch streams.  With frames in flight the launches of consecutive steps overlap, so
+    # the per-launch duration that prices the roofline is the span of the timed region's events divided by
+    # the launches in it (their union, not their sum); the overlapped and the isolated per-launch
+    # durations are reported next to it.
+    ovl_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps
+    span_ms = max(evs[0][0].elapsed_time(e1) for _, e1 in evs)
+    kern_ms = span_ms / a.steps
 
     extras = {}
     if a.random_rays and rank == 0:
@@ -238,7 +259,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (procedural 'Sponza-class' atrium, seed 3; no Sponza/bunny asset exists offline)",
             "config": {"workload": "configs[2]: Sponza-class %d tris, %dx%d, primary + 1 shadow ray per hit%s" % (scene.n_tris, W, H, "" if shadow else " (shadow disabled)"),
-                       "rays_per_step_per_gpu": rays_rank,
+                       "rays_per_step_per_gpu": rays_rank, "frames_in_flight": nfl,
                        "parallelism": ("spp-sharded x%d: one sample (full frame) per GPU, RCCL gather of frames to rank 0" % world) if a.shard == "samples"
                                       else ("row bands x%d of one frame, RCCL gather to rank 0" % world),
                        "bvh_nodes": scene.n_bvh_nodes, "bvh_depth": scene.info.get("max_depth")},
@@ -250,10 +271,12 @@ def main():
         # EXACT launches for the rays with NaN-capable slabs, and the shading pass; priced together
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "rt_persistent_kernel<JOB_RENDER%s> (+ EXACT launches + rt_shade_kernel)" % ("_SHADOW" if shadow else ""),
-                "kernel_ms": round(kern_ms, 4)}
+                "kernel_ms": round(kern_ms, 4), "kernel_ms_overlapped": round(ovl_ms, 4), "kernel_ms_isolated": round(iso_ms, 4),
+                "frames_in_flight": nfl}
         if bytes_launch:
             ach = bytes_launch / (kern_ms * 1e-3) / 1e9
-            roof.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": bytes_launch,
+            roof.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "frac_isolated": round(bytes_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": bytes_launch,
                          "bytes_per_ray": round(bytes_launch / rays_rank, 1), "counts": algo})
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):

@@ -187,6 +187,15 @@ int vxrt_accel_build(const vxrt_scene_t* scene, void* stream, vxrt_accel_t** out
 int vxrt_accel_destroy(vxrt_accel_t* accel);
 uint64_t vxrt_accel_bytes(const vxrt_accel_t* accel);
 
+/* Number of frames (vxrt_render / vxrt_trace calls) this accel keeps in flight, 1..8, default 1.
+ * Each in-flight frame has its own hit-record buffer, deferred-ray list and side stream; calls take
+ * them round robin, and a call that reuses a context is ordered behind that context's previous
+ * call by an event.  With n > 1 and the calls issued on n different streams, the draining tail of
+ * one persistent traversal launch overlaps the head of the next frame's (the reference renders one
+ * frame per vx_start, tracer.cpp:272-281; this is the knob a frame loop around it would use).
+ * Waits for the device to go idle.  Results do not depend on n. */
+int vxrt_accel_frames_in_flight(vxrt_accel_t* accel, uint32_t n);
+
 /* Render rows [y0,y1) of the RTU test's frame: camera ray (kernel.cpp:28-39) -> closest hit ->
  * closest/miss shade -> RGB8 pack -> dst[x + y*W] (kernel.cpp:95-106).  `dst` points at pixel
  * (0,0) of the full W x H frame.  shadow != 0 adds one occlusion ray per hit (extension).
@@ -206,6 +215,13 @@ int vxrt_render(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y
 int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                       const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                       unsigned long long* counters, void* stream);
+
+/* Diagnostic variant of vxrt_render_stats: additionally logs per wavefront of the main traversal
+ * launch {first clock, last clock, rays started} (100 MHz constant clock) into wave_log, a device
+ * u64[3 * 4 * 8 * 256] array, to study load balance of the persistent launch. */
+int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                         const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
+                         unsigned long long* counters, unsigned long long* wave_log, void* stream);
 
 /* Trace n rays (6 floats each: origin, direction) read from HBM, write n hit records.
  * tmax: optional per-ray upper bound (NULL = 1e30). */

@@ -248,3 +248,39 @@ def test_fetch_counters_equal_oracle_counts(vrt, po, gpu_device):
     assert c["shaded_hits"] == int((hits["dist"] < 1e29).sum())
     rpx, _, _ = po.render(sc, w, h)
     assert np.array_equal(px.cpu().numpy().view(np.uint32), rpx)
+
+
+def test_frames_in_flight_do_not_change_results(vrt, po, gpu_device):
+    """vxrt_accel_frames_in_flight: frames issued round robin on three streams (with shadow rays, so the
+    hit-record buffer and the deferred-ray list of a frame are live across kernels) equal the serial
+    frames; a context reused on another stream is ordered behind its previous frame."""
+    import torch
+    sc = vrt.scene.procedural("blob", 4, 0, 5)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    w, h = 320, 200
+    lights = [(40.0, 60.0, 20.0), (-30.0, 50.0, 10.0), (5.0, 80.0, -40.0), (60.0, 20.0, 60.0), (0.0, 100.0, 0.0)]
+    plist = []
+    for lp in lights:
+        p = vrt.rtapi.default_shade_params()
+        p.light_pos[:] = lp
+        plist.append(p)
+    serial = [gpu_render(vrt, ds, w, h, shadow=1, params=p)[0] for p in plist]
+    assert any((serial[0] != s).any() for s in serial[1:])      # the frames really differ
+    with pytest.raises(RuntimeError):
+        vrt.rtapi.accel_frames_in_flight(ds.accel, 0)
+    with pytest.raises(RuntimeError):
+        vrt.rtapi.accel_frames_in_flight(ds.accel, 9)
+    vrt.rtapi.accel_frames_in_flight(ds.accel, 3)
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(2)]   # fewer streams than contexts on purpose
+    outs = [torch.zeros((h, w), dtype=torch.int32, device=gpu_device) for _ in range(2 * len(plist))]
+    torch.cuda.synchronize()
+    for i, buf in enumerate(outs):
+        vrt.rtapi.render(ds.accel, w, h, 0, h, plist[i % len(plist)], buf.data_ptr(), 1, None, None, None,
+                         streams[i % len(streams)].cuda_stream)
+    torch.cuda.synchronize()
+    assert vrt.rtapi.status(streams[0].cuda_stream) == 0
+    for i, buf in enumerate(outs):
+        np.testing.assert_array_equal(buf.cpu().numpy().view(np.uint32), serial[i % len(plist)])
+    vrt.rtapi.accel_frames_in_flight(ds.accel, 1)
+    again = gpu_render(vrt, ds, w, h, shadow=1, params=plist[0])[0]
+    np.testing.assert_array_equal(again, serial[0])

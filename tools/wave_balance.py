@@ -1,0 +1,28 @@
+"""Diagnostic: when do the wavefronts of the persistent traversal launch start and stop?"""
+import ctypes as C, importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+vrt = importlib.import_module("vortex-raytracing_amd")
+W, H = 1920, 1080
+sc = vrt.scene.procedural("atrium", 8, 0, 3)
+ds = vrt.tracer.DeviceScene(sc, "cuda:0")
+p = vrt.rtapi.default_shade_params(); p.light_pos[:] = (300.0, 480.0, 60.0)
+px = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+L = vrt.rtapi._lib()
+L.vxrt_render_wave_log.restype = C.c_int
+L.vxrt_render_wave_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vrt.rtapi.ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+for shadow in (1,):
+    for it in range(2):
+        cnt = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+        log = torch.zeros((4 * 8 * 256, 3), dtype=torch.int64, device="cuda:0")
+        assert L.vxrt_render_wave_log(ds.accel, W, H, 0, H, C.byref(p), shadow, px.data_ptr(), cnt.data_ptr(), log.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+    lg = log.cpu().numpy().astype(np.float64)
+    lg = lg[lg[:, 1] > 0]
+    t0 = lg[:, 0].min()
+    start, end, rays = (lg[:, 0] - t0) / 100.0, (lg[:, 1] - t0) / 100.0, lg[:, 2]
+    span = end.max()
+    print("waves", len(lg), "span_us %.1f" % span, "start p50 %.1f p99 %.1f max %.1f" % (np.percentile(start, 50), np.percentile(start, 99), start.max()))
+    print("end: p1 %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(end, q) for q in (1, 10, 50, 90, 100)))
+    print("rays/wave: min %d p50 %d max %d" % (rays.min(), np.percentile(rays, 50), rays.max()))
+    print("mean alive fraction %.3f" % ((end - start).sum() / (len(lg) * span)))

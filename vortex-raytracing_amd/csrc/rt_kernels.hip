@@ -373,6 +373,7 @@ struct PersistArgs {
   // the main launch: their job id (bit 31 = occlusion phase) is appended here and a second, small
   // launch of the EXACT variant (libstdc++ min/max forms) traces them
   uint32_t* defer_count; uint32_t* defer_list; uint32_t defer_cap;
+  unsigned long long* wave_log;   // STATS only, optional: per wavefront {first clock, last clock, rays started} (100 MHz)
 };
 
 __device__ __forceinline__ bool is_node_desc(uint32_t d) { return d < 0x80000000u; }
@@ -423,6 +424,8 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
   uint32_t tries = 0, loc_next = 0, loc_end = 0;
   Fetches fx;
   unsigned nrays = 0, nhit = 0;
+  unsigned long long t_first = 0;
+  if (STATS && A.wave_log) t_first = wall_clock64();
 
   auto pixel_of = [&](uint32_t r, uint32_t& x, uint32_t& y) {
     const uint32_t tile = r >> 6, l = r & 63u;
@@ -715,6 +718,14 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
   }
 #undef CTX
 
+  if (STATS && A.wave_log && !EXACT) {
+    unsigned s = nrays;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) {
+      unsigned long long* w = A.wave_log + 3ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+      w[0] = t_first; w[1] = wall_clock64(); w[2] = s;
+    }
+  }
   if (A.counters) {
     unsigned v[5] = {nrays, fx.node, fx.inst, fx.tri, nhit};
 #pragma unroll
@@ -926,34 +937,69 @@ static uint32_t persistent_grid(K kernel, uint64_t jobs) {
   return (uint32_t)(g ? g : 1);
 }
 
+// Mutable per-frame state.  An accel owns up to MAX_FRAMES_IN_FLIGHT of these and hands them out round
+// robin, so that renders issued on different streams overlap on the GPU (the tail of one persistent
+// launch, where most wavefronts have drained, is filled by the head of the next frame's launch); a
+// context is handed out again only behind the event of its previous render.
+#define MAX_FRAMES_IN_FLIGHT 8
+struct FrameCtx {
+  void* hitbuf = nullptr;      // W*H hit records between the traversal and the shading pass
+  uint64_t hitbuf_pixels = 0;
+  uint32_t* defer = nullptr;   // [0] count, [1..] job list of the EXACT launch
+  uint64_t defer_cap = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr;
+  bool busy = false;
+};
+
 struct vxrt_accel {
   SceneDev dev{};
   vxrt_scene_t ref{};
   void* tlas_c = nullptr; void* bvh_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr;
-  void* hitbuf = nullptr;      // W*H hit records between the traversal and the shading pass
-  uint64_t hitbuf_pixels = 0;
+  FrameCtx ctx[MAX_FRAMES_IN_FLIGHT];
+  uint32_t n_ctx = 1, next_ctx = 0;
   float* uvtab = nullptr;      // camera tables: u[W] then v[H]
   uint32_t uv_w = 0, uv_h = 0;
-  uint32_t* defer = nullptr;   // [0] count, [1..] job list of the EXACT launch
-  uint64_t defer_cap = 0;
   // camera pixels whose primary ray has a zero direction component (u == 0 or v == 0): listed on the
   // host per (W, H, y0, y1) and traced by an EXACT launch on a side stream, concurrently with the main one
   uint32_t* apriori = nullptr; // [0] count, [1..] job ids
   uint32_t ap_count = 0, ap_key[4] = {0, 0, 0, 0};
   uint64_t ap_cap = 0;
-  hipStream_t side = nullptr;
-  hipEvent_t ev_in = nullptr, ev_side = nullptr;
   int device = 0;
 };
 
 static void accel_free(vxrt_accel* a) {
   if (!a) return;
+  (void)hipDeviceSynchronize();
   (void)hipFree(a->tlas_c); (void)hipFree(a->bvh_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
-  (void)hipFree(a->hitbuf); (void)hipFree(a->uvtab); (void)hipFree(a->defer); (void)hipFree(a->apriori);
-  if (a->side) { (void)hipStreamSynchronize(a->side); (void)hipStreamDestroy(a->side); }
-  if (a->ev_in) (void)hipEventDestroy(a->ev_in);
-  if (a->ev_side) (void)hipEventDestroy(a->ev_side);
+  (void)hipFree(a->uvtab); (void)hipFree(a->apriori);
+  for (FrameCtx& c : a->ctx) {
+    (void)hipFree(c.hitbuf); (void)hipFree(c.defer);
+    if (c.side) (void)hipStreamDestroy(c.side);
+    if (c.ev_in) (void)hipEventDestroy(c.ev_in);
+    if (c.ev_side) (void)hipEventDestroy(c.ev_side);
+    if (c.ev_done) (void)hipEventDestroy(c.ev_done);
+  }
   delete a;
+}
+
+// next frame context, ordered on `s` behind its previous use
+static FrameCtx* acquire_ctx(vxrt_accel* a, hipStream_t s) {
+  FrameCtx& c = a->ctx[a->next_ctx++ % a->n_ctx];
+  if (!c.side) {
+    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.ev_side, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  if (c.busy && hipStreamWaitEvent(s, c.ev_done, 0) != hipSuccess) return nullptr;
+  return &c;
+}
+
+static int release_ctx(FrameCtx* c, hipStream_t s) {
+  if (hipEventRecord(c->ev_done, s) != hipSuccess) return -1;
+  c->busy = true;
+  return 0;
 }
 
 extern "C" {
@@ -1036,19 +1082,26 @@ uint64_t vxrt_accel_bytes(const vxrt_accel_t* a) {
          (uint64_t)a->ref.n_tris * WTRI_FLOATS * 4 + (uint64_t)a->ref.n_blas * 4;
 }
 
-static int ensure_defer(vxrt_accel_t* a, uint64_t jobs, hipStream_t s) {
-  if (a->defer_cap >= jobs) return 0;
+int vxrt_accel_frames_in_flight(vxrt_accel_t* a, uint32_t n) {
+  if (!a || n < 1 || n > MAX_FRAMES_IN_FLIGHT) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  a->n_ctx = n; a->next_ctx = 0;
+  return 0;
+}
+
+static int ensure_defer(FrameCtx* c, uint64_t jobs, hipStream_t s) {
+  if (c->defer_cap >= jobs) return 0;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
-  (void)hipFree(a->defer);
-  a->defer = nullptr; a->defer_cap = 0;
-  if (hipMalloc((void**)&a->defer, (jobs + 1) * sizeof(uint32_t)) != hipSuccess) return -1;
-  a->defer_cap = jobs;
+  (void)hipFree(c->defer);
+  c->defer = nullptr; c->defer_cap = 0;
+  if (hipMalloc((void**)&c->defer, (jobs + 1) * sizeof(uint32_t)) != hipSuccess) return -1;
+  c->defer_cap = jobs;
   return 0;
 }
 
 static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits, float* colors,
-                         unsigned long long* counters, bool stats, void* stream) {
+                         unsigned long long* counters, bool stats, void* stream, unsigned long long* wave_log = nullptr) {
   if (!a || !params || !dst) return -1;
   if (!a->ref.triEx || !a->ref.mat || a->ref.n_mats == 0) return -1;  // shading needs them (closest.cpp:52-55)
   if (width == 0 || height == 0 || y0 > y1 || y1 > height) return -1;
@@ -1069,21 +1122,23 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   const SceneDev& sc = a->dev;
-  // hit-record buffer between the two passes (one render in flight per accel)
+  FrameCtx* c = acquire_ctx(a, s);
+  if (!c) return -1;
+  // hit-record buffer between the two passes (one per frame in flight)
   const uint64_t pixels = (uint64_t)width * height;
-  if (a->hitbuf_pixels < pixels) {
+  if (c->hitbuf_pixels < pixels) {
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
-    (void)hipFree(a->hitbuf);
-    a->hitbuf = nullptr; a->hitbuf_pixels = 0;
-    if (hipMalloc(&a->hitbuf, pixels * sizeof(HitRec)) != hipSuccess) return -1;
-    a->hitbuf_pixels = pixels;
+    (void)hipFree(c->hitbuf);
+    c->hitbuf = nullptr; c->hitbuf_pixels = 0;
+    if (hipMalloc(&c->hitbuf, pixels * sizeof(HitRec)) != hipSuccess) return -1;
+    c->hitbuf_pixels = pixels;
   }
   if (a->uv_w != width || a->uv_h != height) {
     // kernel.cpp:32-33 evaluated on the host in double, once per column and row
     std::vector<float> tab((size_t)width + height);
     for (uint32_t x = 0; x < width; ++x) tab[x] = (float)(((double)x * 2.0 - (double)width) / (double)height);
     for (uint32_t y = 0; y < height; ++y) tab[width + y] = (float)(((double)y * 2.0 - (double)height) / (double)height);
-    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;   // frames in flight on other streams read the old table
     (void)hipFree(a->uvtab);
     a->uvtab = nullptr; a->uv_w = a->uv_h = 0;
     if (hipMalloc((void**)&a->uvtab, tab.size() * sizeof(float)) != hipSuccess) return -1;
@@ -1092,20 +1147,15 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   }
   PersistArgs A{};
   A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.total = n_tiles * 64u;
-  A.hits = (HitRec*)a->hitbuf; A.counters = counters; A.status = st;
+  A.hits = (HitRec*)c->hitbuf; A.counters = counters; A.status = st; A.wave_log = wave_log;
   A.utab = a->uvtab; A.vtab = a->uvtab + width;
-  if (ensure_defer(a, A.total, s) != 0) return -1;
-  A.defer_count = a->defer; A.defer_list = a->defer + 1; A.defer_cap = A.total;
-  if (hipMemsetAsync(a->defer, 0, sizeof(uint32_t), s) != hipSuccess) return -1;
+  if (ensure_defer(c, A.total, s) != 0) return -1;
+  A.defer_count = c->defer; A.defer_list = c->defer + 1; A.defer_cap = A.total;
+  if (hipMemsetAsync(c->defer, 0, sizeof(uint32_t), s) != hipSuccess) return -1;
   A.queue = queue_slot(s);
   if (!A.queue) return -1;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
   // a-priori EXACT list (camera rays with u == 0 or v == 0), rebuilt only when the window changes
-  if (!a->side) {
-    if (hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess) return -1;
-    if (hipEventCreateWithFlags(&a->ev_in, hipEventDisableTiming) != hipSuccess) return -1;
-    if (hipEventCreateWithFlags(&a->ev_side, hipEventDisableTiming) != hipSuccess) return -1;
-  }
   if (a->ap_key[0] != width || a->ap_key[1] != height || a->ap_key[2] != y0 || a->ap_key[3] != y1 || !a->apriori) {
     std::vector<uint32_t> list(1, 0u);
     for (uint32_t t = 0; t < n_tiles; ++t)
@@ -1117,7 +1167,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
         if (u == 0.0f || v == 0.0f) list.push_back(t * 64u + l);
       }
     list[0] = (uint32_t)(list.size() - 1);
-    if (hipStreamSynchronize(s) != hipSuccess || hipStreamSynchronize(a->side) != hipSuccess) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (a->ap_cap < list.size()) {
       (void)hipFree(a->apriori);
       a->apriori = nullptr; a->ap_cap = 0;
@@ -1135,9 +1185,9 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   X.queue = queue_slot(s);
   if (!X.queue) return -1;
   const bool side_launch = a->ap_count != 0;
-  hipStream_t side = a->side;
+  hipStream_t side = c->side;
   if (side_launch) {
-    if (hipEventRecord(a->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, a->ev_in, 0) != hipSuccess) return -1;
+    if (hipEventRecord(c->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, c->ev_in, 0) != hipSuccess) return -1;
     X0.queue = queue_slot(side);
     if (!X0.queue) return -1;
     X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = a->ap_count;
@@ -1152,13 +1202,14 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
 #undef LAUNCH_PD
 #undef LAUNCH_P
   if (side_launch) {
-    if (hipEventRecord(a->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, a->ev_side, 0) != hipSuccess) return -1;
+    if (hipEventRecord(c->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, c->ev_side, 0) != hipSuccess) return -1;
   }
   const uint64_t npx = (uint64_t)width * (y1 - y0);
   dim3 sgrid((uint32_t)((npx + 255) / 256));
-  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
-  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)a->hitbuf, dst, (HitRec*)hits, colors, counters);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters);
+  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters);
+  if (hipGetLastError() != hipSuccess) return -1;
+  return release_ctx(c, s);
 }
 
 int vxrt_render(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
@@ -1176,6 +1227,15 @@ int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
   return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream);
 }
 
+// diagnostic: vxrt_render_stats that also logs, per wavefront of the main traversal launch, the first
+// and last 100 MHz clock and the number of rays it started (wave_log: device u64[3 * waves], waves =
+// 4 * blocks of the launch; 3 * 4 * 8 * 256 entries are always enough)
+int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                         const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
+                         unsigned long long* counters, unsigned long long* wave_log, void* stream) {
+  return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream, wave_log);
+}
+
 int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax,
                vxrt_hit_t* hits, int mode, void* stream) {
   if (!a || (n && (!rays || !hits))) return -1;
@@ -1190,9 +1250,11 @@ int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax
   A.status = st; A.queue = queue_slot(s);
   if (!A.queue) return -1;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
-  if (ensure_defer(a, A.total, s) != 0) return -1;
-  A.defer_count = a->defer; A.defer_list = a->defer + 1; A.defer_cap = A.total;
-  if (hipMemsetAsync(a->defer, 0, sizeof(uint32_t), s) != hipSuccess) return -1;
+  FrameCtx* c = acquire_ctx(a, s);
+  if (!c) return -1;
+  if (ensure_defer(c, A.total, s) != 0) return -1;
+  A.defer_count = c->defer; A.defer_list = c->defer + 1; A.defer_cap = A.total;
+  if (hipMemsetAsync(c->defer, 0, sizeof(uint32_t), s) != hipSuccess) return -1;
   PersistArgs X = A;
   X.queue = queue_slot(s);
   if (!X.queue) return -1;
@@ -1204,7 +1266,8 @@ int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, false, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, false, false>, n)), dim3(256), 0, s, a->dev, p, A);
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, false, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X);
   }
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  if (hipGetLastError() != hipSuccess) return -1;
+  return release_ctx(c, s);
 }
 
 int vxrt_status(void* stream, uint32_t* status) {

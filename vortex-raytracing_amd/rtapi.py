@@ -44,6 +44,8 @@ def _lib():
         L.vxrt_accel_destroy.argtypes = [C.c_void_p]
         L.vxrt_accel_bytes.restype = C.c_uint64
         L.vxrt_accel_bytes.argtypes = [C.c_void_p]
+        L.vxrt_accel_frames_in_flight.restype = C.c_int
+        L.vxrt_accel_frames_in_flight.argtypes = [C.c_void_p, C.c_uint32]
         L.vxrt_render.restype = C.c_int
         L.vxrt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -69,6 +71,12 @@ def accel_build(scene, stream=None):
 def accel_destroy(accel):
     if accel:
         check(_lib().vxrt_accel_destroy(accel), "vxrt_accel_destroy")
+
+
+def accel_frames_in_flight(accel, n):
+    """vxrt_accel_frames_in_flight: frames this accel keeps in flight (1..8); raises on a bad count."""
+    if _lib().vxrt_accel_frames_in_flight(accel, int(n)) != 0:
+        raise RuntimeError("vxrt_accel_frames_in_flight(%r) failed" % (n,))
 
 
 def accel_bytes(accel):
