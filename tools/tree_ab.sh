@@ -3,5 +3,5 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for kv in "$@"; do
   echo "== $kv"
-  env $kv python bench.py --steps 30 --warmup 3 --no-cpu-baseline --random-rays 4194304 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('Mrays/s', d['value'], 'ms', d['roofline']['kernel_ms'], 'B/ray', d['roofline']['bytes_per_ray'], 'frac', d['roofline']['frac'], d['extras'])"
+  env $kv python bench.py --steps 100 --warmup 10 --no-cpu-baseline --random-rays 4194304 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('Mrays/s', d['value'], 'ms', d['roofline']['kernel_ms'], 'B/ray', d['roofline']['bytes_per_ray'], 'frac', d['roofline']['frac'], d['extras'])"
 done

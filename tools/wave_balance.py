@@ -14,7 +14,7 @@ L.vxrt_render_wave_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint3
 for shadow in (1,):
     for it in range(2):
         cnt = torch.zeros(8, dtype=torch.int64, device="cuda:0")
-        log = torch.zeros((4 * 8 * 256, 3), dtype=torch.int64, device="cuda:0")
+        log = torch.zeros((4 * 8 * 256, 10), dtype=torch.int64, device="cuda:0")
         assert L.vxrt_render_wave_log(ds.accel, W, H, 0, H, C.byref(p), shadow, px.data_ptr(), cnt.data_ptr(), log.data_ptr(), None) == 0
         torch.cuda.synchronize()
     lg = log.cpu().numpy().astype(np.float64)
@@ -26,3 +26,9 @@ for shadow in (1,):
     print("end: p1 %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(end, q) for q in (1, 10, 50, 90, 100)))
     print("rays/wave: min %d p50 %d max %d" % (rays.min(), np.percentile(rays, 50), rays.max()))
     print("mean alive fraction %.3f" % ((end - start).sum() / (len(lg) * span)))
+    it, nx, nl, lx, ll = (lg[:, k].sum() for k in range(3, 8))
+    print("iterations/wave %.0f; node body: run in %.3f of iterations, %.1f lanes of 64; leaf body: run in %.3f, %.1f lanes"
+          % (it / len(lg), nx / it, nl / max(nx, 1), lx / it, ll / max(lx, 1)))
+    print("rays %d -> node steps/ray %.2f, leaf visits/ray %.2f; wave-level node runs/ray %.3f leaf runs/ray %.3f"
+          % (rays.sum(), nl / rays.sum(), ll / rays.sum(), nx * 64 / rays.sum(), lx * 64 / rays.sum()))
+    print("node-body runs with no 3rd/4th child in any lane: %.3f; no 4th child: %.3f" % (lg[:, 8].sum() / nx, lg[:, 9].sum() / nx))

@@ -86,11 +86,7 @@ __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b 
 // EXACT selects the libstdc++ min/max forms; the fast form uses v_min/v_max, which differs only
 // when a NaN is present (0*inf), i.e. only if some ray direction component is 0/inf/NaN.
 template <bool EXACT>
-__device__ __forceinline__ float ray_box(float ox, float oy, float oz, float ix, float iy, float iz,
-                                         float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
-  float tx1 = (mnx - ox) * ix, tx2 = (mxx - ox) * ix;
-  float ty1 = (mny - oy) * iy, ty2 = (mxy - oy) * iy;
-  float tz1 = (mnz - oz) * iz, tz2 = (mxz - oz) * iz;
+__device__ __forceinline__ float slab_interval(float tx1, float tx2, float ty1, float ty2, float tz1, float tz2) {
   float tmin, tmax;
   if (EXACT) {
     tmin = std_min(tx1, tx2);
@@ -104,6 +100,15 @@ __device__ __forceinline__ float ray_box(float ox, float oy, float oz, float ix,
     tmax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
   }
   return (tmax < tmin || tmax <= 0) ? RT_LARGE_FLOAT : tmin;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float ray_box(float ox, float oy, float oz, float ix, float iy, float iz,
+                                         float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
+  float tx1 = (mnx - ox) * ix, tx2 = (mxx - ox) * ix;
+  float ty1 = (mny - oy) * iy, ty2 = (mxy - oy) * iy;
+  float tz1 = (mnz - oz) * iz, tz2 = (mxz - oz) * iz;
+  return slab_interval<EXACT>(tx1, tx2, ty1, ty2, tz1, tz2);
 }
 
 // rt_traversal.cpp:263-316 on a wide triangle (v0, edge1, edge2)
@@ -134,25 +139,57 @@ __device__ __forceinline__ float ray_tri(float ox, float oy, float oz, float dx,
   return tf;
 }
 
-struct Cand { float d; uint32_t desc, idx; };
+struct Cand { float d; uint32_t desc; };
 // visit order: nearer first; equal distance -> higher child index first (stable far->near sort of
 // rt_traversal.cpp:76-78 read from the back).  Filtered children carry d = +inf.
+// Adjacent compare-exchange with a strict '<' never reorders equal keys, so a 6-comparator bubble
+// network over the children laid out [3, 2, 1, 0] gives exactly that order without carrying the index.
 __device__ __forceinline__ void cmpx(Cand& x, Cand& y) {
-  const bool sw = (y.d < x.d) || (y.d == x.d && y.idx > x.idx);
+  const bool sw = y.d < x.d;
   const Cand tx = x, ty = y;
-  x.d = sw ? ty.d : tx.d; x.desc = sw ? ty.desc : tx.desc; x.idx = sw ? ty.idx : tx.idx;
-  y.d = sw ? tx.d : ty.d; y.desc = sw ? tx.desc : ty.desc; y.idx = sw ? tx.idx : ty.idx;
+  x.d = sw ? ty.d : tx.d; x.desc = sw ? ty.desc : tx.desc;
+  y.d = sw ? tx.d : ty.d; y.desc = sw ? tx.desc : ty.desc;
+}
+__device__ __forceinline__ void order_children(Cand* c) {   // in: c[k] = child k; out: c[0] nearest ... c[3] farthest
+  Cand s0 = c[3], s1 = c[2], s2 = c[1], s3 = c[0];
+  cmpx(s0, s1); cmpx(s1, s2); cmpx(s2, s3); cmpx(s0, s1); cmpx(s1, s2); cmpx(s0, s1);
+  c[0] = s0; c[1] = s1; c[2] = s2; c[3] = s3;
 }
 
-__device__ __forceinline__ float qbyte(const uint32_t* qb, int byte_off) {   // v_cvt_f32_ubyteN
-  return (float)((qb[byte_off >> 2] >> ((byte_off & 3) * 8)) & 0xffu);
-}
+template <int K>
+__device__ __forceinline__ float qbyte(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }   // v_cvt_f32_ubyteK
 
-// Box tests of the <=4 children of an internal node (rt_traversal.cpp:59-74).
+// Box test of child K of an internal node (rt_traversal.cpp:59-74).  pl[0..2] = the lo planes of x, y, z
+// and pl[3..5] the hi planes, one byte per child.
 // Decode: the reference computes origin + ldexp(float(q), e) (:61-67).  float(q) * 2^e is exact for
 // an 8-bit q whenever 2^e is representable, so fma(float(q), 2^e, origin) rounds the same exact sum
-// once and yields the identical float with one instruction less per coordinate; the accel build
-// verifies this per scene and sets exact_decode otherwise.
+// once and yields the identical float with one instruction less per coordinate.
+// Fast form (!EXACT && !LDEXP): with q_lo <= q_hi the decoded planes, the differences to the origin and
+// the products with 1/d are monotone, so min(t_lo, t_hi) IS the plane on the side the ray comes from:
+// the caller selects the near/far plane words by the sign of 1/d once per node (6 selects for the four
+// children) and the twelve v_min/v_max per child collapse into one v_max3 and one v_min3.  Both
+// preconditions are verified per scene by the accel build, which sets exact_decode otherwise (LDEXP form).
+template <int K, bool EXACT, bool LDEXP>
+__device__ __forceinline__ float child_box(const uint32_t* pl, float px, float py, float pz, float sx, float sy, float sz,
+                                           int ex, int ey, int ez, float rox, float roy, float roz, float rix, float riy, float riz) {
+  float ax, ay, az, bx, by, bz;
+  if (LDEXP) {
+    ax = px + ldexpf(qbyte<K>(pl[0]), ex); ay = py + ldexpf(qbyte<K>(pl[1]), ey); az = pz + ldexpf(qbyte<K>(pl[2]), ez);
+    bx = px + ldexpf(qbyte<K>(pl[3]), ex); by = py + ldexpf(qbyte<K>(pl[4]), ey); bz = pz + ldexpf(qbyte<K>(pl[5]), ez);
+  } else {
+    ax = __fmaf_rn(qbyte<K>(pl[0]), sx, px); ay = __fmaf_rn(qbyte<K>(pl[1]), sy, py); az = __fmaf_rn(qbyte<K>(pl[2]), sz, pz);
+    bx = __fmaf_rn(qbyte<K>(pl[3]), sx, px); by = __fmaf_rn(qbyte<K>(pl[4]), sy, py); bz = __fmaf_rn(qbyte<K>(pl[5]), sz, pz);
+  }
+  const float tx1 = (ax - rox) * rix, tx2 = (bx - rox) * rix;
+  const float ty1 = (ay - roy) * riy, ty2 = (by - roy) * riy;
+  const float tz1 = (az - roz) * riz, tz2 = (bz - roz) * riz;
+  if (EXACT || LDEXP) return slab_interval<EXACT>(tx1, tx2, ty1, ty2, tz1, tz2);
+  const float tmin = fmaxf(fmaxf(tx1, ty1), tz1);   // pl[0..2] already hold the near planes
+  const float tmax = fminf(fminf(tx2, ty2), tz2);
+  return (tmax < tmin || tmax <= 0) ? RT_LARGE_FLOAT : tmin;
+}
+
+// Box tests of the <=4 children of an internal node.
 template <bool EXACT, bool LDEXP>
 __device__ __forceinline__ void eval_children(const uint4* __restrict__ np, bool is_tlas,
                                               float rox, float roy, float roz, float rix, float riy, float riz,
@@ -161,32 +198,27 @@ __device__ __forceinline__ void eval_children(const uint4* __restrict__ np, bool
   const float px = __uint_as_float(q0.x), py = __uint_as_float(q0.y), pz = __uint_as_float(q0.z);
   const int ex = (int)(int8_t)(q0.w & 0xff), ey = (int)(int8_t)((q0.w >> 8) & 0xff), ez = (int)(int8_t)((q0.w >> 16) & 0xff);
   const uint32_t kinds = q0.w >> 24, leftFirst = q1.x;
-  const uint32_t qb[6] = {q1.y, q1.z, q1.w, q2.x, q2.y, q2.z};
+  uint32_t pl[6] = {q1.y, q1.z, q1.w, q2.x, q2.y, q2.z};
+  if (!EXACT && !LDEXP) {
+    const bool nx = rix < 0, ny = riy < 0, nz = riz < 0;
+    pl[0] = nx ? q2.x : q1.y; pl[3] = nx ? q1.y : q2.x;
+    pl[1] = ny ? q2.y : q1.z; pl[4] = ny ? q1.z : q2.y;
+    pl[2] = nz ? q2.z : q1.w; pl[5] = nz ? q1.w : q2.z;
+  }
   const uint32_t pay[4] = {q2.w, q3.x, q3.y, q3.z};
   const float sx = ldexpf(1.0f, ex), sy = ldexpf(1.0f, ey), sz = ldexpf(1.0f, ez);
   const uint32_t node_kind = is_tlas ? DK_TLAS : DK_BLAS;
+  float d[4];
+  d[0] = child_box<0, EXACT, LDEXP>(pl, px, py, pz, sx, sy, sz, ex, ey, ez, rox, roy, roz, rix, riy, riz);
+  d[1] = child_box<1, EXACT, LDEXP>(pl, px, py, pz, sx, sy, sz, ex, ey, ez, rox, roy, roz, rix, riy, riz);
+  d[2] = child_box<2, EXACT, LDEXP>(pl, px, py, pz, sx, sy, sz, ex, ey, ez, rox, roy, roz, rix, riy, riz);
+  d[3] = child_box<3, EXACT, LDEXP>(pl, px, py, pz, sx, sy, sz, ex, ey, ez, rox, roy, roz, rix, riy, riz);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int b = 6 * k;
-    float mnx, mny, mnz, mxx, mxy, mxz;
-    if (LDEXP) {
-      mnx = px + ldexpf(qbyte(qb, b + 0), ex); mny = py + ldexpf(qbyte(qb, b + 1), ey); mnz = pz + ldexpf(qbyte(qb, b + 2), ez);
-      mxx = px + ldexpf(qbyte(qb, b + 3), ex); mxy = py + ldexpf(qbyte(qb, b + 4), ey); mxz = pz + ldexpf(qbyte(qb, b + 5), ez);
-    } else {
-      mnx = __fmaf_rn(qbyte(qb, b + 0), sx, px); mny = __fmaf_rn(qbyte(qb, b + 1), sy, py); mnz = __fmaf_rn(qbyte(qb, b + 2), sz, pz);
-      mxx = __fmaf_rn(qbyte(qb, b + 3), sx, px); mxy = __fmaf_rn(qbyte(qb, b + 4), sy, py); mxz = __fmaf_rn(qbyte(qb, b + 5), sz, pz);
-    }
-    const float d = ray_box<EXACT>(rox, roy, roz, rix, riy, riz, mnx, mny, mnz, mxx, mxy, mxz);
     const uint32_t ck = (kinds >> (2 * k)) & 3u;
-    const bool ok = (ck != 0u) && (d < hit_dist);     // :60, :71
-    c[k].d = ok ? d : __builtin_inff();
+    const bool ok = (ck != 0u) && (d[k] < hit_dist);     // :60, :71
+    c[k].d = ok ? d[k] : __builtin_inff();
     c[k].desc = ck == 1u ? DESC(node_kind, leftFirst + (uint32_t)k) : DESC(ck, pay[k]);   // ck 2 -> leaf, 3 -> instance
-    c[k].idx = (uint32_t)k;
-#if RT_SERIAL_CHILDREN
-    // keep the four box tests from being interleaved: their ~12 temporaries each would otherwise be
-    // live together and cost a wave of occupancy (other waves, not ILP, hide the latency here)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
   }
 }
 
@@ -311,9 +343,6 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 6
 #endif
-#ifndef RT_SERIAL_CHILDREN
-#define RT_SERIAL_CHILDREN 1
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // Persistent traversal kernel.
@@ -373,7 +402,7 @@ struct PersistArgs {
   // the main launch: their job id (bit 31 = occlusion phase) is appended here and a second, small
   // launch of the EXACT variant (libstdc++ min/max forms) traces them
   uint32_t* defer_count; uint32_t* defer_list; uint32_t defer_cap;
-  unsigned long long* wave_log;   // STATS only, optional: per wavefront {first clock, last clock, rays started} (100 MHz)
+  unsigned long long* wave_log;   // STATS only, optional: per wavefront {first clock, last clock, rays started, iterations, node-body runs, lanes in them, leaf-body runs, lanes in them, node-body runs where no lane's node has a 3rd/4th child, ... a 4th child}
 };
 
 __device__ __forceinline__ bool is_node_desc(uint32_t d) { return d < 0x80000000u; }
@@ -425,6 +454,7 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
   Fetches fx;
   unsigned nrays = 0, nhit = 0;
   unsigned long long t_first = 0;
+  unsigned wl_no23 = 0, wl_no3 = 0, wl_iter = 0, wl_node_x = 0, wl_node_l = 0, wl_leaf_x = 0, wl_leaf_l = 0;   // wave_log: lane occupancy of the two bodies
   if (STATS && A.wave_log) t_first = wall_clock64();
 
   auto pixel_of = [&](uint32_t r, uint32_t& x, uint32_t& y) {
@@ -475,7 +505,7 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
     const float cdy = m10 * dx + m11 * dy + m12 * dz;
     const float cdz = m20 * dx + m21 * dy + m22 * dz;
     aix = 1.0f / cdx; aiy = 1.0f / cdy; aiz = 1.0f / cdz;
-    const bool s2 = (aix - aix == 0.0f) && (aiy - aiy == 0.0f) && (aiz - aiz == 0.0f) &&
+    const bool s2 = (aix - aix == 0.0f) && (aiy - aiy == 0.0f) && (aiz - aiz == 0.0f) && aix != 0.0f && aiy != 0.0f && aiz != 0.0f &&
                     (arx - arx == 0.0f) && (ary - ary == 0.0f) && (arz - arz == 0.0f);
     if (!EXACT && !s2) { defer(); return; }   // object-space ray can produce NaN slabs: restart it in the EXACT launch
     flags &= ~F_WORLD;
@@ -487,8 +517,8 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
   auto start_ray = [&](float ox, float oy, float oz, float dx, float dy, float dz, float tmax_, bool any_) {
     arx = ox; ary = oy; arz = oz;
     aix = 1.0f / dx; aiy = 1.0f / dy; aiz = 1.0f / dz;
-    // v_min/v_max slabs are exact only if no slab product can be NaN
-    const bool safe = (aix - aix == 0.0f) && (aiy - aiy == 0.0f) && (aiz - aiz == 0.0f) &&
+    // the fast slab forms are exact only if no slab product can be NaN (finite non-zero 1/d, finite origin)
+    const bool safe = (aix - aix == 0.0f) && (aiy - aiy == 0.0f) && (aiz - aiz == 0.0f) && aix != 0.0f && aiy != 0.0f && aiz != 0.0f &&
                       (ox - ox == 0.0f) && (oy - oy == 0.0f) && (oz - oz == 0.0f);
     flags = (flags & F_SHADOW) | F_WORLD | (any_ ? F_ANYHIT : 0u);
     if (!EXACT && !safe) {
@@ -581,6 +611,17 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
 
     // ================= traverse: one step of whatever each lane holds, per iteration =================
     for (;;) {
+      if (STATS && A.wave_log) {
+        const unsigned long long nm = __ballot(is_node_desc(cur));
+        ++wl_iter;
+        if (nm) {
+          ++wl_node_x; wl_node_l += (unsigned)__popcll(nm);
+          uint32_t kinds_ = 0;
+          if (is_node_desc(cur)) kinds_ = (((cur >> 30) == DK_TLAS ? sc.tlas_c : sc.bvh_c) + (size_t)(cur & PAYLOAD_MASK) * CNODE_VEC4)[0].w >> 24;
+          if (__ballot((kinds_ >> 4) != 0u) == 0ull) ++wl_no23;
+          if (__ballot((kinds_ >> 6) != 0u) == 0ull) ++wl_no3;
+        }
+      }
       if (is_node_desc(cur)) {
         // ---- internal node: 4 box tests, order, push the far ones, continue with the nearest ----
         const bool top = (cur >> 30) == DK_TLAS;
@@ -613,7 +654,7 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
             pop_next();
           }
         } else {
-          cmpx(c[0], c[1]); cmpx(c[2], c[3]); cmpx(c[0], c[2]); cmpx(c[1], c[3]); cmpx(c[1], c[2]);
+          order_children(c);
           if (n > 0) {
             if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
             // far first so that the nearest pending sibling is on top (:98-103)
@@ -639,6 +680,7 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
       const unsigned long long leafm = __ballot(is_leaf_desc(cur));
       if (leafm != 0ull && ((uint32_t)__popcll(leafm) >= (JOB == JOB_TRACE ? RT_TRACE_LEAF_MIN : RT_LEAF_MIN) || __ballot(is_node_desc(cur) || is_inst_desc(cur)) == 0ull)) {
         // ---- BLAS leaf (:123-161): triangles in index order, strict '<' ----
+        if (STATS && A.wave_log) { ++wl_leaf_x; wl_leaf_l += (unsigned)__popcll(leafm); }
         if (is_leaf_desc(cur)) {
           if (STATS) fx.node++;
           uint32_t leftFirst = cur & LEAF_FIRST_MASK, triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
@@ -722,8 +764,9 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
     unsigned s = nrays;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if (lane == 0) {
-      unsigned long long* w = A.wave_log + 3ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
-      w[0] = t_first; w[1] = wall_clock64(); w[2] = s;
+      unsigned long long* w = A.wave_log + 10ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+      w[0] = t_first; w[1] = wall_clock64(); w[2] = s; w[8] = wl_no23; w[9] = wl_no3;
+      w[3] = wl_iter; w[4] = wl_node_x; w[5] = wl_node_l; w[6] = wl_leaf_x; w[7] = wl_leaf_l;
     }
   }
   if (A.counters) {
@@ -805,8 +848,10 @@ __global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_
   uint8_t qb[24];
   for (int k = 0; k < 4; ++k) {
     const uint8_t* c = bytes + 24 + 7 * k;
-    for (int j = 0; j < 6; ++j) qb[6 * k + j] = c[1 + j];
+    for (int j = 0; j < 6; ++j) qb[4 * j + k] = c[1 + j];   // plane-major: word j = plane j (lo xyz, hi xyz) of the four children
     if (c[0] == 0) continue;   // meta (rt_traversal.cpp:60)
+    // the sign-selected slab form needs lo <= hi per axis (child_box); an inverted box falls back to min/max
+    if (c[1] > c[4] || c[2] > c[5] || c[3] > c[6]) atomicOr(status, STATUS_FMA_DECODE_DIFFERS);
     // fma decode must reproduce origin + ldexp(float(q), e) bit for bit (eval_children)
     for (int j = 0; j < 6; ++j) {
       const float q = (float)c[1 + j];
@@ -1228,8 +1273,8 @@ int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
 }
 
 // diagnostic: vxrt_render_stats that also logs, per wavefront of the main traversal launch, the first
-// and last 100 MHz clock and the number of rays it started (wave_log: device u64[3 * waves], waves =
-// 4 * blocks of the launch; 3 * 4 * 8 * 256 entries are always enough)
+// and last 100 MHz clock and the number of rays it started (wave_log: device u64[10 * waves], waves =
+// 4 * blocks of the launch; 10 * 4 * 8 * 256 entries are always enough)
 int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                          unsigned long long* counters, unsigned long long* wave_log, void* stream) {
