@@ -55,6 +55,7 @@
 #define DESC(kind, payload) (((kind) << 30) | (payload))
 #define DESC_DONE 0xFFFFFFFEu   // traversal of the lane's ray has ended
 #define DESC_IDLE 0xFFFFFFFDu   // lane has no ray
+#define DESC_NONE 0xFFFFFFFFu   // compact node: empty child slot
 #define PAYLOAD_MASK 0x3FFFFFFFu
 #define LEAF_FIRST_BITS 26
 #define LEAF_FIRST_MASK 0x03FFFFFFu
@@ -191,23 +192,21 @@ __device__ __forceinline__ float child_box(const uint32_t* pl, float px, float p
 
 // Box tests of the <=4 children of an internal node.
 template <bool EXACT, bool LDEXP>
-__device__ __forceinline__ void eval_children(const uint4* __restrict__ np, bool is_tlas,
+__device__ __forceinline__ void eval_children(const uint4* __restrict__ np,
                                               float rox, float roy, float roz, float rix, float riy, float riz,
                                               float hit_dist, Cand* c) {
   const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
   const float px = __uint_as_float(q0.x), py = __uint_as_float(q0.y), pz = __uint_as_float(q0.z);
   const int ex = (int)(int8_t)(q0.w & 0xff), ey = (int)(int8_t)((q0.w >> 8) & 0xff), ez = (int)(int8_t)((q0.w >> 16) & 0xff);
-  const uint32_t kinds = q0.w >> 24, leftFirst = q1.x;
-  uint32_t pl[6] = {q1.y, q1.z, q1.w, q2.x, q2.y, q2.z};
+  uint32_t pl[6] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
   if (!EXACT && !LDEXP) {
     const bool nx = rix < 0, ny = riy < 0, nz = riz < 0;
-    pl[0] = nx ? q2.x : q1.y; pl[3] = nx ? q1.y : q2.x;
-    pl[1] = ny ? q2.y : q1.z; pl[4] = ny ? q1.z : q2.y;
-    pl[2] = nz ? q2.z : q1.w; pl[5] = nz ? q1.w : q2.z;
+    pl[0] = nx ? q1.w : q1.x; pl[3] = nx ? q1.x : q1.w;
+    pl[1] = ny ? q2.x : q1.y; pl[4] = ny ? q1.y : q2.x;
+    pl[2] = nz ? q2.y : q1.z; pl[5] = nz ? q1.z : q2.y;
   }
-  const uint32_t pay[4] = {q2.w, q3.x, q3.y, q3.z};
+  const uint32_t desc[4] = {q2.z, q2.w, q3.x, q3.y};   // complete work descriptors, DESC_NONE for an empty slot (:60)
   const float sx = ldexpf(1.0f, ex), sy = ldexpf(1.0f, ey), sz = ldexpf(1.0f, ez);
-  const uint32_t node_kind = is_tlas ? DK_TLAS : DK_BLAS;
   float d[4];
   d[0] = child_box<0, EXACT, LDEXP>(pl, px, py, pz, sx, sy, sz, ex, ey, ez, rox, roy, roz, rix, riy, riz);
   d[1] = child_box<1, EXACT, LDEXP>(pl, px, py, pz, sx, sy, sz, ex, ey, ez, rox, roy, roz, rix, riy, riz);
@@ -215,10 +214,9 @@ __device__ __forceinline__ void eval_children(const uint4* __restrict__ np, bool
   d[3] = child_box<3, EXACT, LDEXP>(pl, px, py, pz, sx, sy, sz, ex, ey, ez, rox, roy, roz, rix, riy, riz);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const uint32_t ck = (kinds >> (2 * k)) & 3u;
-    const bool ok = (ck != 0u) && (d[k] < hit_dist);     // :60, :71
+    const bool ok = (desc[k] != DESC_NONE) && (d[k] < hit_dist);     // :60, :71
     c[k].d = ok ? d[k] : __builtin_inff();
-    c[k].desc = ck == 1u ? DESC(node_kind, leftFirst + (uint32_t)k) : DESC(ck, pay[k]);   // ck 2 -> leaf, 3 -> instance
+    c[k].desc = desc[k];
   }
 }
 
@@ -634,18 +632,18 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
         const uint4* np = (top ? sc.tlas_c : sc.bvh_c) + (size_t)(cur & PAYLOAD_MASK) * CNODE_VEC4;
         if (STATS) fx.node++;
         Cand c[4];
-        eval_children<EXACT, LDEXP>(np, top, arx, ary, arz, aix, aiy, aiz, hitd, c);
-        int n = (c[0].d < __builtin_inff()) + (c[1].d < __builtin_inff()) + (c[2].d < __builtin_inff()) + (c[3].d < __builtin_inff());
+        eval_children<EXACT, LDEXP>(np, arx, ary, arz, aix, aiy, aiz, hitd, c);
         if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && !STATS && __all((flags & F_ANYHIT) != 0u)) {   // STATS keeps the reference's order, hence its fetch counts
           // occlusion rays of a frame only feed a boolean (is anything hit before the light?): the set
           // of triangles an any-hit traversal can reach does not depend on the visiting order, so the
           // ordering network and the path_m bookkeeping are skipped (vxrt_trace's MODE_ANY, which
           // returns the reference's FIRST accepted candidate, keeps the ordered path)
           const bool v0 = c[0].d < __builtin_inff(), v1 = c[1].d < __builtin_inff(), v2 = c[2].d < __builtin_inff(), v3 = c[3].d < __builtin_inff();
-          if (n > 0) {
-            if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
+          if (v0 || v1 || v2 || v3) {
+            bool more = true;
+            if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
             cur = v0 ? c[0].desc : (v1 ? c[1].desc : (v2 ? c[2].desc : c[3].desc));
-            if (n > 1) {
+            if (more) {
               if (v1 && v0) push(c[1].desc, c[1].d);
               if (v2 && (v0 || v1)) push(c[2].desc, c[2].d);
               if (v3 && (v0 || v1 || v2)) push(c[3].desc, c[3].d);
@@ -654,13 +652,14 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
             pop_next();
           }
         } else {
-          order_children(c);
-          if (n > 0) {
-            if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); n = 1; }
+          order_children(c);   // valid children first (d < inf), nearest in c[0]
+          if (c[0].d < __builtin_inff()) {
+            bool more = true;
+            if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
             // far first so that the nearest pending sibling is on top (:98-103)
-            if (n > 3) push(c[3].desc, fmaxf(path_m, c[3].d));
-            if (n > 2) push(c[2].desc, fmaxf(path_m, c[2].d));
-            if (n > 1) push(c[1].desc, fmaxf(path_m, c[1].d));
+            if (more && c[3].d < __builtin_inff()) push(c[3].desc, fmaxf(path_m, c[3].d));
+            if (more && c[2].d < __builtin_inff()) push(c[2].desc, fmaxf(path_m, c[2].d));
+            if (more && c[1].d < __builtin_inff()) push(c[1].desc, fmaxf(path_m, c[1].d));
             cur = c[0].desc;
             path_m = fmaxf(path_m, c[0].d);
           } else {
@@ -844,7 +843,7 @@ __global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_
   const float po[3] = {px, py, pz};
   const int ev[3] = {(int)(int8_t)(w[3] & 0xff), (int)(int8_t)((w[3] >> 8) & 0xff), (int)(int8_t)((w[3] >> 16) & 0xff)};
   const uint8_t* bytes = (const uint8_t*)w;
-  uint32_t kinds = 0, pay[4] = {0, 0, 0, 0};
+  uint32_t kinds = 0, pay[4] = {DESC_NONE, DESC_NONE, DESC_NONE, DESC_NONE};   // complete descriptors of the children
   uint8_t qb[24];
   for (int k = 0; k < 4; ++k) {
     const uint8_t* c = bytes + 24 + 7 * k;
@@ -870,15 +869,15 @@ __global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_
     if (is_tlas) {
       if (c_ld != 0xffffffffu) {
         if (c_ld >= n_blas || c_ld >= 0x3FFFFFF0u) { atomicOr(status, STATUS_BAD_SCENE); continue; }
-        kinds |= 3u << (2 * k); pay[k] = c_ld;
-      } else kinds |= 1u << (2 * k);
+        kinds |= 3u << (2 * k); pay[k] = DESC(DK_INST, c_ld);
+      } else { kinds |= 1u << (2 * k); pay[k] = DESC(DK_TLAS, ci); }
     } else {
       if (c_ld != 0u) {
         if ((uint64_t)c_lf + c_ld > n_tris) { atomicOr(status, STATUS_BAD_SCENE); continue; }
         kinds |= 2u << (2 * k);
-        pay[k] = (c_ld <= LEAF_MAX_INLINE && c_lf <= LEAF_FIRST_MASK) ? ((c_ld << LEAF_FIRST_BITS) | c_lf) : ci;   // else by reference
-        if (!(c_ld <= LEAF_MAX_INLINE && c_lf <= LEAF_FIRST_MASK) && ci > LEAF_FIRST_MASK) atomicOr(status, STATUS_BAD_SCENE);
-      } else kinds |= 1u << (2 * k);
+        pay[k] = DESC(DK_LEAF, (c_ld <= LEAF_MAX_INLINE && c_lf <= LEAF_FIRST_MASK) ? ((c_ld << LEAF_FIRST_BITS) | c_lf) : ci);   // else by reference
+        if (!(c_ld <= LEAF_MAX_INLINE && c_lf <= LEAF_FIRST_MASK) && ci > LEAF_FIRST_MASK) { atomicOr(status, STATUS_BAD_SCENE); pay[k] = DESC_NONE; }
+      } else { kinds |= 1u << (2 * k); pay[k] = DESC(DK_BLAS, ci); }
     }
   }
   const uint64_t first64 = (uint64_t)base + leftFirst;
@@ -886,9 +885,9 @@ __global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_
   for (int v = 0; v < 6; ++v) qw[v] = (uint32_t)qb[4 * v] | ((uint32_t)qb[4 * v + 1] << 8) | ((uint32_t)qb[4 * v + 2] << 16) | ((uint32_t)qb[4 * v + 3] << 24);
   uint4* o = out + (size_t)i * CNODE_VEC4;
   o[0] = make_uint4(w[0], w[1], w[2], (w[3] & 0x00ffffffu) | (kinds << 24));
-  o[1] = make_uint4((uint32_t)first64, qw[0], qw[1], qw[2]);
-  o[2] = make_uint4(qw[3], qw[4], qw[5], pay[0]);
-  o[3] = make_uint4(pay[1], pay[2], pay[3], 0u);
+  o[1] = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+  o[2] = make_uint4(qw[4], qw[5], pay[0], pay[1]);
+  o[3] = make_uint4(pay[2], pay[3], (uint32_t)first64, 0u);
 }
 
 __global__ void accel_tris_kernel(const float* __restrict__ tri, uint32_t n, float4* __restrict__ out) {
