@@ -64,8 +64,9 @@
 #define WTRI_FLOATS 12
 
 struct SceneDev {
-  const uint4* tlas_c;       // compact TLAS nodes
-  const uint4* bvh_c;        // compact BLAS nodes
+  const uint4* nodes_c;      // compact nodes: the TLAS nodes, then the BLAS nodes (one index space, no per-lane base select)
+  const uint32_t* ref_tlas;  // reference TLAS nodes (13 dwords each): exponents for the ldexp decode
+  uint32_t n_tlas;           // compact index of BLAS node j = n_tlas + j
   const float4* tri_w;       // wide triangles
   const uint32_t* blas_root; // per instance record: descriptor of its BLAS root
   uint32_t tlas_root;        // descriptor of the TLAS root
@@ -192,12 +193,18 @@ __device__ __forceinline__ float child_box(const uint32_t* pl, float px, float p
 
 // Box tests of the <=4 children of an internal node.
 template <bool EXACT, bool LDEXP>
-__device__ __forceinline__ void eval_children(const uint4* __restrict__ np,
+__device__ __forceinline__ void eval_children(const uint4* __restrict__ np, const uint32_t* __restrict__ ref_node,
                                               float rox, float roy, float roz, float rix, float riy, float riz,
                                               float hit_dist, Cand* c) {
   const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
   const float px = __uint_as_float(q0.x), py = __uint_as_float(q0.y), pz = __uint_as_float(q0.z);
-  const int ex = (int)(int8_t)(q0.w & 0xff), ey = (int)(int8_t)((q0.w >> 8) & 0xff), ez = (int)(int8_t)((q0.w >> 16) & 0xff);
+  // plane scales 2^e as floats (fma decode); the ldexp decode takes the exponents from the reference node
+  const float sx = __uint_as_float(q0.w), sy = __uint_as_float(q3.z), sz = __uint_as_float(q3.w);
+  int ex = 0, ey = 0, ez = 0;
+  if (LDEXP) {
+    const uint32_t ew = ref_node[3];
+    ex = (int)(int8_t)(ew & 0xff); ey = (int)(int8_t)((ew >> 8) & 0xff); ez = (int)(int8_t)((ew >> 16) & 0xff);
+  }
   uint32_t pl[6] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
   if (!EXACT && !LDEXP) {
     const bool nx = rix < 0, ny = riy < 0, nz = riz < 0;
@@ -206,7 +213,6 @@ __device__ __forceinline__ void eval_children(const uint4* __restrict__ np,
     pl[2] = nz ? q2.y : q1.z; pl[5] = nz ? q1.z : q2.y;
   }
   const uint32_t desc[4] = {q2.z, q2.w, q3.x, q3.y};   // complete work descriptors, DESC_NONE for an empty slot (:60)
-  const float sx = ldexpf(1.0f, ex), sy = ldexpf(1.0f, ey), sz = ldexpf(1.0f, ez);
   float d[4];
   d[0] = child_box<0, EXACT, LDEXP>(pl, px, py, pz, sx, sy, sz, ex, ey, ez, rox, roy, roz, rix, riy, riz);
   d[1] = child_box<1, EXACT, LDEXP>(pl, px, py, pz, sx, sy, sz, ex, ey, ez, rox, roy, roz, rix, riy, riz);
@@ -615,7 +621,10 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
         if (nm) {
           ++wl_node_x; wl_node_l += (unsigned)__popcll(nm);
           uint32_t kinds_ = 0;
-          if (is_node_desc(cur)) kinds_ = (((cur >> 30) == DK_TLAS ? sc.tlas_c : sc.bvh_c) + (size_t)(cur & PAYLOAD_MASK) * CNODE_VEC4)[0].w >> 24;
+          if (is_node_desc(cur)) {
+            const uint4* np_ = sc.nodes_c + (size_t)(cur & PAYLOAD_MASK) * CNODE_VEC4;
+            kinds_ = (np_[2].w != DESC_NONE ? 4u : 0u) | (np_[3].x != DESC_NONE ? 16u : 0u) | (np_[3].y != DESC_NONE ? 64u : 0u);
+          }
           if (__ballot((kinds_ >> 4) != 0u) == 0ull) ++wl_no23;
           if (__ballot((kinds_ >> 6) != 0u) == 0ull) ++wl_no3;
         }
@@ -629,10 +638,13 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
           arx = ox; ary = oy; arz = oz; aix = 1.0f / dx; aiy = 1.0f / dy; aiz = 1.0f / dz;
           flags |= F_WORLD;
         }
-        const uint4* np = (top ? sc.tlas_c : sc.bvh_c) + (size_t)(cur & PAYLOAD_MASK) * CNODE_VEC4;
+        const uint32_t ni = cur & PAYLOAD_MASK;
+        const uint4* np = sc.nodes_c + (size_t)ni * CNODE_VEC4;
+        const uint32_t* ref_node = nullptr;
+        if (LDEXP) ref_node = top ? sc.ref_tlas + (size_t)ni * RT_NODE_DWORDS : sc.ref_bvh + (size_t)(ni - sc.n_tlas) * RT_NODE_DWORDS;
         if (STATS) fx.node++;
         Cand c[4];
-        eval_children<EXACT, LDEXP>(np, arx, ary, arz, aix, aiy, aiz, hitd, c);
+        eval_children<EXACT, LDEXP>(np, ref_node, arx, ary, arz, aix, aiy, aiz, hitd, c);
         if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && !STATS && __all((flags & F_ANYHIT) != 0u)) {   // STATS keeps the reference's order, hence its fetch counts
           // occlusion rays of a frame only feed a boolean (is anything hit before the light?): the set
           // of triangles an any-hit traversal can reach does not depend on the visiting order, so the
@@ -825,7 +837,8 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
 // one thread per reference node of one buffer.  bases/ends: sorted BLAS node ranges (nb of them).
 __global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_nodes, uint4* __restrict__ out, int is_tlas,
                                    const uint32_t* __restrict__ bases, const uint32_t* __restrict__ ends, uint32_t nb,
-                                   uint32_t n_tris, uint32_t n_blas, uint32_t* status) {
+                                   uint32_t n_tris, uint32_t n_blas, uint32_t bias, uint32_t* status) {
+  // bias: compact index of this buffer's node 0 (0 for the TLAS pass, n_tlas for the BLAS pass); `out` is already offset by it
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   const uint32_t* w = ref + (size_t)i * RT_NODE_DWORDS;
@@ -861,7 +874,7 @@ __global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_
     const uint64_t ci64 = (uint64_t)base + leftFirst + (uint32_t)k;   // calcNodePtr(base_ptr, leftFirst + childIdx), :91-92
     // children are allocated after their parent by the builders (bvh.cpp:94-97, 371-402): requiring
     // that makes every accepted tree acyclic, so traversal terminates
-    if (ci64 >= end || ci64 <= i || ci64 > PAYLOAD_MASK) { atomicOr(status, STATUS_BAD_SCENE); continue; }
+    if (ci64 >= end || ci64 <= i || ci64 + bias > PAYLOAD_MASK) { atomicOr(status, STATUS_BAD_SCENE); continue; }
     const uint32_t ci = (uint32_t)ci64;
     const uint32_t* cw = ref + (size_t)ci * RT_NODE_DWORDS;
     const uint32_t c_imask = cw[3] >> 24, c_lf = cw[4], c_ld = cw[5];
@@ -870,24 +883,24 @@ __global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_
       if (c_ld != 0xffffffffu) {
         if (c_ld >= n_blas || c_ld >= 0x3FFFFFF0u) { atomicOr(status, STATUS_BAD_SCENE); continue; }
         kinds |= 3u << (2 * k); pay[k] = DESC(DK_INST, c_ld);
-      } else { kinds |= 1u << (2 * k); pay[k] = DESC(DK_TLAS, ci); }
+      } else { kinds |= 1u << (2 * k); pay[k] = DESC(DK_TLAS, ci + bias); }
     } else {
       if (c_ld != 0u) {
         if ((uint64_t)c_lf + c_ld > n_tris) { atomicOr(status, STATUS_BAD_SCENE); continue; }
         kinds |= 2u << (2 * k);
         pay[k] = DESC(DK_LEAF, (c_ld <= LEAF_MAX_INLINE && c_lf <= LEAF_FIRST_MASK) ? ((c_ld << LEAF_FIRST_BITS) | c_lf) : ci);   // else by reference
         if (!(c_ld <= LEAF_MAX_INLINE && c_lf <= LEAF_FIRST_MASK) && ci > LEAF_FIRST_MASK) { atomicOr(status, STATUS_BAD_SCENE); pay[k] = DESC_NONE; }
-      } else { kinds |= 1u << (2 * k); pay[k] = DESC(DK_BLAS, ci); }
+      } else { kinds |= 1u << (2 * k); pay[k] = DESC(DK_BLAS, ci + bias); }
     }
   }
-  const uint64_t first64 = (uint64_t)base + leftFirst;
   uint32_t qw[6];
   for (int v = 0; v < 6; ++v) qw[v] = (uint32_t)qb[4 * v] | ((uint32_t)qb[4 * v + 1] << 8) | ((uint32_t)qb[4 * v + 2] << 16) | ((uint32_t)qb[4 * v + 3] << 24);
   uint4* o = out + (size_t)i * CNODE_VEC4;
-  o[0] = make_uint4(w[0], w[1], w[2], (w[3] & 0x00ffffffu) | (kinds << 24));
+  (void)kinds;
+  o[0] = make_uint4(w[0], w[1], w[2], __float_as_uint(ldexpf(1.0f, ev[0])));
   o[1] = make_uint4(qw[0], qw[1], qw[2], qw[3]);
   o[2] = make_uint4(qw[4], qw[5], pay[0], pay[1]);
-  o[3] = make_uint4(pay[2], pay[3], (uint32_t)first64, 0u);
+  o[3] = make_uint4(pay[2], pay[3], __float_as_uint(ldexpf(1.0f, ev[1])), __float_as_uint(ldexpf(1.0f, ev[2])));
 }
 
 __global__ void accel_tris_kernel(const float* __restrict__ tri, uint32_t n, float4* __restrict__ out) {
@@ -913,7 +926,7 @@ __global__ void accel_roots_kernel(const uint32_t* __restrict__ tlas, const uint
     else if (ld != 0xffffffffu) {
       if (ld >= n_blas || ld >= 0x3FFFFFF0u) atomicOr(status, STATUS_BAD_SCENE);
       else *tlas_root = DESC(DK_INST, ld);
-    } else *tlas_root = DESC(DK_TLAS, 0u);
+    } else *tlas_root = DESC(DK_TLAS, 0u);   // compact index 0
   } else if (t - 1 < n_blas) {
     const uint32_t j = t - 1;
     const uint32_t off = blas[(size_t)j * (RT_BLAS_STRIDE / 4)];
@@ -925,7 +938,8 @@ __global__ void accel_roots_kernel(const uint32_t* __restrict__ tlas, const uint
     else if (ld != 0u) {
       if ((uint64_t)lf + ld > n_tris) atomicOr(status, STATUS_BAD_SCENE);
       else blas_root[j] = DESC(DK_LEAF, (ld <= LEAF_MAX_INLINE && lf <= LEAF_FIRST_MASK) ? ((ld << LEAF_FIRST_BITS) | lf) : off);
-    } else blas_root[j] = DESC(DK_BLAS, off);
+    } else if ((uint64_t)off + n_tlas > PAYLOAD_MASK) atomicOr(status, STATUS_BAD_SCENE);
+    else blas_root[j] = DESC(DK_BLAS, off + n_tlas);
   }
 }
 
@@ -999,7 +1013,7 @@ struct FrameCtx {
 struct vxrt_accel {
   SceneDev dev{};
   vxrt_scene_t ref{};
-  void* tlas_c = nullptr; void* bvh_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr;
+  void* nodes_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr;
   FrameCtx ctx[MAX_FRAMES_IN_FLIGHT];
   uint32_t n_ctx = 1, next_ctx = 0;
   float* uvtab = nullptr;      // camera tables: u[W] then v[H]
@@ -1015,7 +1029,7 @@ struct vxrt_accel {
 static void accel_free(vxrt_accel* a) {
   if (!a) return;
   (void)hipDeviceSynchronize();
-  (void)hipFree(a->tlas_c); (void)hipFree(a->bvh_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
+  (void)hipFree(a->nodes_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
   (void)hipFree(a->uvtab); (void)hipFree(a->apriori);
   for (FrameCtx& c : a->ctx) {
     (void)hipFree(c.hitbuf); (void)hipFree(c.defer);
@@ -1053,7 +1067,7 @@ const char* vxrt_version(void) { return "vortex-rt-mi355x 0.3 (gfx950, compact 6
 int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   if (!s || !out || !s->tlas || !s->blas || !s->bvh || !s->tri) return -1;
   if (s->n_tlas_nodes == 0 || s->n_blas == 0 || s->n_bvh_nodes == 0 || s->n_tris == 0) return -1;
-  if (s->n_tlas_nodes > PAYLOAD_MASK || s->n_bvh_nodes > PAYLOAD_MASK || s->n_tris >= 0x7fffffffu) return -1;
+  if ((uint64_t)s->n_tlas_nodes + s->n_bvh_nodes > PAYLOAD_MASK || s->n_tris >= 0x7fffffffu) return -1;   // one compact index space
   hipStream_t st = (hipStream_t)stream;
   // instance node ranges (host side, n_blas is small): sorted unique bvh_offsets
   std::vector<uint32_t> recs((size_t)s->n_blas * (RT_BLAS_STRIDE / 4));
@@ -1077,8 +1091,7 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   uint32_t* d_ranges = nullptr;
   uint32_t* d_status = nullptr;
   uint32_t* d_troot = nullptr;
-  bool ok = hipMalloc(&a->tlas_c, (size_t)s->n_tlas_nodes * CNODE_VEC4 * 16) == hipSuccess &&
-            hipMalloc(&a->bvh_c, (size_t)s->n_bvh_nodes * CNODE_VEC4 * 16) == hipSuccess &&
+  bool ok = hipMalloc(&a->nodes_c, ((size_t)s->n_tlas_nodes + s->n_bvh_nodes) * CNODE_VEC4 * 16) == hipSuccess &&
             hipMalloc(&a->tri_w, (size_t)s->n_tris * WTRI_FLOATS * 4) == hipSuccess &&
             hipMalloc(&a->blas_root, (size_t)s->n_blas * sizeof(uint32_t)) == hipSuccess &&
             hipMalloc((void**)&d_ranges, bases.size() * 8) == hipSuccess &&
@@ -1092,9 +1105,9 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   if (ok) {
     const uint32_t nb = (uint32_t)bases.size();
     hipLaunchKernelGGL(accel_nodes_kernel, dim3((s->n_tlas_nodes + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->tlas, s->n_tlas_nodes,
-                       (uint4*)a->tlas_c, 1, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, s->n_tris, s->n_blas, d_status);
+                       (uint4*)a->nodes_c, 1, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, s->n_tris, s->n_blas, 0u, d_status);
     hipLaunchKernelGGL(accel_nodes_kernel, dim3((s->n_bvh_nodes + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->bvh, s->n_bvh_nodes,
-                       (uint4*)a->bvh_c, 0, d_ranges, d_ranges + nb, nb, s->n_tris, s->n_blas, d_status);
+                       (uint4*)a->nodes_c + (size_t)s->n_tlas_nodes * CNODE_VEC4, 0, d_ranges, d_ranges + nb, nb, s->n_tris, s->n_blas, s->n_tlas_nodes, d_status);
     hipLaunchKernelGGL(accel_tris_kernel, dim3((s->n_tris + 255) / 256), dim3(256), 0, st, (const float*)s->tri, s->n_tris, (float4*)a->tri_w);
     hipLaunchKernelGGL(accel_roots_kernel, dim3((s->n_blas + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->tlas, (const uint32_t*)s->bvh,
                        (const uint32_t*)s->blas, s->n_tlas_nodes, s->n_bvh_nodes, s->n_blas, s->n_tris, d_troot, (uint32_t*)a->blas_root, d_status);
@@ -1104,7 +1117,7 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   }
   (void)hipFree(d_ranges); (void)hipFree(d_status); (void)hipFree(d_troot);
   if (!ok || (hstatus & STATUS_BAD_SCENE) != 0) { accel_free(a); return -1; }   // malformed tree: rejected before any traversal
-  a->dev.tlas_c = (const uint4*)a->tlas_c; a->dev.bvh_c = (const uint4*)a->bvh_c; a->dev.tri_w = (const float4*)a->tri_w;
+  a->dev.nodes_c = (const uint4*)a->nodes_c; a->dev.ref_tlas = (const uint32_t*)s->tlas; a->dev.n_tlas = s->n_tlas_nodes; a->dev.tri_w = (const float4*)a->tri_w;
   a->dev.blas_root = (const uint32_t*)a->blas_root; a->dev.tlas_root = troot;
   a->dev.exact_decode = (hstatus & STATUS_FMA_DECODE_DIFFERS) ? 1u : 0u;
   a->dev.ref_bvh = (const uint32_t*)s->bvh;
