@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-end evidence in one GPU call: GPU tests, the default bench line, rocprofv3 kernel stats of the
+# default (pipelined) and of the serial bench command, PMC passes.  usage: tools/round_profile.sh <tag>
+set -u
+TAG=$1
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+python -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.txt" 2>&1 || { tail -5 "$OUT/pytest_gpu.txt"; exit 1; }
+tail -1 "$OUT/pytest_gpu.txt"
+python bench.py --random-rays 4194304 > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
+cat "$OUT/bench.json"
+python bench.py --frames-in-flight 1 --no-cpu-baseline > "$OUT/bench_serial.json" 2>> "$OUT/bench.err" || exit 1
+cat "$OUT/bench_serial.json"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_pipelined" -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/stats_pipelined.log" 2>&1 || { echo "rocprof pipelined failed"; exit 1; }
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -- python "$ROOT/bench.py" --no-cpu-baseline --frames-in-flight 1 > "$OUT/stats_serial.log" 2>&1 || { echo "rocprof serial failed"; exit 1; }
+for m in pipelined serial; do
+  f=$(find "$OUT/stats_$m" -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_$m.csv" && head -8 "$OUT/kernel_stats_$m.csv"
+  rm -rf "$OUT/stats_$m"
+done
+"$ROOT/tools/pmc_passes3.sh" "$OUT/pmc" > "$OUT/pmc.log" 2>&1
+tail -3 "$OUT/pmc.log"
+cp "$OUT/pmc/summary.txt" "$OUT/pmc_summary.txt"; rm -rf "$OUT"/pmc/pass*/

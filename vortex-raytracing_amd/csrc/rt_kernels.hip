@@ -387,6 +387,10 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #endif
 #define QUEUE_STRIDE 32u    // one 128-byte line per shard counter
 #ifndef LDS_STACK
+// per-frame control block: [0] deferral count (own 128-byte line), then the queue counters of the main
+// launch, of the EXACT launch over the deferred list and of the a-priori EXACT launch
+#define CTL_QUEUE_DWORDS (QUEUE_SHARDS * QUEUE_STRIDE)
+#define CTL_DWORDS (32u + 3u * CTL_QUEUE_DWORDS)
 #define LDS_STACK 8         // stack levels kept in LDS per lane (4 KiB per wavefront); deeper ones go to scratch
 #endif
 
@@ -798,7 +802,11 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
                                                       const float* __restrict__ utab, const float* __restrict__ vtab,
                                                       const HitRec* __restrict__ hb, uint32_t* __restrict__ dst,
                                                       HitRec* __restrict__ hits, float* __restrict__ colors,
-                                                      unsigned long long* counters) {
+                                                      unsigned long long* counters, uint32_t* __restrict__ ctl_reset) {
+  // last kernel of a frame: every user of the frame's control block (queue counters, deferral count)
+  // has finished, so zero it here for the context's next frame instead of paying fill launches per frame
+  if (ctl_reset && blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < CTL_DWORDS; i += 256u) ctl_reset[i] = 0u;
   const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
   const uint64_t n = (uint64_t)W * (y1 - y0);
   unsigned ntex = 0, npix = 0;
@@ -950,6 +958,9 @@ __global__ void accel_roots_kernel(const uint32_t* __restrict__ tlas, const uint
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 static uint32_t* g_status[16] = {nullptr};
@@ -964,34 +975,33 @@ static uint32_t* status_word() {
   return g_status[dev];
 }
 
-// job-queue counters of the persistent kernels: a ring so that launches in flight on different
-// streams never share a counter (a slot is reused after 64 launches)
-#define QUEUE_RING 64
 #define EXACT_GRID 128   // workgroups of the EXACT launch (it sees a fraction of a percent of the rays)
-static uint32_t* g_queue[16] = {nullptr};
-static unsigned g_queue_next[16] = {0};
 
-static uint32_t* queue_slot(hipStream_t s) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!g_queue[dev]) {
-    if (hipMalloc((void**)&g_queue[dev], (size_t)QUEUE_RING * QUEUE_SHARDS * QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess) return nullptr;
-  }
-  uint32_t* q = g_queue[dev] + (size_t)(g_queue_next[dev]++ % QUEUE_RING) * QUEUE_SHARDS * QUEUE_STRIDE;
-  if (hipMemsetAsync(q, 0, (size_t)QUEUE_SHARDS * QUEUE_STRIDE * sizeof(uint32_t), s) != hipSuccess) return nullptr;
-  return q;
-}
-
+// grid of a persistent launch: what the device holds at once (occupancy x CUs, queried once per kernel
+// and device), capped by the job count
 template <class K>
 static uint32_t persistent_grid(K kernel, uint64_t jobs) {
-  int dev = 0, per_cu = 0, cus = 0;
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, uint64_t> cache;
+  int dev = 0;
   (void)hipGetDevice(&dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-  uint64_t g = (uint64_t)per_cu * (uint64_t)cus;
+  uint64_t g = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({(const void*)kernel, dev});
+    if (it != cache.end()) g = it->second;
+  }
+  if (!g) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    g = (uint64_t)per_cu * (uint64_t)cus;
+    if (getenv("VXRT_DEBUG")) fprintf(stderr, "[vxrt] persistent grid: %d blocks/CU x %d CUs\n", per_cu, cus);
+    std::lock_guard<std::mutex> lk(mu);
+    cache[{(const void*)kernel, dev}] = g;
+  }
   const uint64_t need = (jobs + 255) / 256;
   if (g > need) g = need;
-  if (getenv("VXRT_DEBUG")) fprintf(stderr, "[vxrt] persistent grid: %d blocks/CU x %d CUs -> %llu blocks for %llu jobs\n", per_cu, cus, (unsigned long long)g, (unsigned long long)jobs);
   return (uint32_t)(g ? g : 1);
 }
 
@@ -1003,8 +1013,10 @@ static uint32_t persistent_grid(K kernel, uint64_t jobs) {
 struct FrameCtx {
   void* hitbuf = nullptr;      // W*H hit records between the traversal and the shading pass
   uint64_t hitbuf_pixels = 0;
-  uint32_t* defer = nullptr;   // [0] count, [1..] job list of the EXACT launch
+  uint32_t* defer = nullptr;   // job list of the EXACT launch
   uint64_t defer_cap = 0;
+  uint32_t* ctl = nullptr;     // control block (CTL_DWORDS), zero between frames
+  bool ctl_dirty = false;      // a call failed after touching it: clear before the next use
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr;
   bool busy = false;
@@ -1032,7 +1044,7 @@ static void accel_free(vxrt_accel* a) {
   (void)hipFree(a->nodes_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
   (void)hipFree(a->uvtab); (void)hipFree(a->apriori);
   for (FrameCtx& c : a->ctx) {
-    (void)hipFree(c.hitbuf); (void)hipFree(c.defer);
+    (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl);
     if (c.side) (void)hipStreamDestroy(c.side);
     if (c.ev_in) (void)hipEventDestroy(c.ev_in);
     if (c.ev_side) (void)hipEventDestroy(c.ev_side);
@@ -1049,8 +1061,14 @@ static FrameCtx* acquire_ctx(vxrt_accel* a, hipStream_t s) {
     if (hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c.ev_side, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipMalloc((void**)&c.ctl, CTL_DWORDS * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    if (hipMemset(c.ctl, 0, CTL_DWORDS * sizeof(uint32_t)) != hipSuccess) return nullptr;
   }
   if (c.busy && hipStreamWaitEvent(s, c.ev_done, 0) != hipSuccess) return nullptr;
+  if (c.ctl_dirty) {
+    if (hipMemsetAsync(c.ctl, 0, CTL_DWORDS * sizeof(uint32_t), s) != hipSuccess) return nullptr;
+    c.ctl_dirty = false;
+  }
   return &c;
 }
 
@@ -1151,7 +1169,7 @@ static int ensure_defer(FrameCtx* c, uint64_t jobs, hipStream_t s) {
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   (void)hipFree(c->defer);
   c->defer = nullptr; c->defer_cap = 0;
-  if (hipMalloc((void**)&c->defer, (jobs + 1) * sizeof(uint32_t)) != hipSuccess) return -1;
+  if (hipMalloc((void**)&c->defer, jobs * sizeof(uint32_t)) != hipSuccess) return -1;
   c->defer_cap = jobs;
   return 0;
 }
@@ -1207,10 +1225,8 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   A.hits = (HitRec*)c->hitbuf; A.counters = counters; A.status = st; A.wave_log = wave_log;
   A.utab = a->uvtab; A.vtab = a->uvtab + width;
   if (ensure_defer(c, A.total, s) != 0) return -1;
-  A.defer_count = c->defer; A.defer_list = c->defer + 1; A.defer_cap = A.total;
-  if (hipMemsetAsync(c->defer, 0, sizeof(uint32_t), s) != hipSuccess) return -1;
-  A.queue = queue_slot(s);
-  if (!A.queue) return -1;
+  A.defer_count = c->ctl; A.defer_list = c->defer; A.defer_cap = A.total;
+  A.queue = c->ctl + 32;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
   // a-priori EXACT list (camera rays with u == 0 or v == 0), rebuilt only when the window changes
   if (a->ap_key[0] != width || a->ap_key[1] != height || a->ap_key[2] != y0 || a->ap_key[3] != y1 || !a->apriori) {
@@ -1239,14 +1255,13 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   // `s`: it writes hit records the previous frame's shading pass may still be reading), concurrent with
   // the main launch; then the main launch and the EXACT launch over whatever the main one deferred
   PersistArgs X = A, X0 = A;
-  X.queue = queue_slot(s);
-  if (!X.queue) return -1;
+  X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
+  c->ctl_dirty = true;   // until the shading pass that zeroes the block again is enqueued
   const bool side_launch = a->ap_count != 0;
   hipStream_t side = c->side;
   if (side_launch) {
     if (hipEventRecord(c->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, c->ev_in, 0) != hipSuccess) return -1;
-    X0.queue = queue_slot(side);
-    if (!X0.queue) return -1;
+    X0.queue = c->ctl + 32 + 2 * CTL_QUEUE_DWORDS;
     X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = a->ap_count;
   }
 #define LAUNCH_P(J, ST, LD) do { \
@@ -1263,9 +1278,10 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   }
   const uint64_t npx = (uint64_t)width * (y1 - y0);
   dim3 sgrid((uint32_t)((npx + 255) / 256));
-  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters);
-  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters);
+  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl);
+  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl);
   if (hipGetLastError() != hipSuccess) return -1;
+  c->ctl_dirty = false;
   return release_ctx(c, s);
 }
 
@@ -1304,17 +1320,18 @@ int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax
   hipStream_t s = (hipStream_t)stream;
   PersistArgs A{};
   A.total = (uint32_t)n; A.hits = (HitRec*)hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
-  A.status = st; A.queue = queue_slot(s);
-  if (!A.queue) return -1;
+  A.status = st;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
   FrameCtx* c = acquire_ctx(a, s);
   if (!c) return -1;
   if (ensure_defer(c, A.total, s) != 0) return -1;
-  A.defer_count = c->defer; A.defer_list = c->defer + 1; A.defer_cap = A.total;
-  if (hipMemsetAsync(c->defer, 0, sizeof(uint32_t), s) != hipSuccess) return -1;
+  // no kernel follows the EXACT launch that could zero the control block again: it stays dirty and the
+  // next call on this context clears it with one fill (acquire_ctx)
+  c->ctl_dirty = true;
+  A.defer_count = c->ctl; A.defer_list = c->defer; A.defer_cap = A.total;
+  A.queue = c->ctl + 32;
   PersistArgs X = A;
-  X.queue = queue_slot(s);
-  if (!X.queue) return -1;
+  X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
   ShadeParams p{};
   if (a->dev.exact_decode) {
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, true, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, true, false>, n)), dim3(256), 0, s, a->dev, p, A);
