@@ -3,8 +3,10 @@
 
 Metric (BASELINE.json): Mrays/s (primary + shadow) at 1920x1080 on the 1M-triangle "Sponza-class"
 BVH.  A step = one frame of the RTU test on that scene: camera ray -> closest hit -> Lambert shade
-with one occlusion ray toward the light per hit -> RGB8, i.e. one launch of rt_render_kernel<SHADOW>
-through the C ABI (vxrt_render) on this rank's GPU, scene already resident in HBM.
+with one occlusion ray toward the light per hit -> RGB8, i.e. one vxrt_render call through the C ABI
+(persistent traversal launch + EXACT launches + shading pass) on this rank's GPU, scene already resident in
+HBM.  Frames are issued round robin on --frames-in-flight streams (default 4) so that the draining tail of
+one frame's persistent launch overlaps the next frame's; --frames-in-flight 1 gives strictly serial frames.
 
 Multi-GPU (one process per GPU, torch.distributed over RCCL): the reference's own per-pixel
 `for s < samples_per_pixel` loop (kernel.cpp:67-80) is the data-parallel axis -- rank r traces
