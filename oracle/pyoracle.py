@@ -69,6 +69,9 @@ def orc():
         L.orc_pack_rgb8.argtypes = [vp]
         L.orc_render.restype = C.c_int
         L.orc_render.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ShadeParams), vp, vp, vp]
+        L.orc_render_ex.restype = C.c_int
+        L.orc_render_ex.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ShadeParams), C.c_int, vp, vp, vp,
+                                    C.POINTER(C.c_uint64)]
         L.orc_ray_box.restype = C.c_float
         L.orc_ray_box.argtypes = [vp] + [C.c_float] * 6
         _orc = L
@@ -187,6 +190,21 @@ def render(scene, w, h, params=None, y0=0, y1=None):
     orc().orc_render(w, h, y0, y1, _p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(b["triEx"]), _p(b["mat"]),
                      _p(b["tex"]), C.byref(params), _p(px), _p(hits), _p(col))
     return px, hits.reshape(h, w), col.reshape(h, w, 3)
+
+
+def render_ex(scene, w, h, params=None, shadow=0, y0=0, y1=None):
+    """orc_render_ex: frame with the mirror bounce of closest.cpp:95-121 followed up to params.max_depth and,
+    optionally, the shadow extension at every shaded hit.  Returns pixels, primary hits, colours, rays traced."""
+    y1 = h if y1 is None else y1
+    params = params or shade_params()
+    px = np.zeros((h, w), np.uint32)
+    hits = np.zeros(h * w, HIT_DTYPE)
+    col = np.zeros((h * w, 3), np.float32)
+    n = C.c_uint64(0)
+    b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")}
+    orc().orc_render_ex(w, h, y0, y1, _p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(b["triEx"]), _p(b["mat"]),
+                        _p(b["tex"]), C.byref(params), shadow, _p(px), _p(hits), _p(col), C.byref(n))
+    return px, hits.reshape(h, w), col.reshape(h, w, 3), int(n.value)
 
 
 def shade(scene, rays, hits, params=None):

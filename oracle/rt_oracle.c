@@ -472,16 +472,13 @@ static f3 diffuse_lighting(f3 pixel, f3 normal, f3 diffuse_color, f3 ambient, f3
   return f3_mul(diffuse_color, f3_add(ambient, f3_scale(f3_scale(light_color, att), NdotL)));
 }
 
-void orc_shade(const float ray6[6], const orc_hit_t* hit,
-               const orc_blas_t* blas_ptr, const orc_triex_t* triEx_ptr, const orc_material_t* mat_ptr,
-               const uint8_t* tex_ptr, const orc_shade_params_t* p, float out_color[3]) {
-  f3 background = f3_make(p->background[0], p->background[1], p->background[2]);
-  if (hit->dist == ORC_LARGE_FLOAT) { /* rt_unit.cpp:107-109 -> miss.cpp:9-14 */
-    out_color[0] = background.x; out_color[1] = background.y; out_color[2] = background.z;
-    return;
-  }
-  /* closest.cpp:11-127 */
-  f3 radiance = f3_make(0, 0, 0);
+/* closest.cpp:57-90 for one hit: the non-reflected diffuse contribution `throughput * diffuse *
+ * (1 - reflectivity)` with throughput = 1 (:87), the reflectivity (:84), the hit point I and the shading
+ * normal N.  occluded = result of the shadow extension (0 = the reference: no occlusion query). */
+static void shade_terms(const float ray6[6], const orc_hit_t* hit,
+                        const orc_blas_t* blas_ptr, const orc_triex_t* triEx_ptr, const orc_material_t* mat_ptr,
+                        const uint8_t* tex_ptr, const orc_shade_params_t* p, int occluded,
+                        f3* out_term, float* out_refl, f3* out_I, f3* out_N) {
   float throughput = 1.0f;
   f3 orig = f3_make(ray6[0], ray6[1], ray6[2]);
   f3 dir = f3_make(ray6[3], ray6[4], ray6[5]);
@@ -510,17 +507,90 @@ void orc_shade(const float ray6[6], const orc_hit_t* hit,
   } else {
     texColor = f3_make(mat->diffuse[0], mat->diffuse[1], mat->diffuse[2]);
   }
-  f3 diffuse = diffuse_lighting(I, N, texColor,
-                                f3_make(p->ambient[0], p->ambient[1], p->ambient[2]),
-                                f3_make(p->light_color[0], p->light_color[1], p->light_color[2]),
-                                f3_make(p->light_pos[0], p->light_pos[1], p->light_pos[2]));
+  f3 ambient = f3_make(p->ambient[0], p->ambient[1], p->ambient[2]);
+  f3 light_color = f3_make(p->light_color[0], p->light_color[1], p->light_color[2]);
+  f3 light_pos = f3_make(p->light_pos[0], p->light_pos[1], p->light_pos[2]);
+  f3 diffuse;
+  if (!occluded) {
+    diffuse = diffuse_lighting(I, N, texColor, ambient, light_color, light_pos);
+  } else { /* shadow extension: the same expression with NdotL forced to 0 */
+    f3 L = f3_sub(light_pos, I);
+    float dist = sqrtf(f3_dot(L, L));
+    float att = 1.0f / (1.0f + dist * 0.1f);
+    diffuse = f3_mul(texColor, f3_add(ambient, f3_scale(f3_scale(light_color, att), 0.0f)));
+  }
   float reflectivity = blas->reflectivity;                                             /* :84 */
-  radiance = f3_add(radiance, f3_scale(f3_scale(diffuse, throughput), 1 - reflectivity)); /* :87 */
+  *out_term = f3_add(f3_make(0, 0, 0), f3_scale(f3_scale(diffuse, throughput), 1 - reflectivity)); /* :87 */
+  *out_refl = reflectivity;
+  *out_I = I; *out_N = N;
+}
+
+void orc_shade(const float ray6[6], const orc_hit_t* hit,
+               const orc_blas_t* blas_ptr, const orc_triex_t* triEx_ptr, const orc_material_t* mat_ptr,
+               const uint8_t* tex_ptr, const orc_shade_params_t* p, float out_color[3]) {
+  f3 background = f3_make(p->background[0], p->background[1], p->background[2]);
+  if (hit->dist == ORC_LARGE_FLOAT) { /* rt_unit.cpp:107-109 -> miss.cpp:9-14 */
+    out_color[0] = background.x; out_color[1] = background.y; out_color[2] = background.z;
+    return;
+  }
+  f3 radiance, I, N;
+  float throughput = 1.0f, reflectivity;
+  shade_terms(ray6, hit, blas_ptr, triEx_ptr, mat_ptr, tex_ptr, p, 0, &radiance, &reflectivity, &I, &N);
   throughput *= reflectivity;                                                          /* :90 */
-  /* :95-121: secondary ray only if reflectivity > 0 && bounce+1 < max_depth; the shipped scene
-   * builder hard-codes reflectivity = 0 (scene.cpp:96), so this restatement covers the else arm. */
+  /* :95-121: secondary ray only if reflectivity > 0 && bounce+1 < max_depth (orc_render_ex follows it);
+   * this entry point is the else arm, which is all the shipped scene builder reaches (scene.cpp:96) */
   radiance = f3_add(radiance, f3_scale(background, throughput));                       /* :123 */
   out_color[0] = radiance.x; out_color[1] = radiance.y; out_color[2] = radiance.z;
+}
+
+/* Occlusion ray of the shadow extension (no reference counterpart; BASELINE "primary+shadow"): from the
+ * hit point toward the light, origin pushed 1e-3 along L as the mirror bounce does (closest.cpp:104),
+ * tmax = |L|; any accepted candidate occludes. */
+static int occluded_toward_light(const orc_node_t* tlas, const orc_blas_t* blas, const orc_node_t* bvh, const orc_tri_t* tri,
+                                 const float ray6[6], float hit_dist, const orc_shade_params_t* p, uint64_t* n_rays) {
+  f3 orig = f3_make(ray6[0], ray6[1], ray6[2]), dir = f3_make(ray6[3], ray6[4], ray6[5]);
+  f3 I = f3_add(orig, f3_scale(dir, hit_dist));
+  f3 L = f3_sub(f3_make(p->light_pos[0], p->light_pos[1], p->light_pos[2]), I);
+  float dist = sqrtf(f3_dot(L, L));
+  L = f3_scale(L, 1.0f / dist);
+  f3 so = f3_add(I, f3_scale(L, 0.001f));
+  float sray[6] = {so.x, so.y, so.z, L.x, L.y, L.z};
+  orc_hit_t sh;
+  orc_trace_canonical(tlas, blas, bvh, tri, sray, 1, &dist, &sh, NULL, 1);
+  if (n_rays) ++*n_rays;
+  return sh.dist != ORC_LARGE_FLOAT;
+}
+
+/* Radiance carried by one ray: rt_unit.cpp:98-116 (closest hit or miss) -> closest.cpp:11-127 with the
+ * mirror bounce of :95-121 followed recursively (secPayload.bounce = bounce + 1), miss.cpp:9-14. */
+static f3 radiance_of(const orc_node_t* tlas, const orc_blas_t* blas, const orc_node_t* bvh, const orc_tri_t* tri,
+                      const orc_triex_t* triEx, const orc_material_t* mat, const uint8_t* tex,
+                      const orc_shade_params_t* p, int shadow, const float ray6[6], uint32_t bounce,
+                      orc_hit_t* out_hit, uint64_t* n_rays) {
+  f3 background = f3_make(p->background[0], p->background[1], p->background[2]);
+  orc_hit_t hit;
+  orc_trace_canonical(tlas, blas, bvh, tri, ray6, 1, NULL, &hit, NULL, 0);
+  if (n_rays) ++*n_rays;
+  if (out_hit) *out_hit = hit;
+  if (hit.dist == ORC_LARGE_FLOAT) return background;
+  int occ = shadow ? occluded_toward_light(tlas, blas, bvh, tri, ray6, hit.dist, p, n_rays) : 0;
+  f3 radiance, I, N;
+  float throughput = 1.0f, reflectivity;
+  shade_terms(ray6, &hit, blas, triEx, mat, tex, p, occ, &radiance, &reflectivity, &I, &N);
+  throughput *= reflectivity;                                                          /* :90 */
+  if (reflectivity > 0.0f && bounce + 1 < p->max_depth) {                              /* :95 */
+    f3 dir = f3_make(ray6[3], ray6[4], ray6[5]);
+    /* :96  R = normalize(ray.dir - 2.0f * N * dot(N, ray.dir)):  (2*N) * dot, geometry.h:722,721 */
+    f3 twoN = f3_make(2.0f * N.x, 2.0f * N.y, 2.0f * N.z);
+    f3 R = f3_normalize(f3_sub(dir, f3_scale(twoN, f3_dot(N, dir))));
+    f3 so = f3_add(I, f3_scale(R, 0.001f));                                            /* :99 */
+    float sec[6] = {so.x, so.y, so.z, R.x, R.y, R.z};
+    f3 sc = radiance_of(tlas, blas, bvh, tri, triEx, mat, tex, p, shadow, sec, bounce + 1, NULL, n_rays);
+    radiance = f3_add(radiance, f3_scale(sc, throughput));                             /* :117 */
+  } else {
+    radiance = f3_add(radiance, f3_scale(background, throughput));                     /* :123 */
+  }
+  return radiance;
 }
 
 /* common.h:149-154 RGB32FtoRGB8 */
@@ -544,6 +614,30 @@ int orc_render(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
       orc_trace_canonical(tlas, blas, bvh, tri, ray, 1, NULL, &hit, NULL, 0);
       float col[3];
       orc_shade(ray, &hit, blas, triEx, mat, tex, p, col);
+      uint64_t idx = (uint64_t)x + (uint64_t)y * w;
+      out_pixels[idx] = orc_pack_rgb8(col);
+      if (out_hits) out_hits[idx] = hit;
+      if (out_color) { out_color[3 * idx] = col[0]; out_color[3 * idx + 1] = col[1]; out_color[3 * idx + 2] = col[2]; }
+    }
+  }
+  return 0;
+}
+
+/* orc_render with the mirror bounce followed (max_depth from the parameters) and, optionally, the
+ * shadow extension at every shaded hit.  n_rays: rays traced (camera + bounce + occlusion). */
+int orc_render_ex(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
+                  const orc_node_t* tlas, const orc_blas_t* blas, const orc_node_t* bvh,
+                  const orc_tri_t* tri, const orc_triex_t* triEx, const orc_material_t* mat,
+                  const uint8_t* tex, const orc_shade_params_t* p, int shadow,
+                  uint32_t* out_pixels, orc_hit_t* out_hits, float* out_color, uint64_t* n_rays) {
+  if (n_rays) *n_rays = 0;
+  for (uint32_t y = y0; y < y1; ++y) {
+    for (uint32_t x = 0; x < w; ++x) {
+      float ray[6];
+      orc_generate_ray(x, y, w, h, ray);
+      orc_hit_t hit;
+      f3 c = radiance_of(tlas, blas, bvh, tri, triEx, mat, tex, p, shadow, ray, 0, &hit, n_rays);
+      float col[3] = {c.x, c.y, c.z};
       uint64_t idx = (uint64_t)x + (uint64_t)y * w;
       out_pixels[idx] = orc_pack_rgb8(col);
       if (out_hits) out_hits[idx] = hit;

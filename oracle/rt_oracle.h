@@ -123,6 +123,17 @@ int orc_render(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
                const uint8_t* tex, const orc_shade_params_t* p,
                uint32_t* out_pixels, orc_hit_t* out_hits /* may be NULL */, float* out_color /* may be NULL, 3/pixel */);
 
+/* orc_render following the mirror bounce of closest.cpp:95-121 up to p->max_depth, optionally with the
+ * shadow extension (one occlusion ray toward the light per shaded hit, at every depth).  The bounce arm
+ * cannot be pinned against the reference (its shaders only compile for RISC-V and its scene builder
+ * never sets a reflectivity): parity unpinned for that arm, restated from the source text. */
+int orc_render_ex(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
+                  const orc_node_t* tlas, const orc_blas_t* blas, const orc_node_t* bvh,
+                  const orc_tri_t* tri, const orc_triex_t* triEx, const orc_material_t* mat,
+                  const uint8_t* tex, const orc_shade_params_t* p, int shadow,
+                  uint32_t* out_pixels, orc_hit_t* out_hits /* may be NULL */, float* out_color /* may be NULL */,
+                  uint64_t* n_rays /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,3 +316,28 @@ def test_inverted_child_boxes_take_the_generic_slab_form(vrt, po, golden, gpu_de
     # test applied to these boxes would take far planes for near ones and lose most of them
     base, _ = po.trace_faithful(g, g["rays"])
     np.testing.assert_array_equal(_bits(base), _bits(want))
+
+
+@pytest.mark.parametrize("depth,shadow", [(1, 0), (2, 0), (4, 0), (4, 1), (16, 0)])
+def test_mirror_bounce_matches_oracle(vrt, po, gpu_device, depth, shadow):
+    """closest.cpp:95-121: reflective instances spawn a mirror ray while bounce + 1 < max_depth.  The
+    kernels run it as a wavefront over depth levels and fold the colours back in the reference's order
+    of operations: pixels and colours equal the recursive restatement (which is unpinned for this arm:
+    the reference's shaders only build for RISC-V and its scenes have reflectivity 0)."""
+    from scenes import mirror_hall
+    b = mirror_hall(vrt)
+    ds = vrt.tracer.DeviceScene(b, gpu_device)
+    w, h = 160, 96
+    p = vrt.rtapi.default_shade_params()
+    p.light_pos[:] = (150.0, 220.0, -60.0)
+    p.max_depth = depth
+    px, hits, col, nrays = gpu_render(vrt, ds, w, h, shadow=shadow, params=p)
+    pp = po.shade_params(light_pos=tuple(p.light_pos), max_depth=depth)
+    rpx, rhits, rcol, rn = po.render_ex(b, w, h, pp, shadow)
+    assert np.array_equal(_bits(hits), _bits(rhits))
+    assert nrays == rn
+    np.testing.assert_allclose(col, rcol, rtol=COLOR_RTOL)
+    np.testing.assert_array_equal(px, rpx)
+    if depth > 1:
+        flat, _, fcol, fn = po.render_ex(b, w, h, po.shade_params(light_pos=tuple(p.light_pos), max_depth=1), shadow)
+        assert rn > fn and (rcol != fcol).any()          # the bounce really contributes

@@ -107,3 +107,47 @@ def test_stale_base_quirk_is_confined_to_deep_tlas(po, golden):
     lost = (g["hits"]["dist"][mask] >= 1e29) & (c["dist"][mask] < 1e29)
     print("sphere_x6: %d rays trip the quirk, reference loses a real hit on %d of them" % (mask.sum(), lost.sum()))
     assert (c["dist"][mask] <= g["hits"]["dist"][mask]).all()
+
+
+def test_mirror_bounce_restatement_properties(vrt, po):
+    """orc_render_ex (closest.cpp:95-121 followed recursively; unpinned arm, see oracle/README.md):
+    depth 1 is orc_render; without reflective instances depth does not matter; with them, pixels that
+    see a mirror change and each level only adds rays."""
+    from scenes import mirror_hall
+    w, h = 64, 40
+    lp = (150.0, 220.0, -60.0)
+    b = mirror_hall(vrt)
+    px1, h1, c1 = po.render(b, w, h, po.shade_params(light_pos=lp, max_depth=1))
+    pxe, he, ce, n1 = po.render_ex(b, w, h, po.shade_params(light_pos=lp, max_depth=1))
+    assert np.array_equal(px1, pxe) and np.array_equal(c1.view(np.uint32), ce.view(np.uint32)) and n1 == w * h
+    dull = mirror_hall(vrt, 0.0, 0.0)
+    a = po.render_ex(dull, w, h, po.shade_params(light_pos=lp, max_depth=1))
+    d = po.render_ex(dull, w, h, po.shade_params(light_pos=lp, max_depth=5))
+    assert np.array_equal(a[2].view(np.uint32), d[2].view(np.uint32)) and a[3] == d[3]
+    counts = [po.render_ex(b, w, h, po.shade_params(light_pos=lp, max_depth=k))[3] for k in (1, 2, 3, 4)]
+    assert counts[0] < counts[1] < counts[2] <= counts[3]
+    _, hits, c4, _ = po.render_ex(b, w, h, po.shade_params(light_pos=lp, max_depth=4))
+    sees_mirror = (hits["dist"] < 1e29) & (hits["blasIdx"] == 1)
+    assert sees_mirror.any()
+    changed = (c4.view(np.uint32) != c1.view(np.uint32)).any(-1)
+    # (a mirror ray that leaves the scene returns the background, which is what the else arm adds too)
+    assert changed[sees_mirror].any() and not changed[~sees_mirror].any()
+    # one level by hand: C = term + C(mirror ray) * reflectivity, with term = shade(reflectivity -> the else arm) - bg * refl
+    y, x = np.argwhere(sees_mirror & changed)[0]
+    rays = po.camera_rays(w, h)[y * w + x][None]
+    p2 = po.shade_params(light_pos=lp, max_depth=2)
+    c2 = po.render_ex(b, w, h, p2)[2][y, x]
+    f = np.float32
+    refl = f(b["blas"].view(np.float32).reshape(-1, 40)[1, 38])
+    bg = np.array(p2.background[:], f)
+    else_arm = po.shade(b, rays, hits[y, x][None], p2)[0][0]               # term + bg * refl
+    n_hat = np.array([-1.0, 0.0, 0.0], f)                                   # mirror 1 faces -x
+    dvec = rays[0, 3:].astype(f)
+    R = dvec - (f(2.0) * n_hat) * f(np.dot(n_hat, dvec))
+    R = (R * (f(1.0) / np.sqrt(f(np.dot(R, R)), dtype=f))).astype(f)
+    I = (rays[0, :3] + dvec * hits[y, x]["dist"]).astype(f)
+    sec = np.concatenate([I + R * f(0.001), R]).astype(f)[None]
+    sh, _ = po.trace_faithful(b, sec)
+    csec = po.shade(b, sec, sh, po.shade_params(light_pos=lp, max_depth=1))[0][0]
+    want = (else_arm - bg * refl) + csec * refl
+    np.testing.assert_allclose(c2, want, rtol=2e-6, atol=1e-7)

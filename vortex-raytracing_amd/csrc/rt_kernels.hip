@@ -255,12 +255,15 @@ __device__ __forceinline__ void shadow_ray(const ShadeParams& p, float ox, float
   sdist = dist;
 }
 
-// closest.cpp:57-127 / miss.cpp:9-14.  occluded: result of the shadow extension (false = reference).
+// closest.cpp:57-90 for one hit: the non-reflected diffuse contribution `throughput * diffuse * (1 - reflectivity)`
+// with throughput = 1 (:87), the reflectivity (:84), the hit point I and the shading normal N.
+// occluded: result of the shadow extension (false = reference).
 template <bool STATS = false>
-__device__ void shade_eval(const SceneDev& sc, const ShadeParams& p, float ox, float oy, float oz,
-                           float dx, float dy, float dz, const HitRec& hit, bool found, bool occluded,
-                           float& r, float& g, float& b, unsigned* textured = nullptr) {
-  if (!found) { r = p.bg[0]; g = p.bg[1]; b = p.bg[2]; return; }
+__device__ void shade_terms(const SceneDev& sc, const ShadeParams& p, float ox, float oy, float oz,
+                            float dx, float dy, float dz, const HitRec& hit, bool occluded,
+                            float& r, float& g, float& b, float& refl_out,
+                            float& Ix_o, float& Iy_o, float& Iz_o, float& Nx_o, float& Ny_o, float& Nz_o,
+                            unsigned* textured = nullptr) {
   const uint32_t* bp = sc.blas + (size_t)hit.blasIdx * (RT_BLAS_STRIDE / 4);
   const rt_triex_t te = sc.triEx[hit.triIdx];
   const rt_material_t* mat = sc.mat + te.texId;
@@ -309,14 +312,38 @@ __device__ void shade_eval(const SceneDev& sc, const ShadeParams& p, float ox, f
   const float dg = cg * (p.amb[1] + att * p.lcol[1] * NdotL);
   const float db = cb * (p.amb[2] + att * p.lcol[2] * NdotL);
   const float refl = __uint_as_float(bp[38]);   // blas_node_t::reflectivity @152
-  float thr = 1.0f;
+  const float thr = 1.0f;
   r = 0.0f + thr * dr * (1 - refl);             // :87
   g = 0.0f + thr * dg * (1 - refl);
   b = 0.0f + thr * db * (1 - refl);
+  refl_out = refl;
+  Ix_o = Ix; Iy_o = Iy; Iz_o = Iz; Nx_o = Nx; Ny_o = Ny; Nz_o = Nz;
+}
+
+// closest.cpp:57-127 without a secondary ray (reflectivity <= 0 or bounce + 1 >= max_depth) / miss.cpp:9-14
+template <bool STATS = false>
+__device__ void shade_eval(const SceneDev& sc, const ShadeParams& p, float ox, float oy, float oz,
+                           float dx, float dy, float dz, const HitRec& hit, bool found, bool occluded,
+                           float& r, float& g, float& b, unsigned* textured = nullptr) {
+  if (!found) { r = p.bg[0]; g = p.bg[1]; b = p.bg[2]; return; }
+  float refl, Ix, Iy, Iz, Nx, Ny, Nz;
+  shade_terms<STATS>(sc, p, ox, oy, oz, dx, dy, dz, hit, occluded, r, g, b, refl, Ix, Iy, Iz, Nx, Ny, Nz, textured);
+  float thr = 1.0f;
   thr *= refl;                                  // :90
-  r = r + p.bg[0] * thr;                        // :123 (no secondary ray: scene.cpp:96 sets reflectivity 0)
+  r = r + p.bg[0] * thr;                        // :123
   g = g + p.bg[1] * thr;
   b = b + p.bg[2] * thr;
+}
+
+// closest.cpp:96-99: the mirror ray leaving a hit.  R = normalize(dir - 2.0f * N * dot(N, dir)), origin I + R * 0.001f
+__device__ __forceinline__ void mirror_ray(float dx, float dy, float dz, float Ix, float Iy, float Iz, float Nx, float Ny, float Nz,
+                                           float* out6) {
+  const float nd = Nx * dx + Ny * dy + Nz * dz;
+  const float vx = dx - (2.0f * Nx) * nd, vy = dy - (2.0f * Ny) * nd, vz = dz - (2.0f * Nz) * nd;
+  const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+  const float Rx = vx * inv, Ry = vy * inv, Rz = vz * inv;
+  out6[0] = Ix + Rx * 0.001f; out6[1] = Iy + Ry * 0.001f; out6[2] = Iz + Rz * 0.001f;
+  out6[3] = Rx; out6[4] = Ry; out6[5] = Rz;
 }
 
 __device__ __forceinline__ uint32_t pack_rgb8(float r, float g, float b) {  // common.h:149-154
@@ -839,6 +866,121 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Mirror bounce (closest.cpp:95-121) as a wavefront over depth levels.  The reference recurses inside
+// the closest-hit shader: C(ray) = term + (reflectivity > 0 && bounce + 1 < max_depth ? C(mirror ray)
+// : background) * reflectivity, C(miss) = background.  Here level k holds the rays of bounce k (level 0 =
+// the pixels); shading a level appends the next level's rays, and the colours are folded back from the
+// deepest level to the pixels in the reference's order of operations, so the result has the same bits.
+// Taken only when max_depth > 1 and some instance is reflective (the shipped scene builder has none).
+// ---------------------------------------------------------------------------------------------
+// Shade level `level`.  LEVEL0: entry = pixel of rows [y0,y1), hit record from the traversal (occlusion
+// in bit 31 of blasIdx); else entry i = ray rays[6i..] with hit hits[i] (occluded iff shits[i] hit).
+// Entries that bounce leave (term, reflectivity) in term[] and append a ray; the others are final.
+template <bool LEVEL0>
+__global__ __launch_bounds__(256) void rt_shade_bounce_kernel(SceneDev sc, ShadeParams p, uint32_t level, uint64_t n,
+    uint32_t W, uint32_t y0, const float* __restrict__ utab, const float* __restrict__ vtab,
+    const HitRec* __restrict__ hb, const float* __restrict__ rays, const HitRec* __restrict__ shits,
+    float4* __restrict__ term, float* __restrict__ col, uint32_t* __restrict__ dst, HitRec* __restrict__ hits_out,
+    float* __restrict__ colors_out, uint32_t* next_count, float* __restrict__ next_rays, uint32_t* __restrict__ next_parent,
+    uint32_t* __restrict__ ctl_reset) {
+  if (ctl_reset && blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < CTL_DWORDS; i += 256u) ctl_reset[i] = 0u;
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= n) return;
+  size_t e = (size_t)t;
+  float ox, oy, oz, dx, dy, dz;
+  HitRec h;
+  bool occ;
+  if (LEVEL0) {
+    const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
+    e = (size_t)x + (size_t)y * W;
+    h = hb[e];
+    occ = (h.blasIdx & 0x80000000u) != 0u;
+    h.blasIdx &= 0x7fffffffu;
+    generate_ray(utab[x], vtab[y], ox, oy, oz, dx, dy, dz);
+    if (hits_out) hits_out[e] = h;
+  } else {
+    const float* rp = rays + e * 6;
+    ox = rp[0]; oy = rp[1]; oz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5];
+    h = hb[e];
+    occ = shits != nullptr && shits[e].dist != RT_LARGE_FLOAT;
+  }
+  float r, g, b;
+  bool final_ = true;
+  if (h.dist == RT_LARGE_FLOAT) {   // miss.cpp:9-14
+    r = p.bg[0]; g = p.bg[1]; b = p.bg[2];
+  } else {
+    float refl, Ix, Iy, Iz, Nx, Ny, Nz;
+    shade_terms<false>(sc, p, ox, oy, oz, dx, dy, dz, h, occ, r, g, b, refl, Ix, Iy, Iz, Nx, Ny, Nz);
+    if (refl > 0.0f && level + 1u < p.max_depth) {   // :95
+      final_ = false;
+      term[e] = make_float4(r, g, b, refl);
+      const uint32_t slot = atomicAdd(next_count, 1u);   // every level has room for one ray per entry of the level before
+      mirror_ray(dx, dy, dz, Ix, Iy, Iz, Nx, Ny, Nz, next_rays + (size_t)slot * 6);
+      next_parent[slot] = (uint32_t)e;
+    } else {
+      float thr = 1.0f;
+      thr *= refl;                    // :90
+      r = r + p.bg[0] * thr;          // :123
+      g = g + p.bg[1] * thr;
+      b = b + p.bg[2] * thr;
+    }
+  }
+  if (final_) {
+    if (LEVEL0) {
+      dst[e] = pack_rgb8(r, g, b);
+      if (colors_out) { colors_out[3 * e] = r; colors_out[3 * e + 1] = g; colors_out[3 * e + 2] = b; }
+    } else {
+      col[3 * e] = r; col[3 * e + 1] = g; col[3 * e + 2] = b;
+    }
+  }
+}
+
+// occlusion rays of a bounce level (shadow extension at every depth); a miss gets a ray nothing can hit
+__global__ __launch_bounds__(256) void rt_bounce_shadow_rays_kernel(ShadeParams p, uint32_t n, const float* __restrict__ rays,
+    const HitRec* __restrict__ hits, float* __restrict__ srays, float* __restrict__ stmax, unsigned long long* rays_traced) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  bool real = false;
+  if (i < n) {
+    const float* rp = rays + (size_t)i * 6;
+    float* sp = srays + (size_t)i * 6;
+    const float d = hits[i].dist;
+    if (d == RT_LARGE_FLOAT) {
+      sp[0] = 0.f; sp[1] = 0.f; sp[2] = 0.f; sp[3] = 1.f; sp[4] = 1.f; sp[5] = 1.f;
+      stmax[i] = -1.0f;
+    } else {
+      float sdist;
+      shadow_ray(p, rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], d, sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], sdist);
+      stmax[i] = sdist;
+      real = true;
+    }
+  }
+  const unsigned long long m = __ballot(real);
+  if (rays_traced && (threadIdx.x & 63u) == 0u && m) atomicAdd(rays_traced, (unsigned long long)__popcll(m));
+}
+
+// fold level k into level k-1 (closest.cpp:117): C[parent] = term[parent] + C_k * (1 * reflectivity[parent])
+template <bool TO_PIXELS>
+__global__ __launch_bounds__(256) void rt_bounce_unwind_kernel(uint32_t n, const uint32_t* __restrict__ parent, const float* __restrict__ col_k,
+    const float4* __restrict__ term_prev, float* __restrict__ col_prev, uint32_t* __restrict__ dst, float* __restrict__ colors_out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const size_t q = parent[i];
+  const float4 t = term_prev[q];
+  float thr = 1.0f;
+  thr *= t.w;
+  const float r = t.x + col_k[3 * (size_t)i] * thr, g = t.y + col_k[3 * (size_t)i + 1] * thr, b = t.z + col_k[3 * (size_t)i + 2] * thr;
+  if (TO_PIXELS) {
+    dst[q] = pack_rgb8(r, g, b);
+    if (colors_out) { colors_out[3 * q] = r; colors_out[3 * q + 1] = g; colors_out[3 * q + 2] = b; }
+  } else {
+    col_prev[3 * q] = r; col_prev[3 * q + 1] = g; col_prev[3 * q + 2] = b;
+  }
+}
+
+__global__ void add_counter_kernel(unsigned long long* c, unsigned long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(c, v); }
+
+// ---------------------------------------------------------------------------------------------
 // acceleration-layout build (one pass over the reference-format buffers; validates every index the
 // traversal will follow so that a malformed scene is rejected on the host instead of faulting the GPU)
 // ---------------------------------------------------------------------------------------------
@@ -1017,6 +1159,14 @@ struct FrameCtx {
   uint64_t defer_cap = 0;
   uint32_t* ctl = nullptr;     // control block (CTL_DWORDS), zero between frames
   bool ctl_dirty = false;      // a call failed after touching it: clear before the next use
+  // mirror-bounce levels (allocated on first use; level 0 only holds `term`, one entry per pixel)
+  struct Level {
+    float* rays = nullptr; HitRec* hits = nullptr; uint32_t* parent = nullptr; float4* term = nullptr; float* col = nullptr;
+    float* srays = nullptr; float* stmax = nullptr; HitRec* shits = nullptr;
+    uint64_t cap = 0; uint32_t n = 0;
+  };
+  std::vector<Level> lv;
+  uint32_t* bcount = nullptr;  // device: rays appended to the level being built
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr;
   bool busy = false;
@@ -1035,6 +1185,7 @@ struct vxrt_accel {
   uint32_t* apriori = nullptr; // [0] count, [1..] job ids
   uint32_t ap_count = 0, ap_key[4] = {0, 0, 0, 0};
   uint64_t ap_cap = 0;
+  float max_reflectivity = 0.0f;   // over the instance records: > 0 enables the mirror-bounce path
   int device = 0;
 };
 
@@ -1044,7 +1195,11 @@ static void accel_free(vxrt_accel* a) {
   (void)hipFree(a->nodes_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
   (void)hipFree(a->uvtab); (void)hipFree(a->apriori);
   for (FrameCtx& c : a->ctx) {
-    (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl);
+    (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount);
+    for (FrameCtx::Level& l : c.lv) {
+      (void)hipFree(l.rays); (void)hipFree(l.hits); (void)hipFree(l.parent); (void)hipFree(l.term); (void)hipFree(l.col);
+      (void)hipFree(l.srays); (void)hipFree(l.stmax); (void)hipFree(l.shits);
+    }
     if (c.side) (void)hipStreamDestroy(c.side);
     if (c.ev_in) (void)hipEventDestroy(c.ev_in);
     if (c.ev_side) (void)hipEventDestroy(c.ev_side);
@@ -1092,10 +1247,14 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   if (hipStreamSynchronize(st) != hipSuccess) return -1;
   if (hipMemcpy(recs.data(), s->blas, recs.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   std::vector<uint32_t> bases;
+  float max_refl = 0.0f;
   for (uint32_t j = 0; j < s->n_blas; ++j) {
     const uint32_t off = recs[(size_t)j * (RT_BLAS_STRIDE / 4)];
     if (off >= s->n_bvh_nodes) return -1;
     bases.push_back(off);
+    float refl;
+    memcpy(&refl, &recs[(size_t)j * (RT_BLAS_STRIDE / 4) + 38], sizeof(float));   // blas_node_t::reflectivity @152
+    if (refl > max_refl) max_refl = refl;
   }
   std::sort(bases.begin(), bases.end());
   bases.erase(std::unique(bases.begin(), bases.end()), bases.end());
@@ -1105,6 +1264,7 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   auto a = new (std::nothrow) vxrt_accel();
   if (!a) return -1;
   a->ref = *s;
+  a->max_reflectivity = max_refl;
   (void)hipGetDevice(&a->device);
   uint32_t* d_ranges = nullptr;
   uint32_t* d_status = nullptr;
@@ -1172,6 +1332,117 @@ static int ensure_defer(FrameCtx* c, uint64_t jobs, hipStream_t s) {
   if (hipMalloc((void**)&c->defer, jobs * sizeof(uint32_t)) != hipSuccess) return -1;
   c->defer_cap = jobs;
   return 0;
+}
+
+// ray buffer -> hit records on frame context c (the body of vxrt_trace; also the bounce levels of vxrt_render)
+static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_t n, const float* tmax,
+                        HitRec* hits, int mode, hipStream_t s) {
+  uint32_t* st = status_word();
+  if (!st) return -1;
+  PersistArgs A{};
+  A.total = (uint32_t)n; A.hits = hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
+  A.status = st;
+  A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
+  if (ensure_defer(c, A.total, s) != 0) return -1;
+  if (c->ctl_dirty) {
+    if (hipMemsetAsync(c->ctl, 0, CTL_DWORDS * sizeof(uint32_t), s) != hipSuccess) return -1;
+  }
+  // no kernel follows the EXACT launch that could zero the control block again: it stays dirty and the
+  // next use of this context clears it with one fill
+  c->ctl_dirty = true;
+  A.defer_count = c->ctl; A.defer_list = c->defer; A.defer_cap = A.total;
+  A.queue = c->ctl + 32;
+  PersistArgs X = A;
+  X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
+  ShadeParams p{};
+  if (a->dev.exact_decode) {
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, true, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, true, false>, n)), dim3(256), 0, s, a->dev, p, A);
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, true, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X);
+  } else {
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, false, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, false, false>, n)), dim3(256), 0, s, a->dev, p, A);
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, false, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+static bool grow_buf(void** ptr, uint64_t have, uint64_t need, size_t bytes_per_entry) {
+  if (have >= need && *ptr) return true;
+  (void)hipFree(*ptr);
+  *ptr = nullptr;
+  return hipMalloc(ptr, (size_t)need * bytes_per_entry) == hipSuccess;
+}
+
+static bool level_reserve(FrameCtx::Level& l, uint64_t n, bool shadow, bool only_term) {
+  if (l.cap >= n && l.term && (only_term || l.rays) && (!shadow || only_term || l.srays)) return true;
+  const uint64_t have = l.cap;
+  bool ok = grow_buf((void**)&l.term, have, n, 16);
+  if (!only_term) {
+    ok = ok && grow_buf((void**)&l.rays, have, n, 24) && grow_buf((void**)&l.hits, have, n, sizeof(HitRec)) &&
+         grow_buf((void**)&l.parent, have, n, 4) && grow_buf((void**)&l.col, have, n, 12);
+    if (shadow) ok = ok && grow_buf((void**)&l.srays, l.srays ? have : 0, n, 24) && grow_buf((void**)&l.stmax, l.stmax ? have : 0, n, 4) &&
+                     grow_buf((void**)&l.shits, l.shits ? have : 0, n, sizeof(HitRec));
+  }
+  if (ok && l.cap < n) l.cap = n;
+  return ok;
+}
+
+// Tail of a frame with reflective instances (replaces the plain shading pass): shade level 0, then per
+// bounce level trace -> (occlusion rays ->) shade, then fold the colours back.  The level sizes come back
+// to the host between levels, so this path synchronises the stream (it is not the benchmarked one).
+static int render_bounce_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, uint32_t width, uint32_t y0, uint32_t y1,
+                              int shadow, const float* utab, const float* vtab, uint32_t* dst, HitRec* hits, float* colors,
+                              unsigned long long* rays_traced, hipStream_t s) {
+  const SceneDev& sc = a->dev;
+  const uint64_t npix = (uint64_t)width * (y1 - y0);          // entries of level 0 (addressed by pixel index)
+  const uint64_t pix_span = (uint64_t)width * y1;              // term[] of level 0 is indexed by x + y*W
+  if (npix > 0x7fffffffull) return -1;
+  if (!c->bcount && hipMalloc((void**)&c->bcount, sizeof(uint32_t)) != hipSuccess) return -1;
+  if (c->lv.size() < 2) c->lv.resize(2);
+  if (!level_reserve(c->lv[0], pix_span, false, true)) return -1;
+  if (!level_reserve(c->lv[1], npix, shadow != 0, false)) return -1;
+  dim3 block(256);
+  if (hipMemsetAsync(c->bcount, 0, sizeof(uint32_t), s) != hipSuccess) return -1;
+  hipLaunchKernelGGL(rt_shade_bounce_kernel<true>, dim3((uint32_t)((npix + 255) / 256)), block, 0, s, sc, p, 0u, npix, width, y0, utab, vtab,
+                     (const HitRec*)c->hitbuf, (const float*)nullptr, (const HitRec*)nullptr, c->lv[0].term, (float*)nullptr, dst, hits, colors,
+                     c->bcount, c->lv[1].rays, c->lv[1].parent, c->ctl);
+  if (hipGetLastError() != hipSuccess) return -1;
+  c->ctl_dirty = false;
+  uint32_t depth = 0;   // deepest level that holds rays
+  for (uint32_t k = 1; k < p.max_depth; ++k) {
+    uint32_t n = 0;
+    if (hipMemcpyAsync(&n, c->bcount, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (n == 0) break;
+    FrameCtx::Level& L = c->lv[k];
+    L.n = n;
+    depth = k;
+    if (rays_traced) hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(64), 0, s, rays_traced, (unsigned long long)n);
+    if (trace_on_ctx(a, c, L.rays, n, nullptr, L.hits, VXRT_MODE_CLOSEST, s) != 0) return -1;
+    const dim3 grid((n + 255u) / 256u);
+    if (shadow) {
+      hipLaunchKernelGGL(rt_bounce_shadow_rays_kernel, grid, block, 0, s, p, n, (const float*)L.rays, (const HitRec*)L.hits, L.srays, L.stmax, rays_traced);
+      if (trace_on_ctx(a, c, L.srays, n, L.stmax, L.shits, VXRT_MODE_ANY, s) != 0) return -1;
+    }
+    if (c->lv.size() < (size_t)k + 2) c->lv.resize((size_t)k + 2);
+    FrameCtx::Level& Nx = c->lv[k + 1];
+    const bool more = k + 1 < p.max_depth;
+    if (more && !level_reserve(Nx, n, shadow != 0, false)) return -1;
+    FrameCtx::Level& Lk = c->lv[k];   // (resize may have moved the vector)
+    if (hipMemsetAsync(c->bcount, 0, sizeof(uint32_t), s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(rt_shade_bounce_kernel<false>, grid, block, 0, s, sc, p, k, (uint64_t)n, width, y0, utab, vtab,
+                       (const HitRec*)Lk.hits, (const float*)Lk.rays, shadow ? (const HitRec*)Lk.shits : (const HitRec*)nullptr, Lk.term, Lk.col,
+                       (uint32_t*)nullptr, (HitRec*)nullptr, (float*)nullptr, c->bcount, more ? Nx.rays : (float*)nullptr, more ? Nx.parent : (uint32_t*)nullptr,
+                       (uint32_t*)nullptr);
+    if (hipGetLastError() != hipSuccess) return -1;
+    if (!more) break;
+  }
+  for (uint32_t k = depth; k >= 1; --k) {
+    FrameCtx::Level& L = c->lv[k];
+    const dim3 grid((L.n + 255u) / 256u);
+    if (k == 1) hipLaunchKernelGGL(rt_bounce_unwind_kernel<true>, grid, block, 0, s, L.n, (const uint32_t*)L.parent, (const float*)L.col, (const float4*)c->lv[0].term, (float*)nullptr, dst, colors);
+    else        hipLaunchKernelGGL(rt_bounce_unwind_kernel<false>, grid, block, 0, s, L.n, (const uint32_t*)L.parent, (const float*)L.col, (const float4*)c->lv[k - 1].term, c->lv[k - 1].col, (uint32_t*)nullptr, (float*)nullptr);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
@@ -1276,6 +1547,12 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   if (side_launch) {
     if (hipEventRecord(c->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, c->ev_side, 0) != hipSuccess) return -1;
   }
+  if (p.max_depth > 1 && a->max_reflectivity > 0.0f) {
+    // reflective instances: the shading pass becomes the level-0 step of the mirror-bounce wavefront
+    if (stats) return -1;   // the counting build prices the single-level frame only
+    if (render_bounce_tail(a, c, p, width, y0, y1, shadow, A.utab, A.vtab, dst, (HitRec*)hits, colors, counters, s) != 0) return -1;
+    return release_ctx(c, s);
+  }
   const uint64_t npx = (uint64_t)width * (y1 - y0);
   dim3 sgrid((uint32_t)((npx + 255) / 256));
   if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl);
@@ -1315,32 +1592,10 @@ int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax
   if (mode != VXRT_MODE_CLOSEST && mode != VXRT_MODE_ANY) return -1;
   if (n == 0) return 0;
   if (n > 0x7fffffffull) return -1;
-  uint32_t* st = status_word();
-  if (!st) return -1;
   hipStream_t s = (hipStream_t)stream;
-  PersistArgs A{};
-  A.total = (uint32_t)n; A.hits = (HitRec*)hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
-  A.status = st;
-  A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
   FrameCtx* c = acquire_ctx(a, s);
   if (!c) return -1;
-  if (ensure_defer(c, A.total, s) != 0) return -1;
-  // no kernel follows the EXACT launch that could zero the control block again: it stays dirty and the
-  // next call on this context clears it with one fill (acquire_ctx)
-  c->ctl_dirty = true;
-  A.defer_count = c->ctl; A.defer_list = c->defer; A.defer_cap = A.total;
-  A.queue = c->ctl + 32;
-  PersistArgs X = A;
-  X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
-  ShadeParams p{};
-  if (a->dev.exact_decode) {
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, true, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, true, false>, n)), dim3(256), 0, s, a->dev, p, A);
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, true, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X);
-  } else {
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, false, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, false, false>, n)), dim3(256), 0, s, a->dev, p, A);
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, false, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X);
-  }
-  if (hipGetLastError() != hipSuccess) return -1;
+  if (trace_on_ctx(a, c, rays, n, tmax, (HitRec*)hits, mode, s) != 0) return -1;
   return release_ctx(c, s);
 }
 
