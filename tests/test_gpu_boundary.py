@@ -117,3 +117,21 @@ def test_host_program_renders_and_matches(vrt, po, gpu_device, tmp_path):
     rpx, _, _ = po.render(vrt.scene.procedural("cornell"), 48, 40)
     want = np.stack([(rpx >> 16) & 255, (rpx >> 8) & 255, rpx & 255], -1)[::-1]
     assert np.array_equal(vals, want)
+
+
+def test_mirror_bounce_through_vx_api(vrt, po, gpu_device):
+    """kernel_arg_t::max_depth + blas_node_t::reflectivity reach the kernels through vx_copy_to_dev /
+    vx_start exactly as the reference host passes them (tracer.cpp:217-259, main.cpp -d)."""
+    from scenes import mirror_hall
+    b = mirror_hall(vrt)
+    w, h = 128, 80
+    tr = vrt.tracer.Tracer(w, h, max_depth=3)
+    tr.init(b)
+    tr.setup(light_pos=(150.0, 220.0, -60.0))
+    px = tr.run()
+    rpx, _, _, rn = po.render_ex(b, w, h, po.shade_params(light_pos=(150.0, 220.0, -60.0), max_depth=3))
+    assert np.array_equal(px, rpx)
+    assert tr.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0) == rn > w * h
+    flat, _, _ = po.render(b, w, h, po.shade_params(light_pos=(150.0, 220.0, -60.0)))
+    assert not np.array_equal(px, flat)
+    tr.close()
