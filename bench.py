@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-seconds of host work for cpu_baseline")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="frames kept in flight on as many HIP streams (vxrt_accel_frames_in_flight); 1 = strictly serial frames")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: rehearsal of the N>1 code path where ranks share one GPU (frames gathered through host memory)")
     ap.add_argument("--random-rays", type=int, default=0, help="also time N incoherent random rays (vxrt_trace), reported under extras")
     return ap.parse_args()
 
@@ -115,11 +117,17 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU fallback for the hot path")
+    if a.dist_backend == "gloo":
+        local %= max(1, torch.cuda.device_count())   # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    cdev = dev if a.dist_backend == "nccl" else "cpu"   # where collectives' tensors live
 
     vrt = importlib.import_module("vortex-raytracing_amd")
     rtapi, sharding = vrt.rtapi, vrt.sharding
@@ -174,11 +182,12 @@ def main():
             # image assembly overlaps the next step's traversal: the gather runs on its own stream
             gather_stream.wait_stream(st)
             with torch.cuda.stream(gather_stream):
+                src = buf if cdev != "cpu" else buf.cpu()
                 if a.shard == "rows":
-                    sharding.gather_frame(buf[y0:y1], H, W, rank, world)
+                    sharding.gather_frame(src[y0:y1], H, W, rank, world)
                 else:
-                    out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-                    dist.gather(buf, out, dst=0)
+                    out = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+                    dist.gather(src, out, dst=0)
                 gdone[b] = torch.cuda.Event()
                 gdone[b].record(gather_stream)
 
@@ -208,10 +217,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rays_rank], dtype=torch.int64, device=dev)
+        r = torch.tensor([rays_rank], dtype=torch.int64, device=cdev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         rays_all = int(r.item())
     else:
