@@ -216,6 +216,22 @@ int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
                       const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                       unsigned long long* counters, void* stream);
 
+/* Ambient-occlusion frame (extension for BASELINE config 5, "16 spp Monte-Carlo AO"; the reference has no
+ * such pass, only its RNG is used: common.h:129-147).  Per pixel with a primary hit: spp cosine-weighted
+ * occlusion rays about the shading normal (tmax = radius, any-hit), pixel = Lambert colour of the hit
+ * (closest.cpp:57-127, else arm) x unoccluded / spp.  The sampling recipe is fixed in
+ * oracle/rt_oracle.c:orc_ao_ray and uses IEEE add/mul/div/sqrt only, so the frame is reproducible bit
+ * for bit.  unoccluded (optional): device u32 per pixel.  rays_traced counts primary + occlusion rays. */
+typedef struct vxrt_ao_params {
+  uint32_t spp;      /* occlusion rays per hit, 1..4096 */
+  float radius;      /* tmax of the occlusion rays, > 0 */
+  uint32_t seed;     /* user seed mixed into the per-sample WangHash seed */
+  uint32_t reserved;
+} vxrt_ao_params_t;
+int vxrt_render_ao(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                   const vxrt_shade_params_t* params, const vxrt_ao_params_t* ao, uint32_t* dst, float* colors,
+                   uint32_t* unoccluded, unsigned long long* rays_traced, void* stream);
+
 /* Diagnostic variant of vxrt_render_stats: additionally logs per wavefront of the main traversal
  * launch {first clock, last clock (100 MHz constant clock), rays started, loop iterations, runs of the
  * node body, lanes active in them, runs of the leaf body, lanes active in them, node-body runs in which

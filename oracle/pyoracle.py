@@ -69,6 +69,9 @@ def orc():
         L.orc_pack_rgb8.argtypes = [vp]
         L.orc_render.restype = C.c_int
         L.orc_render.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ShadeParams), vp, vp, vp]
+        L.orc_render_ao.restype = C.c_int
+        L.orc_render_ao.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ShadeParams), u32, C.c_float, u32,
+                                    vp, vp, vp, C.POINTER(C.c_uint64)]
         L.orc_render_ex.restype = C.c_int
         L.orc_render_ex.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ShadeParams), C.c_int, vp, vp, vp,
                                     C.POINTER(C.c_uint64)]
@@ -205,6 +208,21 @@ def render_ex(scene, w, h, params=None, shadow=0, y0=0, y1=None):
     orc().orc_render_ex(w, h, y0, y1, _p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(b["triEx"]), _p(b["mat"]),
                         _p(b["tex"]), C.byref(params), shadow, _p(px), _p(hits), _p(col), C.byref(n))
     return px, hits.reshape(h, w), col.reshape(h, w, 3), int(n.value)
+
+
+def render_ao(scene, w, h, params=None, spp=4, radius=10.0, seed=0, y0=0, y1=None):
+    """orc_render_ao: primary hit -> Lambert colour x fraction of `spp` cosine-weighted occlusion rays
+    (tmax = radius) that reach nothing.  Returns pixels, colours, unoccluded counts, rays traced."""
+    y1 = h if y1 is None else y1
+    params = params or shade_params()
+    px = np.zeros((h, w), np.uint32)
+    col = np.zeros((h * w, 3), np.float32)
+    cnt = np.zeros((h, w), np.uint32)
+    n = C.c_uint64(0)
+    b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")}
+    orc().orc_render_ao(w, h, y0, y1, _p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(b["triEx"]), _p(b["mat"]),
+                        _p(b["tex"]), C.byref(params), spp, radius, seed, _p(px), _p(col), _p(cnt), C.byref(n))
+    return px, col.reshape(h, w, 3), cnt, int(n.value)
 
 
 def shade(scene, rays, hits, params=None):

@@ -646,3 +646,99 @@ int orc_render_ex(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
   }
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Ambient occlusion (extension; BASELINE config 5 asks for "16 spp Monte-Carlo AO", the reference has
+ * no such pass).  Only the RNG is the reference's (common.h:129-147: WangHash, Marsaglia xorshift32,
+ * RandomFloat).  Everything else is defined here and mirrored operation by operation by the HIP kernel
+ * (rt_ao_rays_kernel), using only IEEE add/mul/div/sqrt so that both sides produce the same rays:
+ *   seed  = WangHash((x + y*W) * spp + s + 1 + user_seed * 0x9E3779B9), 0 -> 1
+ *   (u,v) = first of up to 8 draws of (2*RandomFloat-1, 2*RandomFloat-1) with u*u + v*v < 1, else (0,0)
+ *   z     = sqrt(1 - (u*u + v*v))                      cosine-weighted about the facing normal
+ *   N'    = shading normal flipped to face the viewer; basis of Duff et al. 2017 (no trigonometry)
+ *   ray   = (I + N'*1e-3, T*u + B*v + N'*z), tmax = radius; any accepted candidate occludes
+ *   pixel = Lambert colour of the primary hit (closest.cpp else arm) * (unoccluded / spp)
+ * ------------------------------------------------------------------------------------------- */
+static uint32_t wang_hash(uint32_t s) {            /* common.h:129-135 */
+  s = (s ^ 61) ^ (s >> 16);
+  s *= 9, s = s ^ (s >> 4);
+  s *= 0x27d4eb2d;
+  s = s ^ (s >> 15);
+  return s;
+}
+static uint32_t random_int(uint32_t* s) {          /* common.h:137-143 */
+  *s ^= *s << 13;
+  *s ^= *s >> 17;
+  *s ^= *s << 5;
+  return *s;
+}
+static float random_float(uint32_t* s) { return random_int(s) * 2.3283064365387e-10f; }   /* common.h:145-147 */
+
+void orc_ao_ray(uint32_t x, uint32_t y, uint32_t w, uint32_t spp, uint32_t s, uint32_t user_seed,
+                const float I[3], const float N[3], const float view_dir[3], float out6[6]) {
+  uint32_t seed = wang_hash((x + y * w) * spp + s + 1u + user_seed * 0x9E3779B9u);
+  if (seed == 0) seed = 1;
+  float u = 0.0f, v = 0.0f, r2 = 0.0f;
+  int ok = 0;
+  for (int i = 0; i < 8 && !ok; ++i) {
+    float a = 2.0f * random_float(&seed) - 1.0f;
+    float b = 2.0f * random_float(&seed) - 1.0f;
+    float q = a * a + b * b;
+    if (q < 1.0f) { u = a; v = b; r2 = q; ok = 1; }
+  }
+  float z = sqrtf(1.0f - r2);
+  float nx = N[0], ny = N[1], nz = N[2];
+  if (nx * view_dir[0] + ny * view_dir[1] + nz * view_dir[2] > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+  float sign = nz >= 0.0f ? 1.0f : -1.0f;
+  float a = -1.0f / (sign + nz);
+  float b = nx * ny * a;
+  float tx = 1.0f + sign * nx * nx * a, ty = sign * b, tz = -sign * nx;
+  float bx = b, by = sign + ny * ny * a, bz = -ny;
+  out6[0] = I[0] + nx * 0.001f; out6[1] = I[1] + ny * 0.001f; out6[2] = I[2] + nz * 0.001f;
+  out6[3] = tx * u + bx * v + nx * z;
+  out6[4] = ty * u + by * v + ny * z;
+  out6[5] = tz * u + bz * v + nz * z;
+}
+
+int orc_render_ao(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
+                  const orc_node_t* tlas, const orc_blas_t* blas, const orc_node_t* bvh,
+                  const orc_tri_t* tri, const orc_triex_t* triEx, const orc_material_t* mat,
+                  const uint8_t* tex, const orc_shade_params_t* p, uint32_t spp, float radius, uint32_t user_seed,
+                  uint32_t* out_pixels, float* out_color, uint32_t* out_unoccluded, uint64_t* n_rays) {
+  if (n_rays) *n_rays = 0;
+  for (uint32_t y = y0; y < y1; ++y) {
+    for (uint32_t x = 0; x < w; ++x) {
+      float ray[6];
+      orc_generate_ray(x, y, w, h, ray);
+      orc_hit_t hit;
+      orc_trace_canonical(tlas, blas, bvh, tri, ray, 1, NULL, &hit, NULL, 0);
+      if (n_rays) ++*n_rays;
+      uint64_t idx = (uint64_t)x + (uint64_t)y * w;
+      float col[3];
+      uint32_t open = 0;
+      if (hit.dist == ORC_LARGE_FLOAT) {
+        orc_shade(ray, &hit, blas, triEx, mat, tex, p, col);   /* background, no AO */
+      } else {
+        f3 term, I, N;
+        float refl;
+        shade_terms(ray, &hit, blas, triEx, mat, tex, p, 0, &term, &refl, &I, &N);
+        orc_shade(ray, &hit, blas, triEx, mat, tex, p, col);
+        float If[3] = {I.x, I.y, I.z}, Nf[3] = {N.x, N.y, N.z};
+        for (uint32_t s = 0; s < spp; ++s) {
+          float ao[6];
+          orc_ao_ray(x, y, w, spp, s, user_seed, If, Nf, ray + 3, ao);
+          orc_hit_t oh;
+          orc_trace_canonical(tlas, blas, bvh, tri, ao, 1, &radius, &oh, NULL, 1);
+          if (n_rays) ++*n_rays;
+          if (oh.dist == ORC_LARGE_FLOAT) ++open;
+        }
+        float f = (float)open / (float)spp;
+        col[0] *= f; col[1] *= f; col[2] *= f;
+      }
+      out_pixels[idx] = orc_pack_rgb8(col);
+      if (out_color) { out_color[3 * idx] = col[0]; out_color[3 * idx + 1] = col[1]; out_color[3 * idx + 2] = col[2]; }
+      if (out_unoccluded) out_unoccluded[idx] = open;
+    }
+  }
+  return 0;
+}

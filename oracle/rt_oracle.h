@@ -134,6 +134,17 @@ int orc_render_ex(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
                   uint32_t* out_pixels, orc_hit_t* out_hits /* may be NULL */, float* out_color /* may be NULL */,
                   uint64_t* n_rays /* may be NULL */);
 
+/* Ambient-occlusion pass (extension; definition in rt_oracle.c).  Only the RNG is the reference's
+ * (common.h:129-147); the checker and the HIP kernel share the sampling recipe operation by operation. */
+void orc_ao_ray(uint32_t x, uint32_t y, uint32_t w, uint32_t spp, uint32_t s, uint32_t user_seed,
+                const float I[3], const float N[3], const float view_dir[3], float out6[6]);
+int orc_render_ao(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
+                  const orc_node_t* tlas, const orc_blas_t* blas, const orc_node_t* bvh,
+                  const orc_tri_t* tri, const orc_triex_t* triEx, const orc_material_t* mat,
+                  const uint8_t* tex, const orc_shade_params_t* p, uint32_t spp, float radius, uint32_t user_seed,
+                  uint32_t* out_pixels, float* out_color /* may be NULL */, uint32_t* out_unoccluded /* may be NULL */,
+                  uint64_t* n_rays /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -341,3 +341,35 @@ def test_mirror_bounce_matches_oracle(vrt, po, gpu_device, depth, shadow):
     if depth > 1:
         flat, _, fcol, fn = po.render_ex(b, w, h, po.shade_params(light_pos=tuple(p.light_pos), max_depth=1), shadow)
         assert rn > fn and (rcol != fcol).any()          # the bounce really contributes
+
+
+@pytest.mark.parametrize("spp,radius", [(1, 25.0), (4, 60.0), (16, 15.0)])
+def test_ambient_occlusion_pass_matches_oracle(vrt, po, gpu_device, spp, radius):
+    """vxrt_render_ao (extension for BASELINE config 5): the sampling recipe uses the reference RNG
+    (common.h:129-147) and IEEE add/mul/div/sqrt only, so device and checker generate the same occlusion
+    rays: unoccluded counts, ray totals and pixels are equal, colours within the colour tolerance."""
+    import torch
+    from scenes import mirror_hall
+    b = mirror_hall(vrt, 0.0, 0.0)
+    ds = vrt.tracer.DeviceScene(b, gpu_device)
+    w, h = 144, 88
+    p = vrt.rtapi.default_shade_params()
+    p.light_pos[:] = (150.0, 220.0, -60.0)
+    dev = gpu_device
+    px = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    col = torch.zeros(h * w * 3, dtype=torch.float32, device=dev)
+    cnt = torch.full((h, w), -1, dtype=torch.int32, device=dev)
+    nr = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.render_ao(ds.accel, w, h, 0, h, p, spp, radius, px.data_ptr(), seed=7, colors_ptr=col.data_ptr(),
+                        unoccluded_ptr=cnt.data_ptr(), rays_ptr=nr.data_ptr(), stream=stream)
+    assert vrt.rtapi.status(stream) == 0
+    rpx, rcol, rcnt, rn = po.render_ao(b, w, h, po.shade_params(light_pos=tuple(p.light_pos)), spp=spp, radius=radius, seed=7)
+    np.testing.assert_array_equal(cnt.cpu().numpy().view(np.uint32), rcnt)
+    assert int(nr.item()) == rn
+    np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3), rcol, rtol=COLOR_RTOL)
+    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), rpx)
+    hit = rn > w * h
+    assert hit and (rcnt < spp).any() and (rcnt == spp).any()     # some occlusion, some open sky
+    with pytest.raises(vrt.runtime.VxError):
+        vrt.rtapi.render_ao(ds.accel, w, h, 0, h, p, 0, radius, px.data_ptr(), stream=stream)

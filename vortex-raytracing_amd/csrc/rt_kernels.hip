@@ -978,6 +978,129 @@ __global__ __launch_bounds__(256) void rt_bounce_unwind_kernel(uint32_t n, const
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ambient occlusion (extension, BASELINE config 5; recipe defined in oracle/rt_oracle.c:orc_ao_ray and
+// mirrored here operation by operation -- RNG of common.h:129-147, rejection-sampled disk, Duff basis:
+// only IEEE add/mul/div/sqrt, so host and device produce the same rays).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wang_hash(uint32_t s) {   // common.h:129-135
+  s = (s ^ 61u) ^ (s >> 16);
+  s *= 9u; s = s ^ (s >> 4);
+  s *= 0x27d4eb2du;
+  s = s ^ (s >> 15);
+  return s;
+}
+__device__ __forceinline__ float random_float(uint32_t& s) {   // common.h:137-147
+  s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+  return (float)s * 2.3283064365387e-10f;
+}
+
+// per pixel of rows [y0,y1): Lambert colour of the primary hit (else arm of closest.cpp), hit point and
+// shading normal for the occlusion rays; geo[e] = (I, hit?) , nrm[e] = (N, 0), col[e] = (rgb, 0); cnt = 0
+__global__ __launch_bounds__(256) void rt_ao_prepare_kernel(SceneDev sc, ShadeParams p, uint64_t n, uint32_t W, uint32_t y0,
+    const float* __restrict__ utab, const float* __restrict__ vtab, const HitRec* __restrict__ hb,
+    float4* __restrict__ geo, float4* __restrict__ nrm, float4* __restrict__ col, uint32_t* __restrict__ cnt, uint32_t* ctl_reset) {
+  if (ctl_reset && blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < CTL_DWORDS; i += 256u) ctl_reset[i] = 0u;
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
+  const size_t e = (size_t)x + (size_t)y * W;
+  HitRec h = hb[e];
+  h.blasIdx &= 0x7fffffffu;
+  float ox, oy, oz, dx, dy, dz;
+  generate_ray(utab[x], vtab[y], ox, oy, oz, dx, dy, dz);
+  float r, g, b;
+  if (h.dist == RT_LARGE_FLOAT) {
+    r = p.bg[0]; g = p.bg[1]; b = p.bg[2];
+    geo[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    nrm[t] = make_float4(0.f, 0.f, 1.f, 0.f);
+  } else {
+    float refl, Ix, Iy, Iz, Nx, Ny, Nz;
+    shade_terms<false>(sc, p, ox, oy, oz, dx, dy, dz, h, false, r, g, b, refl, Ix, Iy, Iz, Nx, Ny, Nz);
+    float thr = 1.0f;
+    thr *= refl;
+    r = r + p.bg[0] * thr; g = g + p.bg[1] * thr; b = b + p.bg[2] * thr;
+    geo[t] = make_float4(Ix, Iy, Iz, 1.0f);
+    nrm[t] = make_float4(Nx, Ny, Nz, 0.f);
+  }
+  col[t] = make_float4(r, g, b, 0.f);
+  cnt[t] = 0u;
+}
+
+// sample s of every pixel: occlusion ray + tmax (a pixel without a hit gets a ray nothing can hit)
+__global__ __launch_bounds__(256) void rt_ao_rays_kernel(uint64_t n, uint32_t W, uint32_t y0, const float* __restrict__ utab, const float* __restrict__ vtab,
+    const float4* __restrict__ geo, const float4* __restrict__ nrm, uint32_t spp, uint32_t smp, uint32_t user_seed, float radius,
+    float* __restrict__ rays, float* __restrict__ tmax) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= n) return;
+  float* o = rays + (size_t)t * 6;
+  const float4 gI = geo[t];
+  if (gI.w == 0.f) {
+    o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 1.f; o[4] = 1.f; o[5] = 1.f;
+    tmax[t] = -1.0f;
+    return;
+  }
+  const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
+  float ox, oy, oz, vdx, vdy, vdz;
+  generate_ray(utab[x], vtab[y], ox, oy, oz, vdx, vdy, vdz);
+  uint32_t seed = wang_hash((x + y * W) * spp + smp + 1u + user_seed * 0x9E3779B9u);
+  if (seed == 0u) seed = 1u;
+  float u = 0.0f, v = 0.0f, r2 = 0.0f;
+  bool ok = false;
+  for (int i = 0; i < 8 && !ok; ++i) {
+    const float a = 2.0f * random_float(seed) - 1.0f;
+    const float b = 2.0f * random_float(seed) - 1.0f;
+    const float q = a * a + b * b;
+    if (q < 1.0f) { u = a; v = b; r2 = q; ok = true; }
+  }
+  const float z = sqrtf(1.0f - r2);
+  const float4 gN = nrm[t];
+  float nx = gN.x, ny = gN.y, nz = gN.z;
+  if (nx * vdx + ny * vdy + nz * vdz > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+  const float sign = nz >= 0.0f ? 1.0f : -1.0f;
+  const float a = -1.0f / (sign + nz);
+  const float b = nx * ny * a;
+  const float tx = 1.0f + sign * nx * nx * a, ty = sign * b, tz = -sign * nx;
+  const float bx = b, by = sign + ny * ny * a, bz = -ny;
+  o[0] = gI.x + nx * 0.001f; o[1] = gI.y + ny * 0.001f; o[2] = gI.z + nz * 0.001f;
+  o[3] = tx * u + bx * v + nx * z;
+  o[4] = ty * u + by * v + ny * z;
+  o[5] = tz * u + bz * v + nz * z;
+  tmax[t] = radius;
+}
+
+__global__ __launch_bounds__(256) void rt_ao_accumulate_kernel(uint64_t n, const float4* __restrict__ geo, const HitRec* __restrict__ ohits, uint32_t* __restrict__ cnt) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= n) return;
+  if (geo[t].w != 0.f && ohits[t].dist == RT_LARGE_FLOAT) cnt[t] += 1u;
+}
+
+__global__ __launch_bounds__(256) void rt_ao_final_kernel(uint64_t n, uint32_t W, uint32_t y0, const float4* __restrict__ geo, const float4* __restrict__ col,
+    const uint32_t* __restrict__ cnt, uint32_t spp, uint32_t* __restrict__ dst, float* __restrict__ colors_out, uint32_t* __restrict__ unoccluded,
+    unsigned long long* rays_traced) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  bool hit = false;
+  if (t < n) {
+    const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
+    const size_t e = (size_t)x + (size_t)y * W;
+    const float4 c = col[t];
+    float r = c.x, g = c.y, b = c.z;
+    uint32_t open = 0u;
+    if (geo[t].w != 0.f) {
+      hit = true;
+      open = cnt[t];
+      const float f = (float)open / (float)spp;
+      r *= f; g *= f; b *= f;
+    }
+    dst[e] = pack_rgb8(r, g, b);
+    if (colors_out) { colors_out[3 * e] = r; colors_out[3 * e + 1] = g; colors_out[3 * e + 2] = b; }
+    if (unoccluded) unoccluded[e] = open;
+  }
+  const unsigned long long m = __ballot(hit);
+  if (rays_traced && (threadIdx.x & 63u) == 0u && m) atomicAdd(rays_traced, (unsigned long long)__popcll(m) * spp);
+}
+
 __global__ void add_counter_kernel(unsigned long long* c, unsigned long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(c, v); }
 
 // ---------------------------------------------------------------------------------------------
@@ -1167,6 +1290,9 @@ struct FrameCtx {
   };
   std::vector<Level> lv;
   uint32_t* bcount = nullptr;  // device: rays appended to the level being built
+  // ambient-occlusion pass (allocated on first use), one entry per pixel of the window
+  float4* ao_geo = nullptr; float4* ao_nrm = nullptr; float4* ao_col = nullptr; uint32_t* ao_cnt = nullptr;
+  float* ao_rays = nullptr; float* ao_tmax = nullptr; HitRec* ao_hits = nullptr; uint64_t ao_cap = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr;
   bool busy = false;
@@ -1196,6 +1322,7 @@ static void accel_free(vxrt_accel* a) {
   (void)hipFree(a->uvtab); (void)hipFree(a->apriori);
   for (FrameCtx& c : a->ctx) {
     (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount);
+    (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits);
     for (FrameCtx::Level& l : c.lv) {
       (void)hipFree(l.rays); (void)hipFree(l.hits); (void)hipFree(l.parent); (void)hipFree(l.term); (void)hipFree(l.col);
       (void)hipFree(l.srays); (void)hipFree(l.stmax); (void)hipFree(l.shits);
@@ -1445,10 +1572,45 @@ static int render_bounce_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Tail of an ambient-occlusion frame (replaces the plain shading pass): per sample one ray buffer of
+// the window's pixels traced in any-hit mode.  No host synchronisation.
+static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, uint32_t width, uint32_t y0, uint32_t y1,
+                          const vxrt_ao_params_t* ao, const float* utab, const float* vtab, uint32_t* dst, float* colors,
+                          uint32_t* unoccluded, unsigned long long* rays_traced, hipStream_t s) {
+  const SceneDev& sc = a->dev;
+  const uint64_t n = (uint64_t)width * (y1 - y0);
+  if (n > 0x7fffffffull || ao->spp == 0) return -1;
+  if (c->ao_cap < n) {
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    const uint64_t have = c->ao_cap;
+    bool ok = grow_buf((void**)&c->ao_geo, have, n, 16) && grow_buf((void**)&c->ao_nrm, have, n, 16) && grow_buf((void**)&c->ao_col, have, n, 16) &&
+              grow_buf((void**)&c->ao_cnt, have, n, 4) && grow_buf((void**)&c->ao_rays, have, n, 24) && grow_buf((void**)&c->ao_tmax, have, n, 4) &&
+              grow_buf((void**)&c->ao_hits, have, n, sizeof(HitRec));
+    if (!ok) return -1;
+    c->ao_cap = n;
+  }
+  const dim3 block(256), grid((uint32_t)((n + 255) / 256));
+  hipLaunchKernelGGL(rt_ao_prepare_kernel, grid, block, 0, s, sc, p, n, width, y0, utab, vtab, (const HitRec*)c->hitbuf,
+                     c->ao_geo, c->ao_nrm, c->ao_col, c->ao_cnt, c->ctl);
+  if (hipGetLastError() != hipSuccess) return -1;
+  c->ctl_dirty = false;
+  for (uint32_t smp = 0; smp < ao->spp; ++smp) {
+    hipLaunchKernelGGL(rt_ao_rays_kernel, grid, block, 0, s, n, width, y0, utab, vtab, (const float4*)c->ao_geo, (const float4*)c->ao_nrm,
+                       ao->spp, smp, ao->seed, ao->radius, c->ao_rays, c->ao_tmax);
+    if (trace_on_ctx(a, c, c->ao_rays, n, c->ao_tmax, c->ao_hits, VXRT_MODE_ANY, s) != 0) return -1;
+    hipLaunchKernelGGL(rt_ao_accumulate_kernel, grid, block, 0, s, n, (const float4*)c->ao_geo, (const HitRec*)c->ao_hits, c->ao_cnt);
+  }
+  hipLaunchKernelGGL(rt_ao_final_kernel, grid, block, 0, s, n, width, y0, (const float4*)c->ao_geo, (const float4*)c->ao_col, (const uint32_t*)c->ao_cnt,
+                     ao->spp, dst, colors, unoccluded, rays_traced);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits, float* colors,
-                         unsigned long long* counters, bool stats, void* stream, unsigned long long* wave_log = nullptr) {
+                         unsigned long long* counters, bool stats, void* stream, unsigned long long* wave_log = nullptr,
+                         const vxrt_ao_params_t* ao = nullptr, uint32_t* unoccluded = nullptr) {
   if (!a || !params || !dst) return -1;
+  if (ao && (stats || shadow)) return -1;
   if (!a->ref.triEx || !a->ref.mat || a->ref.n_mats == 0) return -1;  // shading needs them (closest.cpp:52-55)
   if (width == 0 || height == 0 || y0 > y1 || y1 > height) return -1;
   if (stats && !counters) return -1;
@@ -1547,6 +1709,10 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   if (side_launch) {
     if (hipEventRecord(c->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, c->ev_side, 0) != hipSuccess) return -1;
   }
+  if (ao) {
+    if (render_ao_tail(a, c, p, width, y0, y1, ao, A.utab, A.vtab, dst, colors, unoccluded, counters, s) != 0) return -1;
+    return release_ctx(c, s);
+  }
   if (p.max_depth > 1 && a->max_reflectivity > 0.0f) {
     // reflective instances: the shading pass becomes the level-0 step of the mirror-bounce wavefront
     if (stats) return -1;   // the counting build prices the single-level frame only
@@ -1584,6 +1750,13 @@ int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, u
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                          unsigned long long* counters, unsigned long long* wave_log, void* stream) {
   return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream, wave_log);
+}
+
+int vxrt_render_ao(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                   const vxrt_shade_params_t* params, const vxrt_ao_params_t* ao, uint32_t* dst, float* colors,
+                   uint32_t* unoccluded, unsigned long long* rays_traced, void* stream) {
+  if (!ao || ao->spp == 0 || ao->spp > 4096 || !(ao->radius > 0.0f)) return -1;
+  return render_common(accel, width, height, y0, y1, params, 0, dst, nullptr, colors, rays_traced, false, stream, nullptr, ao, unoccluded);
 }
 
 int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax,

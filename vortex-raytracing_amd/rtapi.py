@@ -50,6 +50,9 @@ def _lib():
         L.vxrt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vxrt_render_stats.restype = C.c_int
+        L.vxrt_render_ao.restype = C.c_int
+        L.vxrt_render_ao.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ShadeParams),
+                                     C.POINTER(AoParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vxrt_render_stats.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vxrt_trace.restype = C.c_int
@@ -86,6 +89,18 @@ def accel_bytes(accel):
 def render(accel, width, height, y0, y1, params, dst_ptr, shadow=0, hits_ptr=None, colors_ptr=None, rays_ptr=None, stream=None):
     check(_lib().vxrt_render(accel, width, height, y0, y1, C.byref(params), int(shadow), dst_ptr, hits_ptr,
                              colors_ptr, rays_ptr, stream), "vxrt_render")
+
+
+class AoParams(C.Structure):   # vxrt_ao_params_t
+    _fields_ = [("spp", C.c_uint32), ("radius", C.c_float), ("seed", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def render_ao(accel, width, height, y0, y1, params, spp, radius, dst_ptr, seed=0, colors_ptr=None, unoccluded_ptr=None,
+              rays_ptr=None, stream=None):
+    """vxrt_render_ao: primary hit -> Lambert colour x fraction of `spp` occlusion rays (tmax = radius) that reach nothing."""
+    ao = AoParams(int(spp), float(radius), int(seed), 0)
+    check(_lib().vxrt_render_ao(accel, width, height, y0, y1, C.byref(params), C.byref(ao), dst_ptr, colors_ptr,
+                                unoccluded_ptr, rays_ptr, stream), "vxrt_render_ao")
 
 
 STAT_KEYS = ("rays", "node_fetches", "inst_fetches", "tri_fetches", "shaded_hits", "textured_hits", "pixels")
