@@ -77,12 +77,12 @@ def build(force=False, verbose=True):
     scene_so = os.path.join(LIB, "libvxrt_scene.so")
     scene_src = [os.path.join(CSRC, "scene_builder.cpp")]
     if force or _newer(scene_so, scene_src + hdrs):
-        _run(["g++"] + CXX_FLAGS + ["-shared", "-o", scene_so] + scene_src)
+        _run(["g++"] + CXX_FLAGS + ["-pthread", "-shared", "-o", scene_so] + scene_src)
 
     host = os.path.join(LIB, "rt_host")
     host_src = [os.path.join(CSRC, "rt_host.cpp")]
     if os.path.exists(host_src[0]) and (force or _newer(host, host_src + hdrs + [stub_so, scene_so])):
-        _run(["g++"] + CXX_FLAGS + ["-o", host] + host_src + ["-L" + LIB, "-lvortex", "-lvxrt_scene", "-Wl,-rpath,$ORIGIN"])
+        _run(["g++"] + CXX_FLAGS + ["-o", host] + host_src + ["-L" + LIB, "-lvortex", "-lvxrt_scene", "-pthread", "-Wl,-rpath,$ORIGIN"])
 
     write_selectors()
     return {"hip": hip_so, "stub": stub_so, "scene": scene_so}

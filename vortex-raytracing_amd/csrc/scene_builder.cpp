@@ -12,6 +12,7 @@
 // Also holds the deterministic procedural scenes of SURVEY.md s8d (none of Sponza/bunny/hairball
 // exist offline) and a minimal OBJ/MTL reader for the reference's own small assets.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,8 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 #include "rt_types.h"
 
@@ -42,6 +45,7 @@ static int kBins = 16;      // reference: 8 (bvh.cpp:8); 16 gives 6 % fewer node
 static float kLeafK = 1.0f;  // keep <= kLeafMax triangles in one leaf when the best split saves less than kLeafK node-areas
                              // (reference: always split, i.e. 0; VXS_LEAF_K overrides): -9 % node visits, +15 % triangle tests
 static int kLeafMax = 4;
+static int kThreads = 8;     // worker threads of the BLAS builder (VXS_THREADS overrides; the tree and its layout do not depend on it)
 static int kWiden = 0;      // 0: widen the cluster with the largest SAH gain (reference), 1: the one with the largest area
 
 struct Box {
@@ -82,7 +86,47 @@ public:
     nodes_.emplace_back();
     nodes_[0].leftFirst = 0;
     nodes_[0].triCount = n;
-    subdivide(0, 0);
+    // Top of the tree serially; subtrees below `defer_below` triangles are built by worker threads into
+    // private node arrays (their triangle ranges are disjoint, so the in-place reorder needs no locks)
+    // and appended in the order the serial pass met them: the layout does not depend on the thread count.
+    const uint32_t defer_below = std::max<uint32_t>(4096u, n / 256u);
+    std::vector<std::pair<uint32_t, uint32_t>> deferred;   // (node index, depth)
+    subdivide(nodes_, 0, 0, max_depth_, defer_below, &deferred);
+    if (!deferred.empty()) {
+      std::vector<std::vector<WideNode>> sub(deferred.size());
+      std::vector<uint32_t> subdepth(deferred.size(), 0);
+      std::vector<size_t> order(deferred.size());
+      for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+        return nodes_[deferred[x].first].triCount > nodes_[deferred[y].first].triCount; });   // big subtrees first
+      std::atomic<size_t> next{0};
+      auto work = [&]() {
+        for (;;) {
+          const size_t k = next.fetch_add(1);
+          if (k >= order.size()) break;
+          const size_t t = order[k];
+          sub[t].reserve(2 * (size_t)nodes_[deferred[t].first].triCount + 1);
+          sub[t].push_back(nodes_[deferred[t].first]);
+          subdivide(sub[t], 0, deferred[t].second, subdepth[t], 0u, nullptr);
+        }
+      };
+      const int nthreads = (int)std::min<size_t>((size_t)kThreads, deferred.size());
+      std::vector<std::thread> pool;
+      for (int i = 1; i < nthreads; ++i) pool.emplace_back(work);
+      work();
+      for (auto& th : pool) th.join();
+      for (size_t t = 0; t < deferred.size(); ++t) {
+        const uint32_t root = deferred[t].first;
+        const uint32_t base = (uint32_t)nodes_.size();          // local index i >= 1 -> base + i - 1
+        std::vector<WideNode>& L = sub[t];
+        for (size_t i = 0; i < L.size(); ++i)
+          if (L[i].triCount == 0 && L[i].childCount != 0) L[i].leftFirst += base - 1;
+        nodes_[root] = L[0];
+        nodes_.insert(nodes_.end(), L.begin() + 1, L.end());
+        max_depth_ = std::max(max_depth_, subdepth[t]);
+        std::vector<WideNode>().swap(L);
+      }
+    }
   }
   std::vector<WideNode> nodes_;
   uint32_t max_depth_ = 0;
@@ -152,12 +196,14 @@ private:
     return (uint32_t)i;
   }
 
-  void subdivide(uint32_t idx, uint32_t depth) {
-    max_depth_ = std::max(max_depth_, depth);
-    bounds(nodes_[idx]);
-    if (nodes_[idx].triCount <= 1) return;
+  void subdivide(std::vector<WideNode>& nodes, uint32_t idx, uint32_t depth, uint32_t& maxd, uint32_t defer_below,
+                 std::vector<std::pair<uint32_t, uint32_t>>* deferred) {
+    maxd = std::max(maxd, depth);
+    bounds(nodes[idx]);
+    if (nodes[idx].triCount <= 1) return;
+    if (deferred && depth > 0 && nodes[idx].triCount < defer_below) { deferred->push_back({idx, depth}); return; }
     std::vector<WideNode> cl;
-    cl.push_back(nodes_[idx]);
+    cl.push_back(nodes[idx]);
     while (cl.size() < RT_BVH_WIDTH) {
       Split bs; float bestDelta = 0.f; int bi = -1;
       for (int i = 0; i < (int)cl.size(); ++i) {
@@ -168,8 +214,8 @@ private:
         // and split cost in half-areas (common.h:81-83 vs bvh.h:24-27) - kept, it biases to leaves
         float delta = 2.0f * cl[i].box.half_area() * cl[i].triCount - s.cost;
         if (delta <= 0.f) continue;
-        // SAH leaf termination (extension, off by default): a leaf of a few triangles is cheaper to
-        // intersect than another 4-wide node when the split barely separates them
+        // SAH leaf termination (extension): a leaf of a few triangles is cheaper to intersect than
+        // another 4-wide node when the split barely separates them
         if (kLeafK > 0.f && (int)cl[i].triCount <= kLeafMax &&
             s.cost >= cl[i].box.half_area() * ((float)cl[i].triCount - kLeafK)) continue;
         if (kWiden == 1) delta = cl[i].box.half_area();
@@ -187,17 +233,17 @@ private:
       cl.push_back(R);
     }
     if (cl.size() == 1) return;   // leaf with several triangles
-    const uint32_t first = (uint32_t)nodes_.size();
+    const uint32_t first = (uint32_t)nodes.size();
     for (size_t i = 0; i < cl.size(); ++i) {
-      nodes_.emplace_back();
-      nodes_.back().leftFirst = cl[i].leftFirst;
-      nodes_.back().triCount = cl[i].triCount;
+      nodes.emplace_back();
+      nodes.back().leftFirst = cl[i].leftFirst;
+      nodes.back().triCount = cl[i].triCount;
     }
     const uint32_t cc = (uint32_t)cl.size();
-    for (uint32_t i = 0; i < cc; ++i) subdivide(first + i, depth + 1);
-    nodes_[idx].triCount = 0;
-    nodes_[idx].leftFirst = first;
-    nodes_[idx].childCount = cc;
+    for (uint32_t i = 0; i < cc; ++i) subdivide(nodes, first + i, depth + 1, maxd, defer_below, deferred);
+    nodes[idx].triCount = 0;
+    nodes[idx].leftFirst = first;
+    nodes[idx].childCount = cc;
   }
 
   rt_tri_t* tri_;
@@ -735,6 +781,8 @@ extern "C" {
 static void read_knobs() {
   if (const char* e = std::getenv("VXS_BINS")) { int v = std::atoi(e); if (v >= 2 && v <= kMaxBins) kBins = v; }
   if (const char* e = std::getenv("VXS_WIDEN")) kWiden = std::atoi(e);
+  { unsigned hc = std::thread::hardware_concurrency(); kThreads = (int)std::min<unsigned>(hc ? hc : 1u, 16u); }
+  if (const char* e = std::getenv("VXS_THREADS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) kThreads = v; }
   if (const char* e = std::getenv("VXS_LEAF_K")) kLeafK = (float)std::atof(e);
   if (const char* e = std::getenv("VXS_LEAF_MAX")) kLeafMax = std::atoi(e);
 }
