@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""The other BASELINE.json configurations, measured once each on one MI355X (they are parity-test cases, not the
+bench line): prints one JSON object per configuration.  usage: python tools/config_bench.py [2] [4] [5] [--hair-strands N]"""
+import argparse, importlib, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+vrt = importlib.import_module("vortex-raytracing_amd")
+rtapi = vrt.rtapi
+dev = "cuda:0"
+
+
+def timed(fn, steps, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def render_cfg(tag, scene, W, H, light, steps):
+    ds = vrt.tracer.DeviceScene(scene, dev)
+    p = rtapi.default_shade_params()
+    p.light_pos[:] = light
+    px = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    rtapi.render(ds.accel, W, H, 0, H, p, px.data_ptr(), 1, None, None, cnt.data_ptr(), s)
+    torch.cuda.synchronize()
+    rays = int(cnt.item())
+    ms = timed(lambda: rtapi.render(ds.accel, W, H, 0, H, p, px.data_ptr(), 1, None, None, None, s), steps)
+    hit = float((px != px[0, 0]).float().mean().item())
+    return {"config": tag, "tris": scene.n_tris, "resolution": [W, H], "rays_per_frame": rays, "ms_per_frame_serial": round(ms, 4),
+            "mrays_s": round(rays / ms / 1e3, 1), "non_background_fraction": round(hit, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="*", type=int, default=[2, 4, 5])
+    ap.add_argument("--hair-strands", type=int, default=20000)   # x 250 segments x 2 = 10 M triangles
+    a = ap.parse_args()
+    out = []
+    if 2 in a.configs:
+        sc = vrt.scene.procedural("blob", 6, 0, 1)     # 81,920-triangle "bunny-class" blob
+        out.append(render_cfg("configs[1]: bunny-class, 1024x1024, primary + 1 shadow ray", sc, 1024, 1024, (60.0, 260.0, -150.0), 50))
+    if 4 in a.configs:
+        sc = vrt.scene.procedural("atrium", 8, 0, 3)
+        out.append(render_cfg("configs[3] on one GPU: Sponza-class, 3840x2160, primary + 1 shadow ray (the 8-GPU split is bench.py --shard rows)", sc, 3840, 2160, (300.0, 480.0, 60.0), 20))
+    if 5 in a.configs:
+        t0 = time.time()
+        sc = vrt.scene.procedural("hairball", a.hair_strands, 250, 7)
+        build_s = time.time() - t0
+        ds = vrt.tracer.DeviceScene(sc, dev)
+        W, H, spp = 1920, 1080, 16
+        b = sc.bounds
+        radius = 0.25 * 0.5 * float(np.linalg.norm(np.array(b[3:]) - np.array(b[:3])))
+        p = rtapi.default_shade_params()
+        p.light_pos[:] = (0.0, 400.0, 0.0)
+        px = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        rtapi.render_ao(ds.accel, W, H, 0, H, p, spp, radius, px.data_ptr(), seed=7, rays_ptr=cnt.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        assert rtapi.status(s) == 0
+        rays = int(cnt.item())
+        ms = timed(lambda: rtapi.render_ao(ds.accel, W, H, 0, H, p, spp, radius, px.data_ptr(), seed=7, stream=s), 5, 1)
+        out.append({"config": "configs[4]: hairball, 1920x1080, 16 spp AO (tmax = 0.25 scene radius)", "tris": sc.n_tris, "bvh_nodes": sc.n_bvh_nodes,
+                    "bvh_depth": sc.info.get("max_depth"), "host_build_s": round(build_s, 1), "rays_per_frame": rays,
+                    "ms_per_frame": round(ms, 3), "mrays_s": round(rays / ms / 1e3, 1)})
+    for o in out:
+        print(json.dumps(o), flush=True)
+
+
+if __name__ == "__main__":
+    main()

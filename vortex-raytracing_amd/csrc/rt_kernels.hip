@@ -425,7 +425,8 @@ enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2 };
 
 struct PersistArgs {
   uint32_t W, H, y0, y1, tiles_x;
-  uint32_t total;                 // number of jobs (tiles*64 pixels, or rays)
+  uint32_t total;                 // number of jobs (tiles*64 pixels, or rays); an upper bound when total_dev is set
+  const uint32_t* total_dev;      // optional: the job count lives in device memory (produced by an earlier kernel of the stream)
   HitRec* hits;                   // render: W*H hit records (occlusion in bit 31 of blasIdx); trace: n records
   const float* rays; const float* tmax; int any_hit;   // trace inputs
   unsigned long long* counters;   // [0] rays (+ STATS: [1..4])
@@ -466,8 +467,8 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
   constexpr uint32_t FINISH_MIN = JOB == JOB_RENDER_SHADOW ? RT_SHADOW_FINISH_MIN : 65u;
   const uint32_t lane = threadIdx.x & 63u;
   // EXACT launch: the jobs are the entries of the deferral list the main launch left behind
-  const uint32_t n_jobs = EXACT ? min(*A.defer_count, A.defer_cap) : A.total;
-  const uint32_t per_shard = EXACT ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
+  const uint32_t n_jobs = EXACT ? min(*A.defer_count, A.defer_cap) : (A.total_dev ? min(*A.total_dev, A.total) : A.total);
+  const uint32_t per_shard = (EXACT || A.total_dev) ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
 
   __shared__ uint2 s_stk[4][LDS_STACK][64];   // stack levels below the register top, 8 B entries, conflict-free rows
   __shared__ uint32_t s_ctx[4][9][64];        // 0-2 active dir, 3-5 hit bx/by/bz, 6 hit blasIdx, 7 hit triIdx, 8 blasIdx
@@ -996,59 +997,71 @@ __device__ __forceinline__ float random_float(uint32_t& s) {   // common.h:137-1
 }
 
 // per pixel of rows [y0,y1): Lambert colour of the primary hit (else arm of closest.cpp), hit point and
-// shading normal for the occlusion rays; geo[e] = (I, hit?) , nrm[e] = (N, 0), col[e] = (rgb, 0); cnt = 0
+// shading normal for the occlusion rays; geo[t] = (I, hit?), nrm[t] = (N, 0), col[t] = (rgb, 0), cnt[t] = 0;
+// pixels with a hit are appended to list[] (count in hdr[0]; the order is arbitrary, nothing depends on it)
 __global__ __launch_bounds__(256) void rt_ao_prepare_kernel(SceneDev sc, ShadeParams p, uint64_t n, uint32_t W, uint32_t y0,
     const float* __restrict__ utab, const float* __restrict__ vtab, const HitRec* __restrict__ hb,
-    float4* __restrict__ geo, float4* __restrict__ nrm, float4* __restrict__ col, uint32_t* __restrict__ cnt, uint32_t* ctl_reset) {
+    float4* __restrict__ geo, float4* __restrict__ nrm, float4* __restrict__ col, uint32_t* __restrict__ cnt,
+    uint32_t* __restrict__ list, uint32_t* hdr, uint32_t* ctl_reset) {
   if (ctl_reset && blockIdx.x == 0)
     for (uint32_t i = threadIdx.x; i < CTL_DWORDS; i += 256u) ctl_reset[i] = 0u;
   const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (t >= n) return;
-  const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
-  const size_t e = (size_t)x + (size_t)y * W;
-  HitRec h = hb[e];
-  h.blasIdx &= 0x7fffffffu;
-  float ox, oy, oz, dx, dy, dz;
-  generate_ray(utab[x], vtab[y], ox, oy, oz, dx, dy, dz);
-  float r, g, b;
-  if (h.dist == RT_LARGE_FLOAT) {
-    r = p.bg[0]; g = p.bg[1]; b = p.bg[2];
-    geo[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    nrm[t] = make_float4(0.f, 0.f, 1.f, 0.f);
-  } else {
-    float refl, Ix, Iy, Iz, Nx, Ny, Nz;
-    shade_terms<false>(sc, p, ox, oy, oz, dx, dy, dz, h, false, r, g, b, refl, Ix, Iy, Iz, Nx, Ny, Nz);
-    float thr = 1.0f;
-    thr *= refl;
-    r = r + p.bg[0] * thr; g = g + p.bg[1] * thr; b = b + p.bg[2] * thr;
-    geo[t] = make_float4(Ix, Iy, Iz, 1.0f);
-    nrm[t] = make_float4(Nx, Ny, Nz, 0.f);
+  bool hit = false;
+  if (t < n) {
+    const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
+    const size_t e = (size_t)x + (size_t)y * W;
+    HitRec h = hb[e];
+    h.blasIdx &= 0x7fffffffu;
+    float ox, oy, oz, dx, dy, dz;
+    generate_ray(utab[x], vtab[y], ox, oy, oz, dx, dy, dz);
+    float r, g, b;
+    if (h.dist == RT_LARGE_FLOAT) {
+      r = p.bg[0]; g = p.bg[1]; b = p.bg[2];
+      geo[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      nrm[t] = make_float4(0.f, 0.f, 1.f, 0.f);
+    } else {
+      float refl, Ix, Iy, Iz, Nx, Ny, Nz;
+      shade_terms<false>(sc, p, ox, oy, oz, dx, dy, dz, h, false, r, g, b, refl, Ix, Iy, Iz, Nx, Ny, Nz);
+      float thr = 1.0f;
+      thr *= refl;
+      r = r + p.bg[0] * thr; g = g + p.bg[1] * thr; b = b + p.bg[2] * thr;
+      geo[t] = make_float4(Ix, Iy, Iz, 1.0f);
+      nrm[t] = make_float4(Nx, Ny, Nz, 0.f);
+      hit = true;
+    }
+    col[t] = make_float4(r, g, b, 0.f);
+    cnt[t] = 0u;
   }
-  col[t] = make_float4(r, g, b, 0.f);
-  cnt[t] = 0u;
+  // wave-aggregated append
+  const unsigned long long m = __ballot(hit);
+  if (m) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(hdr, (uint32_t)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (hit) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)t;
+  }
 }
 
-// sample s of every pixel: occlusion ray + tmax (a pixel without a hit gets a ray nothing can hit)
-__global__ __launch_bounds__(256) void rt_ao_rays_kernel(uint64_t n, uint32_t W, uint32_t y0, const float* __restrict__ utab, const float* __restrict__ vtab,
-    const float4* __restrict__ geo, const float4* __restrict__ nrm, uint32_t spp, uint32_t smp, uint32_t user_seed, float radius,
-    float* __restrict__ rays, float* __restrict__ tmax) {
-  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (t >= n) return;
-  float* o = rays + (size_t)t * 6;
+// samples [s0, s0 + ns) of every listed pixel: ray i = (pixel list[i / ns], sample s0 + i % ns); hdr[1] = number of rays
+__global__ __launch_bounds__(256) void rt_ao_rays_kernel(uint64_t cap, uint32_t W, uint32_t y0, const float* __restrict__ utab, const float* __restrict__ vtab,
+    const float4* __restrict__ geo, const float4* __restrict__ nrm, const uint32_t* __restrict__ list, uint32_t* hdr,
+    uint32_t spp, uint32_t s0, uint32_t ns, uint32_t user_seed, float radius, float* __restrict__ rays, float* __restrict__ tmax) {
+  const uint64_t total = (uint64_t)hdr[0] * ns;
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i == 0) hdr[1] = (uint32_t)total;
+  if (i >= total || i >= cap) return;
+  const uint32_t t = list[i / ns], smp = s0 + (uint32_t)(i % ns);
+  float* o = rays + (size_t)i * 6;
   const float4 gI = geo[t];
-  if (gI.w == 0.f) {
-    o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 1.f; o[4] = 1.f; o[5] = 1.f;
-    tmax[t] = -1.0f;
-    return;
-  }
-  const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
+  const uint32_t x = t % W, y = y0 + t / W;
   float ox, oy, oz, vdx, vdy, vdz;
   generate_ray(utab[x], vtab[y], ox, oy, oz, vdx, vdy, vdz);
   uint32_t seed = wang_hash((x + y * W) * spp + smp + 1u + user_seed * 0x9E3779B9u);
   if (seed == 0u) seed = 1u;
   float u = 0.0f, v = 0.0f, r2 = 0.0f;
   bool ok = false;
-  for (int i = 0; i < 8 && !ok; ++i) {
+  for (int k = 0; k < 8 && !ok; ++k) {
     const float a = 2.0f * random_float(seed) - 1.0f;
     const float b = 2.0f * random_float(seed) - 1.0f;
     const float q = a * a + b * b;
@@ -1067,13 +1080,14 @@ __global__ __launch_bounds__(256) void rt_ao_rays_kernel(uint64_t n, uint32_t W,
   o[3] = tx * u + bx * v + nx * z;
   o[4] = ty * u + by * v + ny * z;
   o[5] = tz * u + bz * v + nz * z;
-  tmax[t] = radius;
+  tmax[i] = radius;
 }
 
-__global__ __launch_bounds__(256) void rt_ao_accumulate_kernel(uint64_t n, const float4* __restrict__ geo, const HitRec* __restrict__ ohits, uint32_t* __restrict__ cnt) {
-  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (t >= n) return;
-  if (geo[t].w != 0.f && ohits[t].dist == RT_LARGE_FLOAT) cnt[t] += 1u;
+__global__ __launch_bounds__(256) void rt_ao_accumulate_kernel(uint64_t cap, const uint32_t* __restrict__ list, const uint32_t* __restrict__ hdr, uint32_t ns,
+    const HitRec* __restrict__ ohits, uint32_t* __restrict__ cnt) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= hdr[1] || i >= cap) return;
+  if (ohits[i].dist == RT_LARGE_FLOAT) atomicAdd(cnt + list[i / ns], 1u);
 }
 
 __global__ __launch_bounds__(256) void rt_ao_final_kernel(uint64_t n, uint32_t W, uint32_t y0, const float4* __restrict__ geo, const float4* __restrict__ col,
@@ -1292,7 +1306,8 @@ struct FrameCtx {
   uint32_t* bcount = nullptr;  // device: rays appended to the level being built
   // ambient-occlusion pass (allocated on first use), one entry per pixel of the window
   float4* ao_geo = nullptr; float4* ao_nrm = nullptr; float4* ao_col = nullptr; uint32_t* ao_cnt = nullptr;
-  float* ao_rays = nullptr; float* ao_tmax = nullptr; HitRec* ao_hits = nullptr; uint64_t ao_cap = 0;
+  uint32_t* ao_list = nullptr; uint32_t* ao_hdr = nullptr;   // pixels with a hit; [0] their number, [1] rays of the current batch
+  float* ao_rays = nullptr; float* ao_tmax = nullptr; HitRec* ao_hits = nullptr; uint64_t ao_cap = 0, ao_ray_cap = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr;
   bool busy = false;
@@ -1322,7 +1337,7 @@ static void accel_free(vxrt_accel* a) {
   (void)hipFree(a->uvtab); (void)hipFree(a->apriori);
   for (FrameCtx& c : a->ctx) {
     (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount);
-    (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits);
+    (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits); (void)hipFree(c.ao_list); (void)hipFree(c.ao_hdr);
     for (FrameCtx::Level& l : c.lv) {
       (void)hipFree(l.rays); (void)hipFree(l.hits); (void)hipFree(l.parent); (void)hipFree(l.term); (void)hipFree(l.col);
       (void)hipFree(l.srays); (void)hipFree(l.stmax); (void)hipFree(l.shits);
@@ -1463,11 +1478,12 @@ static int ensure_defer(FrameCtx* c, uint64_t jobs, hipStream_t s) {
 
 // ray buffer -> hit records on frame context c (the body of vxrt_trace; also the bounce levels of vxrt_render)
 static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_t n, const float* tmax,
-                        HitRec* hits, int mode, hipStream_t s) {
+                        HitRec* hits, int mode, hipStream_t s, const uint32_t* n_dev = nullptr) {
   uint32_t* st = status_word();
   if (!st) return -1;
   PersistArgs A{};
   A.total = (uint32_t)n; A.hits = hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
+  A.total_dev = n_dev;
   A.status = st;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
   if (ensure_defer(c, A.total, s) != 0) return -1;
@@ -1481,6 +1497,7 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   A.queue = c->ctl + 32;
   PersistArgs X = A;
   X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
+  X.total_dev = nullptr;   // the EXACT launch takes its count from the deferral list
   ShadeParams p{};
   if (a->dev.exact_decode) {
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, true, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, true, false>, n)), dim3(256), 0, s, a->dev, p, A);
@@ -1572,33 +1589,42 @@ static int render_bounce_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// Tail of an ambient-occlusion frame (replaces the plain shading pass): per sample one ray buffer of
-// the window's pixels traced in any-hit mode.  No host synchronisation.
+// Tail of an ambient-occlusion frame (replaces the plain shading pass): the pixels with a hit are listed on
+// the device, their occlusion rays are generated in batches of whole samples (<= AO_BATCH_RAYS rays) and each
+// batch is one any-hit launch whose job count stays in device memory.  No host synchronisation.
+#define AO_BATCH_RAYS (32ull << 20)
 static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, uint32_t width, uint32_t y0, uint32_t y1,
                           const vxrt_ao_params_t* ao, const float* utab, const float* vtab, uint32_t* dst, float* colors,
                           uint32_t* unoccluded, unsigned long long* rays_traced, hipStream_t s) {
   const SceneDev& sc = a->dev;
   const uint64_t n = (uint64_t)width * (y1 - y0);
   if (n > 0x7fffffffull || ao->spp == 0) return -1;
-  if (c->ao_cap < n) {
+  uint32_t ns = (uint32_t)std::min<uint64_t>(ao->spp, std::max<uint64_t>(1, AO_BATCH_RAYS / n));   // samples per batch
+  const uint64_t ray_cap = n * ns;
+  if (ray_cap > 0x7fffffffull) return -1;
+  if (c->ao_cap < n || c->ao_ray_cap < ray_cap) {
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
-    const uint64_t have = c->ao_cap;
+    const uint64_t have = c->ao_cap, rhave = c->ao_ray_cap;
     bool ok = grow_buf((void**)&c->ao_geo, have, n, 16) && grow_buf((void**)&c->ao_nrm, have, n, 16) && grow_buf((void**)&c->ao_col, have, n, 16) &&
-              grow_buf((void**)&c->ao_cnt, have, n, 4) && grow_buf((void**)&c->ao_rays, have, n, 24) && grow_buf((void**)&c->ao_tmax, have, n, 4) &&
-              grow_buf((void**)&c->ao_hits, have, n, sizeof(HitRec));
+              grow_buf((void**)&c->ao_cnt, have, n, 4) && grow_buf((void**)&c->ao_list, have, n, 4) && grow_buf((void**)&c->ao_hdr, c->ao_hdr ? 1 : 0, 1, 8) &&
+              grow_buf((void**)&c->ao_rays, rhave, ray_cap, 24) && grow_buf((void**)&c->ao_tmax, rhave, ray_cap, 4) &&
+              grow_buf((void**)&c->ao_hits, rhave, ray_cap, sizeof(HitRec));
     if (!ok) return -1;
-    c->ao_cap = n;
+    c->ao_cap = std::max(have, n); c->ao_ray_cap = std::max(rhave, ray_cap);
   }
-  const dim3 block(256), grid((uint32_t)((n + 255) / 256));
+  const dim3 block(256), grid((uint32_t)((n + 255) / 256)), rgrid((uint32_t)((ray_cap + 255) / 256));
+  if (hipMemsetAsync(c->ao_hdr, 0, 8, s) != hipSuccess) return -1;
   hipLaunchKernelGGL(rt_ao_prepare_kernel, grid, block, 0, s, sc, p, n, width, y0, utab, vtab, (const HitRec*)c->hitbuf,
-                     c->ao_geo, c->ao_nrm, c->ao_col, c->ao_cnt, c->ctl);
+                     c->ao_geo, c->ao_nrm, c->ao_col, c->ao_cnt, c->ao_list, c->ao_hdr, c->ctl);
   if (hipGetLastError() != hipSuccess) return -1;
   c->ctl_dirty = false;
-  for (uint32_t smp = 0; smp < ao->spp; ++smp) {
-    hipLaunchKernelGGL(rt_ao_rays_kernel, grid, block, 0, s, n, width, y0, utab, vtab, (const float4*)c->ao_geo, (const float4*)c->ao_nrm,
-                       ao->spp, smp, ao->seed, ao->radius, c->ao_rays, c->ao_tmax);
-    if (trace_on_ctx(a, c, c->ao_rays, n, c->ao_tmax, c->ao_hits, VXRT_MODE_ANY, s) != 0) return -1;
-    hipLaunchKernelGGL(rt_ao_accumulate_kernel, grid, block, 0, s, n, (const float4*)c->ao_geo, (const HitRec*)c->ao_hits, c->ao_cnt);
+  for (uint32_t s0 = 0; s0 < ao->spp; s0 += ns) {
+    const uint32_t k = std::min(ns, ao->spp - s0);
+    hipLaunchKernelGGL(rt_ao_rays_kernel, rgrid, block, 0, s, ray_cap, width, y0, utab, vtab, (const float4*)c->ao_geo, (const float4*)c->ao_nrm,
+                       (const uint32_t*)c->ao_list, c->ao_hdr, ao->spp, s0, k, ao->seed, ao->radius, c->ao_rays, c->ao_tmax);
+    if (trace_on_ctx(a, c, c->ao_rays, n * k, c->ao_tmax, c->ao_hits, VXRT_MODE_ANY, s, c->ao_hdr + 1) != 0) return -1;
+    hipLaunchKernelGGL(rt_ao_accumulate_kernel, rgrid, block, 0, s, ray_cap, (const uint32_t*)c->ao_list, (const uint32_t*)c->ao_hdr, k,
+                       (const HitRec*)c->ao_hits, c->ao_cnt);
   }
   hipLaunchKernelGGL(rt_ao_final_kernel, grid, block, 0, s, n, width, y0, (const float4*)c->ao_geo, (const float4*)c->ao_col, (const uint32_t*)c->ao_cnt,
                      ao->spp, dst, colors, unoccluded, rays_traced);
