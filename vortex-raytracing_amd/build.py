@@ -77,7 +77,7 @@ def build(force=False, verbose=True):
     scene_so = os.path.join(LIB, "libvxrt_scene.so")
     scene_src = [os.path.join(CSRC, "scene_builder.cpp")]
     if force or _newer(scene_so, scene_src + hdrs):
-        _run(["g++"] + CXX_FLAGS + ["-pthread", "-shared", "-o", scene_so] + scene_src)
+        _run(["g++"] + CXX_FLAGS + ["-pthread", "-shared", "-o", scene_so] + scene_src + ["-lz"])
 
     host = os.path.join(LIB, "rt_host")
     host_src = [os.path.join(CSRC, "rt_host.cpp")]

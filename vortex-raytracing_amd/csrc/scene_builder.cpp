@@ -13,17 +13,20 @@
 // exist offline) and a minimal OBJ/MTL reader for the reference's own small assets.
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <sstream>
 #include <string>
 #include <thread>
 #include <utility>
 #include <vector>
+#include <zlib.h>
 #include "rt_types.h"
 
 namespace {
@@ -718,12 +721,177 @@ Mesh make_hairball(uint32_t strands, uint32_t segs, uint32_t seed) {
   return m;
 }
 
-// minimal OBJ (+MTL colours) reader: v / vn / vt / f (fan-triangulated) / usemtl / mtllib
+// ---------------------------------------------------------------------------------------------
+// Image ingest (role of surface.cpp:28-55, which calls stb_image with 3 forced channels and packs
+// (r << 16) + (g << 8) + b): PNG (8/16-bit, grey / grey+alpha / RGB / RGBA / palette, non-interlaced and
+// Adam7, zlib inflate) and binary/ASCII PPM/PGM.  Written from the PNG specification, no stb code.
+// ---------------------------------------------------------------------------------------------
+static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+static int paeth(int a, int b, int c) {
+  const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// undo the scanline filters of one (sub)image in place: rows of `stride` bytes, each preceded by its filter byte
+static bool png_unfilter(uint8_t* d, size_t rows, size_t stride, size_t bpp, uint8_t* out) {
+  std::vector<uint8_t> zero(stride, 0);
+  const uint8_t* prev = zero.data();
+  for (size_t y = 0; y < rows; ++y) {
+    const uint8_t f = d[y * (stride + 1)];
+    const uint8_t* in = d + y * (stride + 1) + 1;
+    uint8_t* o = out + y * stride;
+    for (size_t i = 0; i < stride; ++i) {
+      const int a = i >= bpp ? o[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+      int v;
+      switch (f) {
+      case 0: v = in[i]; break;
+      case 1: v = in[i] + a; break;
+      case 2: v = in[i] + b; break;
+      case 3: v = in[i] + ((a + b) >> 1); break;
+      case 4: v = in[i] + paeth(a, b, c); break;
+      default: return false;
+      }
+      o[i] = (uint8_t)v;
+    }
+    prev = o;
+  }
+  return true;
+}
+
+static bool load_png(const std::vector<uint8_t>& f, uint32_t& W, uint32_t& H, std::vector<uint32_t>& px) {
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  if (f.size() < 8 + 25 || std::memcmp(f.data(), sig, 8) != 0) return false;
+  uint32_t depth = 0, ctype = 0, interlace = 0;
+  std::vector<uint8_t> idat, plte;
+  size_t pos = 8;
+  bool have_hdr = false, end = false;
+  while (!end && pos + 12 <= f.size()) {
+    const uint32_t len = be32(&f[pos]);
+    const char* type = (const char*)&f[pos + 4];
+    if (pos + 12 + (size_t)len > f.size()) return false;
+    const uint8_t* data = &f[pos + 8];
+    if (!std::memcmp(type, "IHDR", 4)) {
+      if (len != 13) return false;
+      W = be32(data); H = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
+      if (data[10] != 0 || data[11] != 0 || interlace > 1) return false;
+      have_hdr = true;
+    } else if (!std::memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
+    else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+    else if (!std::memcmp(type, "IEND", 4)) end = true;
+    pos += 12 + (size_t)len;
+  }
+  if (!have_hdr || W == 0 || H == 0 || (uint64_t)W * H > (1ull << 28)) return false;
+  uint32_t ch;
+  switch (ctype) { case 0: ch = 1; break; case 2: ch = 3; break; case 3: ch = 1; break; case 4: ch = 2; break; case 6: ch = 4; break; default: return false; }
+  if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
+  if (ctype == 3 && depth == 16) return false;
+  const size_t bits = (size_t)ch * depth, bpp = std::max<size_t>(1, bits / 8);
+  auto stride_of = [&](uint32_t w) { return ((size_t)w * bits + 7) / 8; };
+  // sub-images: one for non-interlaced, the seven Adam7 passes otherwise
+  struct Pass { uint32_t x0, y0, dx, dy; };
+  static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  std::vector<Pass> passes;
+  if (interlace) passes.assign(adam7, adam7 + 7); else passes.push_back({0, 0, 1, 1});
+  size_t raw = 0;
+  for (const Pass& ps : passes) {
+    const uint32_t pw = (W - ps.x0 + ps.dx - 1) / ps.dx, ph = (H - ps.y0 + ps.dy - 1) / ps.dy;
+    if (ps.x0 < W && ps.y0 < H && pw && ph) raw += (stride_of(pw) + 1) * ph;
+  }
+  std::vector<uint8_t> buf(raw);
+  uLongf got = (uLongf)raw;
+  if (uncompress(buf.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw) return false;
+  px.assign((size_t)W * H, 0u);
+  auto sample = [&](const uint8_t* row, uint32_t x, uint32_t c) -> uint32_t {   // channel c of pixel x, scaled to 8 bit like stb (16 -> high byte)
+    if (depth == 8) return row[(size_t)x * ch + c];
+    if (depth == 16) return row[((size_t)x * ch + c) * 2];
+    const uint32_t per = 8 / depth, v = (row[x / per] >> ((per - 1 - x % per) * depth)) & ((1u << depth) - 1u);
+    return ctype == 3 ? v : v * 255u / ((1u << depth) - 1u);
+  };
+  size_t off = 0;
+  for (const Pass& ps : passes) {
+    if (ps.x0 >= W || ps.y0 >= H) continue;
+    const uint32_t pw = (W - ps.x0 + ps.dx - 1) / ps.dx, ph = (H - ps.y0 + ps.dy - 1) / ps.dy;
+    if (!pw || !ph) continue;
+    const size_t st = stride_of(pw);
+    std::vector<uint8_t> img(st * ph);
+    if (!png_unfilter(buf.data() + off, ph, st, bpp, img.data())) return false;
+    off += (st + 1) * ph;
+    for (uint32_t y = 0; y < ph; ++y) {
+      const uint8_t* row = img.data() + (size_t)y * st;
+      for (uint32_t x = 0; x < pw; ++x) {
+        uint32_t r, g, b;
+        if (ctype == 3) {
+          const uint32_t i = sample(row, x, 0);
+          if ((size_t)i * 3 + 2 >= plte.size()) return false;
+          r = plte[i * 3]; g = plte[i * 3 + 1]; b = plte[i * 3 + 2];
+        } else if (ctype == 0 || ctype == 4) { r = g = b = sample(row, x, 0); }
+        else { r = sample(row, x, 0); g = sample(row, x, 1); b = sample(row, x, 2); }
+        px[(size_t)(ps.y0 + y * ps.dy) * W + ps.x0 + x * ps.dx] = (r << 16) + (g << 8) + b;   // surface.cpp:47
+      }
+    }
+  }
+  return true;
+}
+
+static bool load_pnm(const std::vector<uint8_t>& f, uint32_t& W, uint32_t& H, std::vector<uint32_t>& px) {
+  if (f.size() < 7 || f[0] != 'P') return false;
+  const int kind = f[1] - '0';
+  if (kind != 2 && kind != 3 && kind != 5 && kind != 6) return false;
+  size_t pos = 2;
+  auto next_int = [&](uint32_t& v) -> bool {
+    for (;;) {
+      while (pos < f.size() && std::isspace(f[pos])) ++pos;
+      if (pos < f.size() && f[pos] == '#') { while (pos < f.size() && f[pos] != '\n') ++pos; continue; }
+      break;
+    }
+    if (pos >= f.size() || !std::isdigit(f[pos])) return false;
+    uint64_t a = 0;
+    while (pos < f.size() && std::isdigit(f[pos])) { a = a * 10 + (f[pos++] - '0'); if (a > 0xffffffffull) return false; }
+    v = (uint32_t)a;
+    return true;
+  };
+  uint32_t maxv = 0;
+  if (!next_int(W) || !next_int(H) || !next_int(maxv) || W == 0 || H == 0 || maxv == 0 || maxv > 65535 || (uint64_t)W * H > (1ull << 28)) return false;
+  const uint32_t ch = (kind == 3 || kind == 6) ? 3 : 1;
+  px.assign((size_t)W * H, 0u);
+  auto scale = [&](uint32_t v) { return maxv == 255 ? v : v * 255u / maxv; };
+  if (kind == 5 || kind == 6) {
+    ++pos;   // the single whitespace after maxval
+    const size_t bps = maxv > 255 ? 2 : 1;
+    if (pos + (size_t)W * H * ch * bps > f.size()) return false;
+    for (size_t i = 0; i < (size_t)W * H; ++i) {
+      uint32_t c[3];
+      for (uint32_t k = 0; k < ch; ++k) { const uint8_t* q = &f[pos + (i * ch + k) * bps]; c[k] = scale(bps == 2 ? ((uint32_t)q[0] << 8) | q[1] : q[0]); }
+      if (ch == 1) c[1] = c[2] = c[0];
+      px[i] = (c[0] << 16) + (c[1] << 8) + c[2];
+    }
+  } else {
+    for (size_t i = 0; i < (size_t)W * H; ++i) {
+      uint32_t c[3];
+      for (uint32_t k = 0; k < ch; ++k) { if (!next_int(c[k])) return false; c[k] = scale(std::min(c[k], maxv)); }
+      if (ch == 1) c[1] = c[2] = c[0];
+      px[i] = (c[0] << 16) + (c[1] << 8) + c[2];
+    }
+  }
+  return true;
+}
+
+// file -> 0x00RRGGBB texels, row-major, top row first
+static bool load_image(const char* path, uint32_t& W, uint32_t& H, std::vector<uint32_t>& px) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) return false;
+  std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  return load_png(f, W, H, px) || load_pnm(f, W, H, px);
+}
+
+// OBJ + MTL reader: v / vn / vt / f (fan-triangulated) / usemtl / mtllib with Kd, Ka and map_Kd (PNG, PPM/PGM)
 bool load_obj(const char* path, Mesh& m) {
   std::ifstream in(path);
   if (!in) return false;
   std::vector<V3> P, N; std::vector<std::pair<float, float>> T;
   std::map<std::string, uint32_t> matid;
+  std::map<std::string, int> texid;
   uint32_t cur = 0;
   std::string line, dir(path);
   auto slash = dir.find_last_of('/');
@@ -743,6 +911,25 @@ bool load_obj(const char* path, Mesh& m) {
         if (mk == "newmtl") { ms >> name; matid[name] = (uint32_t)m.mats.size(); m.mats.push_back(make_mat(0.8f, 0.8f, 0.8f, -1)); }
         else if (mk == "Kd" && !m.mats.empty()) { ms >> m.mats.back().diffuse[0] >> m.mats.back().diffuse[1] >> m.mats.back().diffuse[2]; }
         else if (mk == "Ka" && !m.mats.empty()) { ms >> m.mats.back().ambient[0] >> m.mats.back().ambient[1] >> m.mats.back().ambient[2]; }
+        else if (mk == "map_Kd" && !m.mats.empty()) {
+          // mesh.cpp:130-293 keeps one texture per distinct file; a file that cannot be read leaves the material untextured
+          std::string tf, tok;
+          while (ms >> tok) tf = tok;          // options (-s, -o ...) precede the file name
+          std::replace(tf.begin(), tf.end(), '\\', '/');
+          auto it = texid.find(tf);
+          if (it == texid.end()) {
+            uint32_t tw = 0, th = 0; std::vector<uint32_t> px;
+            if (load_image((dir + tf).c_str(), tw, th, px)) {
+              it = texid.emplace(tf, (int)m.textures.size()).first;
+              m.textures.push_back(std::move(px));
+              m.tex_dims.push_back({tw, th});
+            } else {
+              it = texid.emplace(tf, -1).first;
+              std::fprintf(stderr, "[vxs] cannot read texture %s\n", (dir + tf).c_str());
+            }
+          }
+          m.mats.back().diffuse_tex_id = it->second;
+        }
       }
     } else if (k == "usemtl") { std::string n; ss >> n; auto it = matid.find(n); cur = it == matid.end() ? 0 : it->second; }
     else if (k == "f") {
@@ -785,6 +972,18 @@ static void read_knobs() {
   if (const char* e = std::getenv("VXS_THREADS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) kThreads = v; }
   if (const char* e = std::getenv("VXS_LEAF_K")) kLeafK = (float)std::atof(e);
   if (const char* e = std::getenv("VXS_LEAF_MAX")) kLeafMax = std::atoi(e);
+}
+
+// decode an image file the way the scene ingest does (PNG, PPM/PGM -> 0x00RRGGBB); out may be NULL to query the size
+int vxs_image_load(const char* path, uint32_t* w, uint32_t* h, uint32_t* out, uint64_t cap_pixels) {
+  uint32_t W = 0, H = 0; std::vector<uint32_t> px;
+  if (!path || !w || !h || !load_image(path, W, H, px)) return -1;
+  *w = W; *h = H;
+  if (out) {
+    if (cap_pixels < px.size()) return -1;
+    std::memcpy(out, px.data(), px.size() * 4);
+  }
+  return 0;
 }
 
 void* vxs_scene_create_procedural(const char* name, uint32_t a, uint32_t b, uint32_t seed) {

@@ -109,5 +109,19 @@ def from_triangles(meshes, transforms=None):
     return _from_handle(h, "triangles")
 
 
+def image_load(path):
+    """Decode an image file as the scene ingest does (PNG, PPM/PGM): uint32 array [h, w] of 0x00RRGGBB texels."""
+    L = _load()
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    L.vxs_image_load.restype = C.c_int
+    L.vxs_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]
+    if L.vxs_image_load(str(path).encode(), C.byref(w), C.byref(h), None, 0) != 0:
+        raise ValueError("cannot decode image %s" % path)
+    out = np.zeros((h.value, w.value), np.uint32)
+    if L.vxs_image_load(str(path).encode(), C.byref(w), C.byref(h), out.ctypes.data, out.size) != 0:
+        raise ValueError("cannot decode image %s" % path)
+    return out
+
+
 def load_obj(path, instances=1):
     return _from_handle(_load().vxs_scene_load_obj(str(path).encode(), instances), str(path))
