@@ -54,18 +54,29 @@ static bool shadow = false, quiet = false;
 static uint32_t row0 = 0, row1 = 0;
 
 static void write_ppm(const std::vector<uint8_t>& out, uint32_t w, uint32_t h, const char* file) {
-  // P3, vertical flip, bytes 2,1,0 of each little-endian pixel (tracer.cpp:15-33)
+  // P3, vertical flip, bytes 2,1,0 of each little-endian pixel (tracer.cpp:15-33: same bytes, but the
+  // reference streams three float conversions per pixel through operator<<; here a 256-entry table of
+  // decimal strings fills one buffer -- a 4K frame takes tens of milliseconds instead of seconds)
+  char dec[256][4]; uint8_t len[256];
+  for (int v = 0; v < 256; ++v) len[v] = (uint8_t)std::snprintf(dec[v], sizeof dec[v], "%d", v);
   std::string s = "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
-  s.reserve(s.size() + (size_t)w * h * 12);
-  char tmp[16];
-  for (uint32_t y = 0; y < h; ++y)
+  const size_t head = s.size();
+  s.resize(head + (size_t)w * h * 12);
+  char* q = &s[head];
+  for (uint32_t y = 0; y < h; ++y) {
+    const uint8_t* row = out.data() + (size_t)(h - 1 - y) * w * 4;
     for (uint32_t x = 0; x < w; ++x) {
-      const size_t i = ((size_t)(h - 1 - y) * w + x) * 4;
-      int n = std::snprintf(tmp, sizeof tmp, "%u %u %u\n", out[i + 2], out[i + 1], out[i + 0]);
-      s.append(tmp, n);
+      const uint8_t* px = row + (size_t)x * 4;
+      for (int k = 2; k >= 0; --k) {
+        const uint8_t v = px[k];
+        std::memcpy(q, dec[v], len[v]); q += len[v];
+        *q++ = k ? ' ' : '\n';
+      }
     }
+  }
+  s.resize((size_t)(q - s.data()));
   std::ofstream ofs(file, std::ios::binary);
-  ofs << s;
+  ofs.write(s.data(), (std::streamsize)s.size());
   std::printf("Image saved to: %s\n", file);
 }
 
