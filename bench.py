@@ -46,7 +46,8 @@ def parse():
                     help="frames kept in flight on as many HIP streams (vxrt_accel_frames_in_flight); 1 = strictly serial frames")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal of the N>1 code path where ranks share one GPU (frames gathered through host memory)")
-    ap.add_argument("--random-rays", type=int, default=0, help="also time N incoherent random rays (vxrt_trace), reported under extras")
+    ap.add_argument("--random-rays", type=int, default=16777216,
+                    help="second leg (SURVEY s8d 'random rays vs fixed BVH'): N incoherent rays per GPU through vxrt_trace, reported under extras; 0 = skip")
     return ap.parse_args()
 
 
@@ -235,27 +236,51 @@ def main():
     kern_ms = span_ms / a.steps
 
     extras = {}
-    if a.random_rays and rank == 0:
+    if a.random_rays:
+        # north_star's second figure: synthetic random rays against the fixed BVH, ray buffer (24 B/ray) in HBM ->
+        # hit records (24 B/ray); every rank traces its own N rays (seed 12345 + rank), no collective
         n = a.random_rays
-        g = torch.Generator(device=dev).manual_seed(12345)
+        g = torch.Generator(device=dev).manual_seed(12345 + rank)
         lo = torch.tensor(scene.bounds[:3], device=dev)
         hi = torch.tensor(scene.bounds[3:], device=dev)
         o = lo + (hi - lo) * torch.rand((n, 3), generator=g, device=dev)
         d = torch.randn((n, 3), generator=g, device=dev)
         d = d / d.norm(dim=1, keepdim=True)
         rays = torch.cat([o, d], 1).contiguous()
+        del o, d
         hits = torch.zeros(n * 24, dtype=torch.uint8, device=dev)
+        rstats = rtapi.trace_stats(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr) if rank == 0 else None
+        reps = 5
         for _ in range(2):
             rtapi.trace(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(5):
-            rtapi.trace(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
-        e1.record(stream)
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        extras["random_rays_mrays_s"] = round(n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 1)
-        extras["random_rays_n"] = n
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            rtapi.trace(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        rt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([rt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rt = float(t.item())
+        assert rtapi.status(sptr) == 0
+        mr = n * world * reps / rt / 1e6
+        extras["random_rays_mrays_s"] = round(mr, 1)
+        extras["random_rays_n"] = n * world
+        if rstats:
+            gbs = mr * 1e6 * rstats["bytes_per_ray"] / 1e9
+            extras["random_rays"] = {"rays_per_gpu": n, "mrays_s": round(mr, 1), "ms_per_launch": round(rt / reps * 1e3, 3),
+                                     "bytes_per_ray": round(rstats["bytes_per_ray"], 1), "achieved_GBs": round(gbs, 1),
+                                     "frac_of_hbm_peak": round(gbs / (HBM_PEAK_GBS * world), 4),
+                                     "node_fetches_per_ray": round(rstats["node_fetches"] / n, 2),
+                                     "tri_fetches_per_ray": round(rstats["tri_fetches"] / n, 2)}
+        del rays, hits
 
     if rank == 0:
         out = {

@@ -216,6 +216,12 @@ int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
                       const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                       unsigned long long* counters, void* stream);
 
+/* vxrt_trace with the fetch counters compiled in (slower; never a timed path).  counters: device u64[8], of which
+ * [0..3] = rays, node fetches, instance fetches, triangle fetches as the reference accounts them (rt_traversal.cpp:
+ * 54,116,148,158, without restart re-reads) -- the inputs of the algorithmic bytes per ray. */
+int vxrt_trace_stats(vxrt_accel_t* accel, const float* rays, uint64_t n, const float* tmax,
+                     vxrt_hit_t* hits, int mode, unsigned long long* counters, void* stream);
+
 /* Ambient-occlusion frame (extension for BASELINE config 5, "16 spp Monte-Carlo AO"; the reference has no
  * such pass, only its RNG is used: common.h:129-147).  Per pixel with a primary hit: spp cosine-weighted
  * occlusion rays about the shading normal (tmax = radius, any-hit), pixel = Lambert colour of the hit

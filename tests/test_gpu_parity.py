@@ -373,3 +373,25 @@ def test_ambient_occlusion_pass_matches_oracle(vrt, po, gpu_device, spp, radius)
     assert hit and (rcnt < spp).any() and (rcnt == spp).any()     # some occlusion, some open sky
     with pytest.raises(vrt.runtime.VxError):
         vrt.rtapi.render_ao(ds.accel, w, h, 0, h, p, 0, radius, px.data_ptr(), stream=stream)
+
+
+def test_trace_fetch_counters_equal_oracle_counts(vrt, po, gpu_device):
+    """vxrt_trace_stats: the counts behind the random-ray leg's bytes per ray equal the canonical restatement's."""
+    import torch
+    sc = vrt.scene.procedural("atrium", 5, 0, 3)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    rng = np.random.default_rng(77)
+    b = np.array(sc.bounds, np.float32)
+    n = 20000
+    o = b[:3] + (b[3:] - b[:3]) * rng.random((n, 3), dtype=np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    r = torch.from_numpy(rays).to(gpu_device)
+    out = torch.zeros(n * 24, dtype=torch.uint8, device=gpu_device)
+    c = vrt.rtapi.trace_stats(ds.accel, r.data_ptr(), n, out.data_ptr(), vrt.rtapi.MODE_CLOSEST, None, torch.cuda.current_stream().cuda_stream)
+    hits, st = po.trace_canonical(sc, rays)
+    assert c["rays"] == n
+    assert c["node_fetches"] == st["node_reads"] and c["inst_fetches"] == st["inst_reads"] and c["tri_fetches"] == st["tri_reads"]
+    assert c["bytes"] == 48 * n + 52 * (st["node_reads"] + st["inst_reads"]) + 36 * st["tri_reads"]
+    assert np.array_equal(_bits(_hits_np(out)[:n]), _bits(hits))

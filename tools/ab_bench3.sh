@@ -6,6 +6,6 @@ for flags in "$@"; do
   VXRT_EXTRA_HIPFLAGS="$flags" python -c "import importlib,sys; sys.path.insert(0,'.'); b=importlib.import_module('vortex-raytracing_amd.build'); b.build(force=True)" > /dev/null 2>&1
   echo "== flags: [$flags]"
   for rep in 1 2; do
-    python bench.py --steps 100 --warmup 10 --no-cpu-baseline --random-rays 4194304 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('Mrays/s', d['value'], 'ms', r['kernel_ms'], 'iso', r['kernel_ms_isolated'], d['extras']['random_rays_mrays_s'])"
+    python bench.py --steps 100 --warmup 10 --no-cpu-baseline  2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('Mrays/s', d['value'], 'ms', r['kernel_ms'], 'iso', r['kernel_ms_isolated'], d['extras']['random_rays_mrays_s'])"
   done
 done

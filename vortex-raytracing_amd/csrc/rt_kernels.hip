@@ -1478,12 +1478,14 @@ static int ensure_defer(FrameCtx* c, uint64_t jobs, hipStream_t s) {
 
 // ray buffer -> hit records on frame context c (the body of vxrt_trace; also the bounce levels of vxrt_render)
 static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_t n, const float* tmax,
-                        HitRec* hits, int mode, hipStream_t s, const uint32_t* n_dev = nullptr) {
+                        HitRec* hits, int mode, hipStream_t s, const uint32_t* n_dev = nullptr,
+                        unsigned long long* stats_counters = nullptr) {
   uint32_t* st = status_word();
   if (!st) return -1;
   PersistArgs A{};
   A.total = (uint32_t)n; A.hits = hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
   A.total_dev = n_dev;
+  A.counters = stats_counters;
   A.status = st;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
   if (ensure_defer(c, A.total, s) != 0) return -1;
@@ -1499,13 +1501,12 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
   X.total_dev = nullptr;   // the EXACT launch takes its count from the deferral list
   ShadeParams p{};
-  if (a->dev.exact_decode) {
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, true, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, true, false>, n)), dim3(256), 0, s, a->dev, p, A);
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, true, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X);
-  } else {
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, false, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, false, false, false>, n)), dim3(256), 0, s, a->dev, p, A);
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, false, false, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X);
-  }
+#define LAUNCH_T(ST, LD) do { \
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, false>, n)), dim3(256), 0, s, a->dev, p, A); \
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X); } while (0)
+  if (stats_counters) { if (a->dev.exact_decode) LAUNCH_T(true, true); else LAUNCH_T(true, false); }
+  else                { if (a->dev.exact_decode) LAUNCH_T(false, true); else LAUNCH_T(false, false); }
+#undef LAUNCH_T
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1783,6 +1784,21 @@ int vxrt_render_ao(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_
                    uint32_t* unoccluded, unsigned long long* rays_traced, void* stream) {
   if (!ao || ao->spp == 0 || ao->spp > 4096 || !(ao->radius > 0.0f)) return -1;
   return render_common(accel, width, height, y0, y1, params, 0, dst, nullptr, colors, rays_traced, false, stream, nullptr, ao, unoccluded);
+}
+
+// vxrt_trace with the fetch counters compiled in (slower; never the timed path): counters = device u64[8],
+// [0..3] = {rays, node fetches, instance fetches, triangle fetches}, the inputs of SURVEY s8d's per-ray formula
+int vxrt_trace_stats(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax,
+                     vxrt_hit_t* hits, int mode, unsigned long long* counters, void* stream) {
+  if (!a || !counters || (n && (!rays || !hits))) return -1;
+  if (mode != VXRT_MODE_CLOSEST && mode != VXRT_MODE_ANY) return -1;
+  if (n == 0) return 0;
+  if (n > 0x7fffffffull) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  FrameCtx* c = acquire_ctx(a, s);
+  if (!c) return -1;
+  if (trace_on_ctx(a, c, rays, n, tmax, (HitRec*)hits, mode, s, nullptr, counters) != 0) return -1;
+  return release_ctx(c, s);
 }
 
 int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax,

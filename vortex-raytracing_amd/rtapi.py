@@ -91,6 +91,21 @@ def render(accel, width, height, y0, y1, params, dst_ptr, shadow=0, hits_ptr=Non
                              colors_ptr, rays_ptr, stream), "vxrt_render")
 
 
+def trace_stats(accel, rays_ptr, n, hits_ptr, mode=0, tmax_ptr=None, stream=None):
+    """vxrt_trace_stats: counting build of the ray-buffer traversal; returns counts and SURVEY s8d bytes per ray
+    (24 B ray read + 52 B per node / instance record + 36 B per triangle + 24 B hit record written)."""
+    import torch
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda:%d" % torch.cuda.current_device())
+    L = _lib()
+    L.vxrt_trace_stats.restype = C.c_int
+    L.vxrt_trace_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    check(L.vxrt_trace_stats(accel, rays_ptr, n, tmax_ptr, hits_ptr, mode, cnt.data_ptr(), stream), "vxrt_trace_stats")
+    torch.cuda.synchronize()
+    r, nn, ni, nt = (int(v) for v in cnt.tolist()[:4])
+    total = 24 * r + 52 * (nn + ni) + 36 * nt + 24 * r
+    return {"rays": r, "node_fetches": nn, "inst_fetches": ni, "tri_fetches": nt, "bytes": total, "bytes_per_ray": total / max(r, 1)}
+
+
 class AoParams(C.Structure):   # vxrt_ao_params_t
     _fields_ = [("spp", C.c_uint32), ("radius", C.c_float), ("seed", C.c_uint32), ("reserved", C.c_uint32)]
 
