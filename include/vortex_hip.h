@@ -241,7 +241,8 @@ int vxrt_render_ao(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_
 /* Diagnostic variant of vxrt_render_stats: additionally logs per wavefront of the main traversal
  * launch {first clock, last clock (100 MHz constant clock), rays started, loop iterations, runs of the
  * node body, lanes active in them, runs of the leaf body, lanes active in them, node-body runs in which
- * no lane's node has a 3rd or 4th child, ... a 4th child} into wave_log, a device u64[10 * 4 * 8 * 256] array, to study load balance and lane occupancy of the launch. */
+ * no lane's node has a 3rd or 4th child, ... a 4th child, shader clocks in the node body, in the instance + leaf part,
+ * in the whole kernel} into wave_log, a device u64[13 * 4 * 8 * 256] array, to study load balance and lane occupancy of the launch. */
 int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                          unsigned long long* counters, unsigned long long* wave_log, void* stream);

@@ -21,6 +21,6 @@ for m in pipelined serial; do
   [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_$m.csv" && head -8 "$OUT/kernel_stats_$m.csv"
   rm -rf "$OUT/stats_$m"
 done
-"$ROOT/tools/pmc_passes3.sh" "$OUT/pmc" > "$OUT/pmc.log" 2>&1
+"$ROOT/tools/pmc_passes.sh" "$OUT/pmc" > "$OUT/pmc.log" 2>&1
 tail -3 "$OUT/pmc.log"
 cp "$OUT/pmc/summary.txt" "$OUT/pmc_summary.txt"; rm -rf "$OUT"/pmc/pass*/

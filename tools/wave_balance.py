@@ -14,7 +14,7 @@ L.vxrt_render_wave_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint3
 for shadow in (1,):
     for it in range(2):
         cnt = torch.zeros(8, dtype=torch.int64, device="cuda:0")
-        log = torch.zeros((4 * 8 * 256, 10), dtype=torch.int64, device="cuda:0")
+        log = torch.zeros((4 * 8 * 256, 13), dtype=torch.int64, device="cuda:0")
         assert L.vxrt_render_wave_log(ds.accel, W, H, 0, H, C.byref(p), shadow, px.data_ptr(), cnt.data_ptr(), log.data_ptr(), None) == 0
         torch.cuda.synchronize()
     lg = log.cpu().numpy().astype(np.float64)
@@ -32,3 +32,5 @@ for shadow in (1,):
     print("rays %d -> node steps/ray %.2f, leaf visits/ray %.2f; wave-level node runs/ray %.3f leaf runs/ray %.3f"
           % (rays.sum(), nl / rays.sum(), ll / rays.sum(), nx * 64 / rays.sum(), lx * 64 / rays.sum()))
     print("node-body runs with no 3rd/4th child in any lane: %.3f; no 4th child: %.3f" % (lg[:, 8].sum() / nx, lg[:, 9].sum() / nx))
+    tn, tl, tt = lg[:, 10].sum(), lg[:, 11].sum(), lg[:, 12].sum()
+    print("shader clocks: node body %.3f, instance+leaf part %.3f, rest (fetch, finish, loop control) %.3f of the wave lifetime" % (tn / tt, tl / tt, 1 - (tn + tl) / tt))

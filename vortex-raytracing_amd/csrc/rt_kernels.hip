@@ -30,21 +30,21 @@
 // accel_* kernels below (the reference bytes stay the source of truth).
 //
 // Work descriptor, 32 bit: [31:30] kind, [29:0] payload
-//     kind 0  TLAS internal node   payload = node index in the TLAS buffer
-//     kind 1  BLAS internal node   payload = node index in the bvh buffer (absolute)
+//     kind 0  TLAS internal node   payload = compact node index (TLAS nodes come first)
+//     kind 1  BLAS internal node   payload = compact node index (n_tlas + index in the bvh buffer)
 //     kind 2  BLAS leaf            payload = count<<26 | firstTriangle   (count 1..15; count 0:
 //                                  payload = index of the reference leaf node, range read from it)
 //     kind 3  instance (TLAS leaf) payload = blasIdx
+//     0xFFFFFFFF = empty child slot, 0xFFFFFFFE = ray finished, 0xFFFFFFFD = lane idle
 //
-// Compact node, 64 B = half a cache line, one per INTERNAL node (same index as the reference node):
-//     q0 = origin.xyz, ex | ey<<8 | ez<<16 | kinds<<24     kinds: 2 bits per child (0 none,
-//                                                            1 internal, 2 leaf, 3 instance)
-//     q1 = leftFirst (index of child 0's node), qb0, qb1, qb2   qb0..5 = the 24 quantised box bytes
-//     q2 = qb3, qb4, qb5, pay0                                  pay k = descriptor payload of a leaf
-//     q3 = pay1, pay2, pay3, 0                                          or instance child k
+// Compact node, 64 B = half a cache line, one per INTERNAL node, TLAS and BLAS nodes in one index space:
+//     q0 = origin.xyz, 2^ex as float
+//     q1 = plane words lo.x, lo.y, lo.z, hi.x     one byte per child: byte k of word j = plane j of child k
+//     q2 = plane words hi.y, hi.z, desc0, desc1   desc k = complete work descriptor of child k
+//     q3 = desc2, desc3, 2^ey, 2^ez
 //   -> a node visit is four 16-byte loads per lane (the vector-memory return path, not HBM, is what
-//      saturates first on MI355X for this access pattern: profiles/r01_b_*), a leaf or instance never
-//      costs a node fetch of its own, and stack entries are 2 dwords.
+//      saturates first on MI355X for wider nodes: profiles/r01_b_*), no index arithmetic on children,
+//      a leaf or instance never costs a node fetch of its own, and stack entries are 2 dwords.
 // Wide triangle, 48 B: v0, edge1 = v1 - v0, edge2 = v2 - v0 (the subtractions of
 //     rt_traversal.cpp:272-278 done once), three aligned 16-byte loads.
 // ---------------------------------------------------------------------------------------------
@@ -490,8 +490,10 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
   Fetches fx;
   unsigned nrays = 0, nhit = 0;
   unsigned long long t_first = 0;
+  unsigned long long wl_tn = 0, wl_tl = 0, wl_t0 = 0;   // wave_log: shader clocks inside the node body / the leaf body
   unsigned wl_no23 = 0, wl_no3 = 0, wl_iter = 0, wl_node_x = 0, wl_node_l = 0, wl_leaf_x = 0, wl_leaf_l = 0;   // wave_log: lane occupancy of the two bodies
-  if (STATS && A.wave_log) t_first = wall_clock64();
+  unsigned long long wl_tstart = 0;
+  if (STATS && A.wave_log) { t_first = wall_clock64(); wl_tstart = __builtin_readcyclecounter(); }
 
   auto pixel_of = [&](uint32_t r, uint32_t& x, uint32_t& y) {
     const uint32_t tile = r >> 6, l = r & 63u;
@@ -652,15 +654,9 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
         ++wl_iter;
         if (nm) {
           ++wl_node_x; wl_node_l += (unsigned)__popcll(nm);
-          uint32_t kinds_ = 0;
-          if (is_node_desc(cur)) {
-            const uint4* np_ = sc.nodes_c + (size_t)(cur & PAYLOAD_MASK) * CNODE_VEC4;
-            kinds_ = (np_[2].w != DESC_NONE ? 4u : 0u) | (np_[3].x != DESC_NONE ? 16u : 0u) | (np_[3].y != DESC_NONE ? 64u : 0u);
-          }
-          if (__ballot((kinds_ >> 4) != 0u) == 0ull) ++wl_no23;
-          if (__ballot((kinds_ >> 6) != 0u) == 0ull) ++wl_no3;
         }
       }
+      if (STATS && A.wave_log) wl_t0 = __builtin_readcyclecounter();
       if (is_node_desc(cur)) {
         // ---- internal node: 4 box tests, order, push the far ones, continue with the nearest ----
         const bool top = (cur >> 30) == DK_TLAS;
@@ -711,6 +707,7 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
           }
         }
       }
+      if (STATS && A.wave_log) { const unsigned long long t1 = __builtin_readcyclecounter(); wl_tn += t1 - wl_t0; wl_t0 = t1; }
       if (__any(is_inst_desc(cur))) {
         if (is_inst_desc(cur)) {
           float ox, oy, oz, dx, dy, dz, tm;
@@ -755,6 +752,7 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
           else pop_next();
         }
       }
+      if (STATS && A.wave_log) { const unsigned long long t1 = __builtin_readcyclecounter(); wl_tl += t1 - wl_t0; }
       // leave when nothing traverses any more, or when enough lanes are dead weight AND leaving can
       // revive them (finished rays to retire, or idle lanes while jobs remain)
       const unsigned long long work = __ballot(is_work_desc(cur));
@@ -807,8 +805,8 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
     unsigned s = nrays;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if (lane == 0) {
-      unsigned long long* w = A.wave_log + 10ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
-      w[0] = t_first; w[1] = wall_clock64(); w[2] = s; w[8] = wl_no23; w[9] = wl_no3;
+      unsigned long long* w = A.wave_log + 13ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+      w[0] = t_first; w[1] = wall_clock64(); w[2] = s; w[8] = wl_no23; w[9] = wl_no3; w[10] = wl_tn; w[11] = wl_tl; w[12] = __builtin_readcyclecounter() - wl_tstart;
       w[3] = wl_iter; w[4] = wl_node_x; w[5] = wl_node_l; w[6] = wl_leaf_x; w[7] = wl_leaf_l;
     }
   }
@@ -1771,8 +1769,8 @@ int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
 }
 
 // diagnostic: vxrt_render_stats that also logs, per wavefront of the main traversal launch, the first
-// and last 100 MHz clock and the number of rays it started (wave_log: device u64[10 * waves], waves =
-// 4 * blocks of the launch; 10 * 4 * 8 * 256 entries are always enough)
+// and last 100 MHz clock and the number of rays it started (wave_log: device u64[13 * waves], waves =
+// 4 * blocks of the launch; 13 * 4 * 8 * 256 entries are always enough)
 int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                          unsigned long long* counters, unsigned long long* wave_log, void* stream) {
