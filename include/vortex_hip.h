@@ -238,6 +238,27 @@ int vxrt_render_ao(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_
                    const vxrt_shade_params_t* params, const vxrt_ao_params_t* ao, uint32_t* dst, float* colors,
                    uint32_t* unoccluded, unsigned long long* rays_traced, void* stream);
 
+/* ---- software twin: the reference's raycast test (tests/regression/raycast) ----
+ * Buffers in the reference's formats (raycast/common.h): tlas_node_t 32 B, blas_node_t 160 B (transform,
+ * invTransform, bvh_offset@128, tex_offset@136, tex_width@144, tex_height@148, reflectivity@152),
+ * bvh_node_t 32 B, tri_t 36 B, tri_ex_t 60 B, triIdx u32, 0x00RRGGBB texels.  Device pointers. */
+typedef struct vxrc_scene {
+  const void* tlas; const void* blas; const void* bvh; const void* tri; const void* triEx; const void* triIdx; const void* tex;
+  uint32_t n_tlas_nodes, n_blas, n_bvh_nodes, n_tris, n_tri_idx, tlas_root;
+  uint64_t tex_bytes;
+} vxrc_scene_t;
+typedef struct vxrc_params {     /* the fields of raycast/common.h:126-150 kernel_arg_t that are not addresses */
+  float camera_pos[3], camera_forward[3], camera_right[3], camera_up[3], viewplane[2];
+  uint32_t samples_per_pixel, max_depth;
+  float light_pos[3], light_color[3], ambient_color[3], background_color[3];
+} vxrc_params_t;
+/* Rows [y0,y1) of the frame kernel.cpp:9-33 renders: GenerateRay (render.h:192-211) -> Trace (:213-275) summed
+ * over the samples -> RGB32FtoRGB8 -> dst[x + y*W].  colors (optional): f32 rgb per pixel before packing.
+ * Every index the traversal follows is bounds-checked in the kernel; a violation, a stack deeper than the
+ * reference's BVH_STACK_SIZE (64, undefined behaviour there) or a runaway loop sets vxrt_status bits 4/1/2. */
+int vxrc_render(const vxrc_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                const vxrc_params_t* params, uint32_t* dst, float* colors, void* stream);
+
 /* Diagnostic variant of vxrt_render_stats: additionally logs per wavefront of the main traversal
  * launch {first clock, last clock (100 MHz constant clock), rays started, loop iterations, runs of the
  * node body, lanes active in them, runs of the leaf body, lanes active in them, node-body runs in which

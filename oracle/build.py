@@ -15,10 +15,11 @@ def _newer(target, sources):
 
 def build(force=False):
     so = os.path.join(HERE, "librt_oracle.so")
-    src = [os.path.join(HERE, "rt_oracle.c"), os.path.join(HERE, "rt_oracle.h")]
+    csrc = [os.path.join(HERE, "rt_oracle.c"), os.path.join(HERE, "rc_oracle.c")]
+    src = csrc + [os.path.join(HERE, "rt_oracle.h"), os.path.join(HERE, "rc_oracle.h")]
     if force or _newer(so, src):
         # flags are part of the oracle: no contraction, no -march=native, no fast-math
-        cmd = ["gcc", "-std=c99", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-o", so, src[0], "-lm"]
+        cmd = ["gcc", "-std=c99", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-o", so] + csrc + ["-lm"]
         print("+", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     if os.path.isdir(os.path.join(REF, "sim", "simx")):

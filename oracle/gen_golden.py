@@ -123,5 +123,47 @@ def main():
     make("cylinder", [wrap("cylinder.obj")], 96, 15)
 
 
+# ---------------------------------------------------------------------------------------------
+# software twin (tests/regression/raycast): fixtures from the reference's own CPU path
+# ---------------------------------------------------------------------------------------------
+RC_ASSETS = "/root/reference/tests/regression/raycast/assets/"
+
+
+def gen_raycast():
+    """tests/golden/rc_*.npz: buffers built by the reference's raycast Scene/BVH/TLAS code, the camera of
+    Tracer::setup, and what the reference's own GenerateRay/Trace (its -c path) rendered; plus hit records of
+    TLASIntersect for a subset of the camera rays.  red.png travels as a data file with the texels stb_image
+    decoded from it (surface.cpp:28-55), to pin the package's own PNG decoder."""
+    cases = [
+        ("rc_teapot", ["teapot.obj"], ["red.png"], [0.0], 80, 60, 1, 1),
+        ("rc_teapot_x3", ["teapot.obj"] * 3, ["green.png", "red.png", "flower.png"], [0.0, 0.5, 0.3], 96, 64, 2, 3),
+        ("rc_torus_x2", ["torus.obj"] * 2, ["green.png", "blue.png"], [0.6, 0.4], 64, 48, 1, 4),
+        ("rc_cube_x2", ["cube.obj"] * 2, ["blue.png", "red.png"], [0.2, 0.9], 64, 48, 3, 5),
+    ]
+    for name, objs, texs, refl, w, h, spp, depth in cases:
+        sc = po.RefRcScene([RC_ASSETS + o for o in objs], [RC_ASSETS + t for t in texs], refl)
+        cam = sc.camera(45.0, 1.0, w, h)
+        light = np.array(po.RC_DEFAULT_LIGHT, np.float32)
+        px = sc.render(w, h, spp, depth, cam, light)
+        b = dict(sc.buffers)
+        b["tlas_root"] = sc.tlas_root
+        args = po.rc_args(b, w, h, cam, light, spp, depth)
+        rays = po.rc_camera_rays(args)[::5]
+        hits = sc.trace(rays)
+        out = dict(sc.buffers)
+        out.update(tlas_root=np.uint32(sc.tlas_root), cam14=cam, light12=light, width=np.uint32(w), height=np.uint32(h),
+                   spp=np.uint32(spp), max_depth=np.uint32(depth), pixels=px, rays=rays, hits=hits)
+        if name == "rc_teapot":
+            out["red_png"] = np.frombuffer(open(RC_ASSETS + "red.png", "rb").read(), np.uint8)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k in ("tri", "bvh", "tex", "pixels", "hits")},
+              "non-background %.3f" % (px != px[0, 0]).mean(), "hits", int((hits["dist"] < 1e29).sum()))
+        sc.close()
+
+
 if __name__ == "__main__":
-    main()
+    if "--raycast" in sys.argv:      # python -m oracle.gen_golden --raycast : only the software-twin fixtures
+        gen_raycast()
+    else:
+        main()
+        gen_raycast()

@@ -105,6 +105,155 @@ def _p(a):
     return a.ctypes.data if a is not None else None
 
 
+# ---- software twin (tests/regression/raycast) through the reference's own object code ----
+REF_RC_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libvxref_rc.so")
+_ref_rc = None
+RC_BUFFERS = ("tlas", "blas", "bvh", "tri", "triEx", "triIdx", "tex")
+
+
+def have_ref_rc():
+    return os.path.exists(REF_RC_SO)
+
+
+def ref_rc():
+    global _ref_rc
+    if _ref_rc is None:
+        L = C.CDLL(REF_RC_SO)
+        vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+        L.rcref_scene_create.restype = vp
+        L.rcref_scene_create.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int, C.c_int]
+        L.rcref_scene_destroy.argtypes = [vp]
+        L.rcref_scene_buffer.restype = u64
+        L.rcref_scene_buffer.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.rcref_tlas_root.restype = u32
+        L.rcref_tlas_root.argtypes = [vp]
+        L.rcref_sizeof.restype = u32
+        L.rcref_camera.argtypes = [vp, C.c_float, C.c_float, u32, u32, vp]
+        L.rcref_render.restype = C.c_int
+        L.rcref_render.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp]
+        L.rcref_trace.argtypes = [vp, vp, vp, vp, vp, vp]
+        _ref_rc = L
+    return _ref_rc
+
+
+class RcArgs(C.Structure):   # rc_args_t (oracle/rc_oracle.h)
+    _fields_ = [("dst_width", C.c_uint32), ("dst_height", C.c_uint32),
+                ("tri", C.c_void_p), ("triEx", C.c_void_p), ("triIdx", C.c_void_p), ("tex", C.c_void_p),
+                ("bvh", C.c_void_p), ("blas", C.c_void_p), ("tlas", C.c_void_p), ("tlas_root", C.c_uint32),
+                ("camera_pos", C.c_float * 3), ("camera_forward", C.c_float * 3), ("camera_right", C.c_float * 3),
+                ("camera_up", C.c_float * 3), ("viewplane", C.c_float * 2),
+                ("samples_per_pixel", C.c_uint32), ("max_depth", C.c_uint32),
+                ("light_pos", C.c_float * 3), ("light_color", C.c_float * 3), ("ambient_color", C.c_float * 3),
+                ("background_color", C.c_float * 3)]
+
+
+RC_DEFAULT_LIGHT = (0.0, 10.0, -10.0, 1.0, 1.0, 1.0, 0.4, 0.4, 0.4, 0.4, 0.35, 0.25)   # raycast/main.cpp:29-32
+
+
+def rc_args(scene, w, h, cam14, light12=RC_DEFAULT_LIGHT, spp=1, max_depth=1, tlas_root=None):
+    """rc_args_t over the buffers of a raycast scene (dict of uint8 arrays: tlas, blas, bvh, tri, triEx, triIdx, tex).
+    The returned object keeps the arrays alive."""
+    a = RcArgs()
+    keep = {k: np.ascontiguousarray(scene[k], np.uint8) for k in RC_BUFFERS}
+    a.dst_width, a.dst_height = w, h
+    for k in RC_BUFFERS:
+        setattr(a, k, keep[k].ctypes.data if keep[k].size else None)
+    a.tlas_root = int(scene["tlas_root"]) if tlas_root is None else tlas_root
+    cam14 = [float(v) for v in cam14]
+    a.camera_pos[:] = cam14[0:3]; a.camera_forward[:] = cam14[3:6]; a.camera_right[:] = cam14[6:9]
+    a.camera_up[:] = cam14[9:12]; a.viewplane[:] = cam14[12:14]
+    a.samples_per_pixel, a.max_depth = spp, max_depth
+    l = [float(v) for v in light12]
+    a.light_pos[:] = l[0:3]; a.light_color[:] = l[3:6]; a.ambient_color[:] = l[6:9]; a.background_color[:] = l[9:12]
+    a._keep = keep
+    return a
+
+
+def rc_render(args, y0=0, y1=None):
+    """oracle/rc_oracle.c:rc_render -> pixels [h, w] u32, colours [h, w, 3] f32"""
+    L = orc()
+    h, w = args.dst_height, args.dst_width
+    y1 = h if y1 is None else y1
+    px = np.zeros((h, w), np.uint32)
+    col = np.zeros((h, w, 3), np.float32)
+    L.rc_render.restype = C.c_int
+    L.rc_render.argtypes = [C.POINTER(RcArgs), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    if L.rc_render(C.byref(args), y0, y1, _p(px), _p(col)) != 0:
+        raise RuntimeError("rc_render: traversal stack would exceed BVH_STACK_SIZE")
+    return px, col
+
+
+def rc_trace(args, rays):
+    L = orc()
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    out = np.zeros(len(rays), HIT_DTYPE)
+    L.rc_trace.restype = C.c_int
+    L.rc_trace.argtypes = [C.POINTER(RcArgs), C.c_void_p, C.c_void_p]
+    for i in range(len(rays)):
+        if L.rc_trace(C.byref(args), rays[i].ctypes.data, out[i:i + 1].ctypes.data) != 0:
+            raise RuntimeError("rc_trace: stack")
+    return out
+
+
+def rc_camera_rays(args):
+    L = orc()
+    h, w = args.dst_height, args.dst_width
+    out = np.zeros((h * w, 6), np.float32)
+    L.rc_generate_ray.argtypes = [C.POINTER(RcArgs), C.c_uint32, C.c_uint32, C.c_void_p]
+    for y in range(h):
+        for x in range(w):
+            L.rc_generate_ray(C.byref(args), x, y, out[y * w + x].ctypes.data)
+    return out
+
+
+class RefRcScene:
+    """A scene built by the reference's raycast Scene/BVH/TLAS code (oracle/_ref/libvxref_rc.so)."""
+
+    def __init__(self, objs, texs, refl, rotate=True):
+        L = ref_rc()
+        n = len(objs)
+        a = (C.c_char_p * n)(*[o.encode() for o in objs])
+        t = (C.c_char_p * n)(*[x.encode() for x in texs])
+        r = (C.c_float * n)(*refl)
+        self.h = L.rcref_scene_create(a, t, r, n, 1 if rotate else 0)
+        if not self.h:
+            raise RuntimeError("reference raycast scene build failed")
+        self.buffers = {}
+        for i, k in enumerate(RC_BUFFERS):
+            ptr = C.c_void_p()
+            size = L.rcref_scene_buffer(self.h, i, C.byref(ptr))
+            self.buffers[k] = np.frombuffer((C.c_uint8 * size).from_address(ptr.value), np.uint8).copy() if size else np.zeros(0, np.uint8)
+        self.tlas_root = int(L.rcref_tlas_root(self.h))
+
+    def camera(self, vfov_deg, zoom, w, h):
+        out = np.zeros(14, np.float32)
+        ref_rc().rcref_camera(self.h, vfov_deg, zoom, w, h, _p(out))
+        return out
+
+    def render(self, w, h, spp, max_depth, cam14, light12):
+        out = np.zeros((h, w), np.uint32)
+        cam14 = np.ascontiguousarray(cam14, np.float32)
+        light12 = np.ascontiguousarray(light12, np.float32)
+        ref_rc().rcref_render(self.h, w, h, spp, max_depth, _p(cam14), _p(light12), _p(out))
+        return out
+
+    def trace(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros(len(rays), HIT_DTYPE)
+        d, bc, bi, ti = C.c_float(), (C.c_float * 3)(), C.c_uint32(), C.c_uint32()
+        L = ref_rc()
+        for i, r in enumerate(rays):
+            rr = np.ascontiguousarray(r)
+            L.rcref_trace(self.h, _p(rr), C.byref(d), bc, C.byref(bi), C.byref(ti))
+            out[i] = (d.value, bc[0], bc[1], bc[2], bi.value, ti.value)
+        return out
+
+    def close(self):
+        if self.h:
+            ref_rc().rcref_scene_destroy(self.h)
+            self.h = None
+
+
 class Image:
     """Flat device-memory image + the four 32-bit DCR offsets (tracer.cpp:252-256), 64-byte aligned."""
 

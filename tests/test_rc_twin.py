@@ -1,0 +1,112 @@
+"""Software twin (tests/regression/raycast).  The fixtures tests/golden/rc_*.npz hold buffers built
+by the reference's own raycast Scene/BVH/TLAS code and what its own CPU path (GenerateRay/Trace, tracer.cpp:249-263)
+rendered: the restatement oracle/rc_oracle.c and the HIP kernel must reproduce the pixels exactly."""
+import numpy as np
+import pytest
+
+RC_FIXTURES = ["rc_teapot", "rc_teapot_x3", "rc_torus_x2", "rc_cube_x2"]
+
+
+def _args(po, g):
+    sc = {k: g[k] for k in po.RC_BUFFERS}
+    sc["tlas_root"] = int(g["tlas_root"])
+    return po.rc_args(sc, int(g["width"]), int(g["height"]), g["cam14"], g["light12"], int(g["spp"]), int(g["max_depth"]))
+
+
+@pytest.mark.parametrize("name", RC_FIXTURES)
+def test_restatement_matches_reference_cpu_path(po, golden, name):
+    g = golden(name)
+    a = _args(po, g)
+    px, col = po.rc_render(a)
+    np.testing.assert_array_equal(px, g["pixels"])
+    assert (px != px[0, 0]).mean() > 0.1
+    hits = po.rc_trace(a, g["rays"])
+    assert np.array_equal(hits.view(np.uint8), g["hits"].view(np.uint8))
+    np.testing.assert_array_equal(po.rc_camera_rays(a)[::5], g["rays"])
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("vfov,zoom,depth,spp", [(45.0, 1.0, 1, 1), (46.0, 1.0, 4, 2)])
+def test_restatement_equals_reference_object_code_live(po, golden, vfov, zoom, depth, spp):
+    """Fresh cameras on reference-built scenes, through oracle/_ref/libvxref_rc.so (skipped where it was not built)."""
+    import os
+    A = "/root/reference/tests/regression/raycast/assets/"
+    if not po.have_ref_rc() or not os.path.isdir(A):
+        pytest.skip("oracle/_ref/libvxref_rc.so or the reference assets are not here")
+    sc = po.RefRcScene([A + "sphere.obj", A + "cone.obj"], [A + "bricks.png", A + "green.png"], [0.35, 0.0])
+    w, h = 72, 52
+    cam = sc.camera(vfov, zoom, w, h)
+    ref = sc.render(w, h, spp, depth, cam, po.RC_DEFAULT_LIGHT)
+    b = dict(sc.buffers)
+    b["tlas_root"] = sc.tlas_root
+    px, _ = po.rc_render(po.rc_args(b, w, h, cam, po.RC_DEFAULT_LIGHT, spp, depth))
+    sc.close()
+    np.testing.assert_array_equal(px, ref)
+    assert (ref != ref[0, 0]).mean() > 0.01
+
+
+def test_png_decoder_equals_stb_on_a_reference_asset(vrt, golden, tmp_path):
+    """rc_teapot carries the reference's red.png (data file) and, in its texture buffer, the texels stb_image decoded
+    from it (surface.cpp:28-55): the package's own PNG decoder must produce the same words."""
+    g = golden("rc_teapot")
+    f = tmp_path / "red.png"
+    f.write_bytes(g["red_png"].tobytes())
+    got = vrt.scene.image_load(f)
+    blas = g["blas"].view(np.uint32).reshape(-1, 40)
+    tw, th, off = int(blas[0, 36]), int(blas[0, 37]), int(blas[0, 34])
+    assert got.shape == (th, tw)
+    want = g["tex"][off:off + tw * th * 4].view(np.uint32).reshape(th, tw)
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", RC_FIXTURES)
+def test_hip_twin_matches_reference_pixels(vrt, po, golden, gpu_device, name):
+    import torch
+    g = golden(name)
+    sc = {k: g[k] for k in po.RC_BUFFERS}
+    sc["tlas_root"] = int(g["tlas_root"])
+    w, h = int(g["width"]), int(g["height"])
+    ds = vrt.tracer.RcDeviceScene(sc, gpu_device)
+    prm = vrt.rtapi.rc_params(g["cam14"], g["light12"], int(g["spp"]), int(g["max_depth"]))
+    px = torch.full((h, w), -1, dtype=torch.int32, device=gpu_device)
+    col = torch.zeros(h * w * 3, dtype=torch.float32, device=gpu_device)
+    stream = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.rc_render(ds.c, w, h, 0, h, prm, px.data_ptr(), col.data_ptr(), stream)
+    assert vrt.rtapi.status(stream) == 0
+    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), g["pixels"])
+    _, ocol = po.rc_render(_args(po, g))
+    np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3), ocol, rtol=1e-5)
+    # row window: only rows [y0,y1) are written
+    px2 = torch.full((h, w), 0x7EADBEEF, dtype=torch.int32, device=gpu_device)
+    vrt.rtapi.rc_render(ds.c, w, h, 8, 20, prm, px2.data_ptr(), None, stream)
+    out = px2.cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(out[8:20], g["pixels"][8:20])
+    assert (out[:8] == 0x7EADBEEF).all() and (out[20:] == 0x7EADBEEF).all()
+
+
+@pytest.mark.gpu
+def test_twin_through_vx_api_and_bad_scenes(vrt, po, golden, gpu_device):
+    """raycast/tracer.cpp's call sequence (vx_mem_alloc x8, vx_copy_to_dev x7, vx_upload_bytes(kernel_arg_t 192 B),
+    vx_start, vx_ready_wait, vx_copy_from_dev) against libvortex-hip.so with the raycast kernel selector."""
+    g = golden("rc_teapot_x3")
+    sc = {k: g[k] for k in po.RC_BUFFERS}
+    sc["tlas_root"] = int(g["tlas_root"])
+    w, h = int(g["width"]), int(g["height"])
+    tr = vrt.tracer.RaycastTracer(w, h, int(g["spp"]), int(g["max_depth"]))
+    tr.init(sc)
+    tr.setup(g["cam14"], g["light12"])
+    px = tr.run()
+    np.testing.assert_array_equal(px, g["pixels"])
+    # a BVH node pointing outside the buffer is caught by the in-kernel bounds checks: ready_wait fails, nothing faults
+    bad = {k: v.copy() for k, v in sc.items() if k != "tlas_root"}
+    bad["tlas_root"] = sc["tlas_root"]
+    nodes = bad["bvh"].view(np.uint32).reshape(-1, 8)
+    inner = int(np.nonzero(nodes[:, 7] == 0)[0][0])
+    nodes[inner, 3] = 0x7FFFFFF0
+    tr2 = vrt.tracer.RaycastTracer(w, h, 1, 1)
+    tr2.init(bad)
+    tr2.setup(g["cam14"], g["light12"])
+    with pytest.raises(vrt.runtime.VxError):
+        tr2.run()
+    tr.close()

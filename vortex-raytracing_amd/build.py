@@ -33,6 +33,8 @@ SELECTORS = {
     "miss": (0x80100000, "raytracing.miss"),
     "closest": (0x80200000, "raytracing.closest"),
     "anyhit": (0x80300000, "raytracing.anyhit"),
+    # the software twin's single kernel image (tests/regression/raycast loads "kernel.vxbin" from its own directory)
+    "raycast/kernel": (0x80000000, "raycast.kernel"),
 }
 
 
@@ -54,6 +56,7 @@ def write_selectors():
         payload = ("VXHIP1:" + tag).encode() + b"\0"
         payload += b"\0" * (64 - len(payload))
         blob = struct.pack("<QQ", vma, vma + 0x1000) + payload   # kernel/scripts/vxbin.py:53-74
+        os.makedirs(os.path.dirname(os.path.join(VXBIN, name)), exist_ok=True)
         with open(os.path.join(VXBIN, name + ".vxbin"), "wb") as f:
             f.write(blob)
 
@@ -65,7 +68,7 @@ def build(force=False, verbose=True):
         raise RuntimeError("hipcc not found at %s: the HIP path cannot be built" % HIPCC)
 
     hip_so = os.path.join(LIB, "libvortex-hip.so")
-    hip_src = [os.path.join(CSRC, "rt_kernels.hip"), os.path.join(CSRC, "vx_backend.hip")]
+    hip_src = [os.path.join(CSRC, "rt_kernels.hip"), os.path.join(CSRC, "rc_kernels.hip"), os.path.join(CSRC, "vx_backend.hip")]
     if force or _newer(hip_so, hip_src + hdrs):
         _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", hip_so] + hip_src)
 

@@ -1373,6 +1373,8 @@ static int release_ctx(FrameCtx* c, hipStream_t s) {
   return 0;
 }
 
+extern "C" uint32_t* vxrt_status_word_device(void) { return status_word(); }   // shared with rc_kernels.hip (not part of the public header)
+
 extern "C" {
 
 const char* vxrt_version(void) { return "vortex-rt-mi355x 0.3 (gfx950, compact 64-byte nodes, persistent wavefronts)"; }

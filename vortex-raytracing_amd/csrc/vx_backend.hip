@@ -224,6 +224,7 @@ struct vx_device {
   }
 
   int start(uint64_t krnl_va, uint64_t args_va);
+  int start_raycast(uint64_t args_va);
   int ready_wait(uint64_t timeout_ms);
 };
 
@@ -236,6 +237,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   dcrs[VX_DCR_BASE_STARTUP_ARG1] = (uint32_t)(args_va >> 32);
 
   const std::string tag = tag_of(krnl_va);
+  if (tag == "raycast.kernel") return start_raycast(args_va);   // the software twin (tests/regression/raycast)
   if (tag != "raytracing.kernel") {
     VXLOG("start: kernel image at 0x%llx is not a HIP kernel selector (tag '%s'); this backend cannot run RISC-V binaries",
           (unsigned long long)krnl_va, tag.c_str());
@@ -323,6 +325,68 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
                        (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, nullptr, d_rays, stream);
   if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
   if (rc != 0) { VXLOG("start: launch rejected (shape check)"); return -1; }
+  run_pending = true;
+  return 0;
+}
+
+// tests/regression/raycast: kernel_arg_t of raycast/common.h:126-150 (192 bytes; offsets checked against the
+// reference header with offsetof), all buffers addressed through it (tracer.cpp:107-150), no DCRs, no SBT.
+#pragma pack(push, 1)
+struct rc_kernel_arg_t {
+  uint32_t dst_width, dst_height; uint64_t dst_addr;
+  uint64_t tri_addr, triEx_addr, triIdx_addr, tex_addr, bvh_addr, blas_addr, tlas_addr;
+  uint32_t tlas_root;
+  float camera_pos[3], camera_forward[3], camera_right[3], camera_up[3], viewplane[2];
+  uint32_t samples_per_pixel, max_depth;
+  float light_pos[3], light_color[3], ambient_color[3], background_color[3];
+  uint32_t _pad;
+};
+#pragma pack(pop)
+static_assert(sizeof(rc_kernel_arg_t) == 192, "raycast kernel_arg_t layout");
+
+int vx_device::start_raycast(uint64_t args_va) {
+  Alloc* aa = find(args_va, sizeof(rc_kernel_arg_t));
+  if (!aa || aa->shadow.size() < (args_va - aa->va) + sizeof(rc_kernel_arg_t)) { VXLOG("start: bad raycast kernel_arg buffer"); return -1; }
+  rc_kernel_arg_t ka;
+  std::memcpy(&ka, aa->shadow.data() + (args_va - aa->va), sizeof ka);
+  if (ka.samples_per_pixel == 0) { VXLOG("start: samples_per_pixel == 0"); return -1; }
+  struct Res { Alloc* a; uint64_t off; };
+  auto res64 = [&](uint64_t va) -> Res { Alloc* a = find(va); return {a, a ? va - a->va : 0}; };
+  Res r_tri = res64(ka.tri_addr), r_triex = res64(ka.triEx_addr), r_idx = res64(ka.triIdx_addr), r_tex = res64(ka.tex_addr);
+  Res r_bvh = res64(ka.bvh_addr), r_blas = res64(ka.blas_addr), r_tlas = res64(ka.tlas_addr), r_dst = res64(ka.dst_addr);
+  if (!r_tri.a || !r_triex.a || !r_idx.a || !r_tex.a || !r_bvh.a || !r_blas.a || !r_tlas.a || !r_dst.a) {
+    VXLOG("start: a raycast scene/output address does not name device memory");
+    return -1;
+  }
+  auto ptr = [](Res r) { return (const void*)((const char*)r.a->dptr + r.off); };
+  auto count = [](Res r, uint64_t stride) { return (uint32_t)std::min<uint64_t>((r.a->size - r.off) / stride, 0x7fffffff); };
+  vxrc_scene_t sc{};
+  sc.tlas = ptr(r_tlas); sc.blas = ptr(r_blas); sc.bvh = ptr(r_bvh); sc.tri = ptr(r_tri); sc.triEx = ptr(r_triex);
+  sc.triIdx = ptr(r_idx); sc.tex = ptr(r_tex);
+  sc.n_tlas_nodes = count(r_tlas, 32); sc.n_blas = count(r_blas, 160); sc.n_bvh_nodes = count(r_bvh, 32);
+  sc.n_tris = std::min(count(r_tri, 36), count(r_triex, 60)); sc.n_tri_idx = count(r_idx, 4);
+  sc.tex_bytes = r_tex.a->size - r_tex.off;
+  sc.tlas_root = ka.tlas_root;
+  if ((uint64_t)ka.dst_width * ka.dst_height * 4 > r_dst.a->size - r_dst.off) { VXLOG("start: output buffer too small"); return -1; }
+  vxrc_params_t pr{};
+  for (int i = 0; i < 3; ++i) {
+    pr.camera_pos[i] = ka.camera_pos[i]; pr.camera_forward[i] = ka.camera_forward[i]; pr.camera_right[i] = ka.camera_right[i];
+    pr.camera_up[i] = ka.camera_up[i]; pr.light_pos[i] = ka.light_pos[i]; pr.light_color[i] = ka.light_color[i];
+    pr.ambient_color[i] = ka.ambient_color[i]; pr.background_color[i] = ka.background_color[i];
+  }
+  pr.viewplane[0] = ka.viewplane[0]; pr.viewplane[1] = ka.viewplane[1];
+  pr.samples_per_pixel = ka.samples_per_pixel; pr.max_depth = ka.max_depth;
+  uint32_t y0 = 0, y1 = 0;
+  auto dcr = [&](uint32_t id, uint32_t* v) { auto it = dcrs.find(id); if (it == dcrs.end()) return false; *v = it->second; return true; };
+  dcr(VX_DCR_HIP_ROW_BEGIN, &y0);
+  dcr(VX_DCR_HIP_ROW_END, &y1);
+  if (y1 == 0 || y1 > ka.dst_height) y1 = ka.dst_height;
+  if (y0 > y1) y0 = y1;
+  if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
+  if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
+  const int rc = vxrc_render(&sc, ka.dst_width, ka.dst_height, y0, y1, &pr, (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, stream);
+  if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
+  if (rc != 0) { VXLOG("start: raycast launch rejected (shape check)"); return -1; }
   run_pending = true;
   return 0;
 }

@@ -106,6 +106,39 @@ def trace_stats(accel, rays_ptr, n, hits_ptr, mode=0, tmax_ptr=None, stream=None
     return {"rays": r, "node_fetches": nn, "inst_fetches": ni, "tri_fetches": nt, "bytes": total, "bytes_per_ray": total / max(r, 1)}
 
 
+class RcScene(C.Structure):    # vxrc_scene_t
+    _fields_ = [(k, C.c_void_p) for k in ("tlas", "blas", "bvh", "tri", "triEx", "triIdx", "tex")] + \
+               [(k, C.c_uint32) for k in ("n_tlas_nodes", "n_blas", "n_bvh_nodes", "n_tris", "n_tri_idx", "tlas_root")] + \
+               [("tex_bytes", C.c_uint64)]
+
+
+class RcParams(C.Structure):   # vxrc_params_t
+    _fields_ = [("camera_pos", C.c_float * 3), ("camera_forward", C.c_float * 3), ("camera_right", C.c_float * 3),
+                ("camera_up", C.c_float * 3), ("viewplane", C.c_float * 2),
+                ("samples_per_pixel", C.c_uint32), ("max_depth", C.c_uint32),
+                ("light_pos", C.c_float * 3), ("light_color", C.c_float * 3), ("ambient_color", C.c_float * 3),
+                ("background_color", C.c_float * 3)]
+
+
+def rc_params(cam14, light12, spp=1, max_depth=1):
+    p = RcParams()
+    c = [float(v) for v in cam14]
+    p.camera_pos[:] = c[0:3]; p.camera_forward[:] = c[3:6]; p.camera_right[:] = c[6:9]; p.camera_up[:] = c[9:12]; p.viewplane[:] = c[12:14]
+    l = [float(v) for v in light12]
+    p.light_pos[:] = l[0:3]; p.light_color[:] = l[3:6]; p.ambient_color[:] = l[6:9]; p.background_color[:] = l[9:12]
+    p.samples_per_pixel, p.max_depth = int(spp), int(max_depth)
+    return p
+
+
+def rc_render(scene, width, height, y0, y1, params, dst_ptr, colors_ptr=None, stream=None):
+    """vxrc_render: the software twin (tests/regression/raycast) on device buffers described by an RcScene."""
+    L = _lib()
+    L.vxrc_render.restype = C.c_int
+    L.vxrc_render.argtypes = [C.POINTER(RcScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RcParams),
+                              C.c_void_p, C.c_void_p, C.c_void_p]
+    check(L.vxrc_render(C.byref(scene), width, height, y0, y1, C.byref(params), dst_ptr, colors_ptr, stream), "vxrc_render")
+
+
 class AoParams(C.Structure):   # vxrt_ao_params_t
     _fields_ = [("spp", C.c_uint32), ("radius", C.c_float), ("seed", C.c_uint32), ("reserved", C.c_uint32)]
 

@@ -134,3 +134,84 @@ def write_ppm(pixels, path):
         f.write("P3\n%d %d\n255\n" % (w, h))
         # the reference streams float(byte) through operator<<, i.e. "b g r" of the little-endian pixel bytes 2,1,0
         np.savetxt(f, np.stack([b2, b1, b0], axis=1), fmt="%d")
+
+
+# ---------------------------------------------------------------------------------------------
+# software twin: tests/regression/raycast/tracer.cpp through the same vx_* calls
+# ---------------------------------------------------------------------------------------------
+RC_KERNEL_ARG_FMT = "<IIQ7QI12f2fII12fI"   # raycast/common.h:126-150, 192 bytes
+assert struct.calcsize(RC_KERNEL_ARG_FMT) == 192
+RC_VXBIN_DIR = os.path.join(VXBIN_DIR, "raycast")
+RC_BUFFERS = ("tri", "triEx", "triIdx", "tlas", "blas", "bvh", "tex")
+
+
+class RaycastTracer:
+    """Call sequence of raycast/tracer.cpp (init :107-150, setup :168-224, run :226-247) on buffers already in the
+    reference's formats (dict of uint8 arrays + tlas_root), with camera/light as Tracer::setup computes them."""
+
+    def __init__(self, width, height, samples_per_pixel=1, max_depth=1):
+        self.width, self.height, self.spp, self.max_depth = width, height, samples_per_pixel, max_depth
+        self.dev, self.bufs, self.args = None, {}, None
+
+    def init(self, scene, vxbin_dir=RC_VXBIN_DIR):
+        self.scene = scene
+        d = self.dev = runtime.Device()
+        self.krnl = d.upload_kernel_file(os.path.join(vxbin_dir, "kernel.vxbin"))
+        for k in RC_BUFFERS:
+            self.bufs[k] = d.mem_alloc(int(scene[k].size), runtime.VX_MEM_READ)
+        self.bufs["out"] = d.mem_alloc(self.width * self.height * 4, runtime.VX_MEM_WRITE)
+        return 0
+
+    def setup(self, cam14, light12, row_window=None):
+        d = self.dev
+        for k in RC_BUFFERS:
+            self.bufs[k].write(self.scene[k])
+        a = {k: b.address for k, b in self.bufs.items()}
+        y0, y1 = row_window if row_window else (0, 0)
+        d.dcr_write(runtime.VX_DCR_HIP_ROW_BEGIN, y0)
+        d.dcr_write(runtime.VX_DCR_HIP_ROW_END, y1)
+        self.kernel_arg = struct.pack(
+            RC_KERNEL_ARG_FMT, self.width, self.height, a["out"], a["tri"], a["triEx"], a["triIdx"], a["tex"], a["bvh"], a["blas"], a["tlas"],
+            int(self.scene["tlas_root"]), *[float(v) for v in cam14[:12]], float(cam14[12]), float(cam14[13]), self.spp, self.max_depth,
+            *[float(v) for v in light12], 0)
+        return 0
+
+    def run(self):
+        d = self.dev
+        if self.args is not None:
+            self.args.free()
+        self.args = d.upload_bytes(self.kernel_arg)
+        d.start(self.krnl, self.args)
+        d.ready_wait(runtime.VX_MAX_TIMEOUT)
+        raw = self.bufs["out"].read()
+        return np.frombuffer(raw, dtype=np.uint32).reshape(self.height, self.width).copy()
+
+    def close(self):
+        if self.dev is None:
+            return
+        for b in list(self.bufs.values()) + [self.args, self.krnl]:
+            if b is not None:
+                b.free()
+        self.bufs = {}
+        self.dev.close()
+        self.dev = None
+
+
+class RcDeviceScene:
+    """Raycast scene buffers resident in HBM as torch uint8 tensors + the vxrc_scene_t that points at them."""
+
+    def __init__(self, scene, device="cuda:0"):
+        import torch
+        self.device = device
+        self.t = {k: torch.from_numpy(np.ascontiguousarray(scene[k], np.uint8)).to(device) for k in RC_BUFFERS}
+        s = rtapi.RcScene()
+        for k, t in self.t.items():
+            setattr(s, k, t.data_ptr() if t.numel() else None)
+        s.n_tlas_nodes = scene["tlas"].size // 32
+        s.n_blas = scene["blas"].size // 160
+        s.n_bvh_nodes = scene["bvh"].size // 32
+        s.n_tris = min(scene["tri"].size // 36, scene["triEx"].size // 60)
+        s.n_tri_idx = scene["triIdx"].size // 4
+        s.tlas_root = int(scene["tlas_root"])
+        s.tex_bytes = scene["tex"].size
+        self.c = s
