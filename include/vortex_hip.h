@@ -273,9 +273,10 @@ int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, u
 int vxrt_trace(vxrt_accel_t* accel, const float* rays, uint64_t n, const float* tmax,
                vxrt_hit_t* hits, int mode, void* stream);
 
-/* Status word of the last launches on this device: 0 = ok, bit0 = traversal stack overflow
- * (tree deeper than the 32 levels the reference's own trail supports), bit1 = iteration limit.
- * Synchronises `stream`. */
+/* Status word of the launches on this device since the last call: 0 = ok, bit0 = traversal stack overflow
+ * (tree deeper than the 32 levels the reference's own trail supports; the twin: deeper than BVH_STACK_SIZE),
+ * bit1 = iteration limit, bit2 = the twin's kernel met an index outside its buffers.  Synchronises `stream`;
+ * a non-zero word is cleared by the call (read-and-clear), so one failed run does not fail the next. */
 int vxrt_status(void* stream, uint32_t* status);
 /* Raw device pointer behind a vx_buffer_h of the hip backend (for zero-copy hand-off to RCCL). */
 int vx_hip_buffer_device_ptr(vx_buffer_h hbuffer, void** dev_ptr);

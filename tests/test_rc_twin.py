@@ -110,3 +110,82 @@ def test_twin_through_vx_api_and_bad_scenes(vrt, po, golden, gpu_device):
     with pytest.raises(vrt.runtime.VxError):
         tr2.run()
     tr.close()
+
+
+def test_rc_scene_builder_invariants_and_oracle_render(vrt, po):
+    """The package's BVH2/TLAS builder in the twin's formats: children adjacent, leaves index triIdx, boxes contain
+    their triangles, TLAS child indices 16 bit, and the restatement renders it (hits = brute force over all triangles)."""
+    sc = vrt.scene.rc_procedural("blob", 3, 0, 2, copies=3, reflectivity=[0.0, 0.4, 0.0])
+    bvh = sc["bvh"].view(np.uint32).reshape(-1, 8)
+    fb = sc["bvh"].view(np.float32).reshape(-1, 8)
+    tri = sc["tri"].view(np.float32).reshape(-1, 9)
+    idx = sc["triIdx"].view(np.uint32)
+    blas = sc["blas"].view(np.uint32).reshape(-1, 40)
+    assert len(blas) == 3 and len(idx) == len(tri)
+    covered = np.zeros(len(tri), int)
+    for b in range(3):
+        base = int(blas[b, 32])
+        end = int(blas[b + 1, 32]) if b + 1 < 3 else len(bvh)
+        stack = [0]
+        while stack:
+            n = stack.pop()
+            lf, tc = int(bvh[base + n, 3]), int(bvh[base + n, 7])
+            lo, hi = fb[base + n, 0:3], fb[base + n, 4:7]
+            if tc:
+                t = tri[idx[lf:lf + tc]].reshape(-1, 3)
+                assert (t >= lo - 1e-4).all() and (t <= hi + 1e-4).all()
+                covered[idx[lf:lf + tc]] += 1
+            else:
+                assert 0 < lf and lf + 1 < end - base
+                for c in (lf, lf + 1):
+                    assert (fb[base + c, 0:3] >= lo - 1e-4).all() and (fb[base + c, 4:7] <= hi + 1e-4).all()
+                stack += [lf, lf + 1]
+    assert (covered == 1).all()
+    tl = sc["tlas"].view(np.uint32).reshape(-1, 8)
+    assert tl[sc["tlas_root"], 3] != 0 and (tl[1:, 3] >> 16 < len(tl)).all()
+    w, h = 64, 40
+    cam = vrt.scene.rc_camera_like_rtu(w, h)
+    a = po.rc_args(sc, w, h, cam, po.RC_DEFAULT_LIGHT, 1, 2)
+    px, col = po.rc_render(a)
+    rays = po.rc_camera_rays(a)
+    hits = po.rc_trace(a, rays)
+    assert 0.02 < (hits["dist"] < 1e29).mean() < 0.98
+    # brute force in instance space for a sample of rays
+    inv = sc["blas"].view(np.float32).reshape(-1, 40)[:, 16:32].reshape(-1, 4, 4)
+    counts = np.diff(np.append(blas[:, 32], len(bvh)))
+    tri_of = np.cumsum([0] + [len(tri) // 3] * 3)
+    for r in rays[:: max(1, len(rays) // 60)]:
+        best = 1e30
+        for b in range(3):
+            o = inv[b][:3, :3] @ r[:3] + inv[b][:3, 3]
+            d = inv[b][:3, :3] @ r[3:]
+            T = tri[tri_of[b]:tri_of[b + 1]].astype(np.float64)
+            v0, e1, e2 = T[:, 0:3], T[:, 3:6] - T[:, 0:3], T[:, 6:9] - T[:, 0:3]
+            hh = np.cross(d, e2); aa = (e1 * hh).sum(1)
+            ok = np.abs(aa) >= 1e-6
+            f = np.where(ok, 1.0 / np.where(ok, aa, 1), 0)
+            s_ = o - v0; u = f * (s_ * hh).sum(1); q = np.cross(s_, e1); v = f * (q @ d); t = f * (e2 * q).sum(1)
+            m = ok & (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (t > 1e-6)
+            if m.any():
+                best = min(best, t[m].min())
+        got = float(po.rc_trace(a, r[None])["dist"][0])
+        assert (best > 1e29 and got > 1e29) or abs(got - best) <= 2e-4 * max(1.0, best)
+
+
+@pytest.mark.gpu
+def test_hip_twin_on_package_built_scene(vrt, po, gpu_device):
+    import torch
+    sc = vrt.scene.rc_procedural("blob", 4, 0, 5, copies=3, reflectivity=[0.5, 0.0, 0.3])
+    w, h = 200, 120
+    cam = vrt.scene.rc_camera_like_rtu(w, h)
+    light = (150.0, 300.0, -80.0, 1, 1, 1, 0.3, 0.3, 0.3, 0.4, 0.35, 0.25)
+    opx, ocol = po.rc_render(po.rc_args(sc, w, h, cam, light, 2, 3))
+    ds = vrt.tracer.RcDeviceScene(sc, gpu_device)
+    px = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
+    col = torch.zeros(h * w * 3, dtype=torch.float32, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.rc_render(ds.c, w, h, 0, h, vrt.rtapi.rc_params(cam, light, 2, 3), px.data_ptr(), col.data_ptr(), s)
+    assert vrt.rtapi.status(s) == 0
+    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), opx)
+    np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3), ocol, rtol=1e-5)
+    assert (opx != opx[0, 0]).mean() > 0.05

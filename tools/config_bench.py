@@ -73,6 +73,21 @@ def main():
         out.append({"config": "configs[4]: hairball, 1920x1080, 16 spp AO (tmax = 0.25 scene radius)", "tris": sc.n_tris, "bvh_nodes": sc.n_bvh_nodes,
                     "bvh_depth": sc.info.get("max_depth"), "host_build_s": round(build_s, 1), "rays_per_frame": rays,
                     "ms_per_frame": round(ms, 3), "mrays_s": round(rays / ms / 1e3, 1)})
+    if 6 in a.configs:
+        # software twin (tests/regression/raycast) on the same geometry in its own formats: BVH2, per-instance texture
+        t0 = time.time()
+        sc = vrt.scene.rc_procedural("atrium", 8, 0, 3)
+        build_s = time.time() - t0
+        ds = vrt.tracer.RcDeviceScene(sc, dev)
+        W, H = 1920, 1080
+        prm = rtapi.rc_params(vrt.scene.rc_camera_like_rtu(W, H), (300.0, 480.0, 60.0, 1, 1, 1, 0.4, 0.4, 0.4, 0.4, 0.35, 0.25), 1, 1)
+        px = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        ms = timed(lambda: rtapi.rc_render(ds.c, W, H, 0, H, prm, px.data_ptr(), None, s), 20)
+        assert rtapi.status(s) == 0
+        out.append({"config": "software twin (raycast): Sponza-class BVH2, 1920x1080, primary rays, 1 spp", "tris": sc["tri"].size // 36,
+                    "bvh2_nodes": sc["bvh"].size // 32, "bvh2_depth": sc["max_depth"], "host_build_s": round(build_s, 1),
+                    "ms_per_frame": round(ms, 3), "mrays_s": round(W * H / ms / 1e3, 1)})
     for o in out:
         print(json.dumps(o), flush=True)
 

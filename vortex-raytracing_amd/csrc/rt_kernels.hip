@@ -1819,6 +1819,8 @@ int vxrt_status(void* stream, uint32_t* status) {
   if (!st || !status) return -1;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
   if (hipMemcpy(status, st, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  // read-and-clear: a failed run must not poison the runs after it (the word is per device, shared by all launches)
+  if (*status != 0u && hipMemset(st, 0, sizeof(uint32_t)) != hipSuccess) return -1;
   return 0;
 }
 

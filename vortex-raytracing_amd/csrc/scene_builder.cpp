@@ -79,7 +79,7 @@ inline V3 tv(const float* p) { return {p[0], p[1], p[2]}; }
 // ---------------------------------------------------------------------------------------------
 class BlasBuilder {
 public:
-  BlasBuilder(rt_tri_t* tri, rt_triex_t* triEx, uint32_t n) : tri_(tri), triEx_(triEx), n_(n) {
+  BlasBuilder(rt_tri_t* tri, rt_triex_t* triEx, uint32_t n, uint32_t width = RT_BVH_WIDTH) : tri_(tri), triEx_(triEx), n_(n), width_(width) {
     cent_.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
       V3 s = tv(tri[i].v0) + tv(tri[i].v1) + tv(tri[i].v2);
@@ -207,7 +207,7 @@ private:
     if (deferred && depth > 0 && nodes[idx].triCount < defer_below) { deferred->push_back({idx, depth}); return; }
     std::vector<WideNode> cl;
     cl.push_back(nodes[idx]);
-    while (cl.size() < RT_BVH_WIDTH) {
+    while (cl.size() < width_) {
       Split bs; float bestDelta = 0.f; int bi = -1;
       for (int i = 0; i < (int)cl.size(); ++i) {
         if (cl[i].triCount <= 1) continue;
@@ -252,6 +252,7 @@ private:
   rt_tri_t* tri_;
   rt_triex_t* triEx_;
   uint32_t n_;
+  uint32_t width_;
   std::vector<V3> cent_;
 };
 
@@ -478,6 +479,127 @@ Scene* build_scene(std::vector<Mesh>& meshes) {
   uint32_t tlas_depth = 0;
   build_tlas_rec(*sc, items, 0, (uint32_t)items.size(), 0, 0, &tlas_depth);
   sc->max_depth = tlas_depth + blas_depth;   // TLAS leaf and BLAS root share a level (rt_traversal.cpp:109-121)
+  sc->bounds[0] = world.lo.x; sc->bounds[1] = world.lo.y; sc->bounds[2] = world.lo.z;
+  sc->bounds[3] = world.hi.x; sc->bounds[4] = world.hi.y; sc->bounds[5] = world.hi.z;
+  return sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scenes in the formats of the software twin (tests/regression/raycast/common.h): binary BVH of 32-byte
+// nodes with adjacent children, triIdx indirection (identity here: triangles are reordered in place),
+// 160-byte instance records carrying the texture, 32-byte TLAS nodes with 16-bit child indices.  Same SAH
+// builder with width 2; the reference's own builder is raycast/bvh.cpp (not reproduced node for node).
+// ---------------------------------------------------------------------------------------------
+#pragma pack(push, 1)
+struct rc_bvh_node_t { float aabbMin[3]; uint32_t leftFirst; float aabbMax[3]; uint32_t triCount; };
+struct rc_tlas_node_t { float aabbMin[3]; uint32_t leftRight; float aabbMax[3]; uint32_t blasIdx; };
+struct rc_blas_t { float transform[16]; float invTransform[16]; uint32_t bvh_offset, _pad0; uint64_t tex_offset; uint32_t tex_width, tex_height; float reflectivity; uint32_t _pad1; };
+struct rc_triex_t { float N0[3], N1[3], N2[3]; float uv0[2], uv1[2], uv2[2]; };
+#pragma pack(pop)
+static_assert(sizeof(rc_bvh_node_t) == 32 && sizeof(rc_tlas_node_t) == 32 && sizeof(rc_blas_t) == 160 && sizeof(rc_triex_t) == 60, "raycast layouts");
+
+struct RcScene {
+  std::vector<rc_tlas_node_t> tlas;
+  std::vector<rc_blas_t> blas;
+  std::vector<rc_bvh_node_t> bvh;
+  std::vector<rt_tri_t> tri;
+  std::vector<rc_triex_t> triEx;
+  std::vector<uint32_t> triIdx;
+  std::vector<uint8_t> tex;
+  uint32_t tlas_root = 0, max_depth = 0;
+  float bounds[6] = {0};
+};
+
+static uint32_t rc_tlas_rec(RcScene& sc, std::vector<TlasItem>& items, uint32_t begin, uint32_t end) {
+  if (end - begin == 1) {
+    rc_tlas_node_t n{};
+    const Box& b = items[begin].box;
+    n.aabbMin[0] = b.lo.x; n.aabbMin[1] = b.lo.y; n.aabbMin[2] = b.lo.z;
+    n.aabbMax[0] = b.hi.x; n.aabbMax[1] = b.hi.y; n.aabbMax[2] = b.hi.z;
+    n.leftRight = 0; n.blasIdx = items[begin].blasIdx;
+    sc.tlas.push_back(n);
+    return (uint32_t)sc.tlas.size() - 1;
+  }
+  Box cb;
+  for (uint32_t i = begin; i < end; ++i) cb.grow((items[i].box.lo + items[i].box.hi) * 0.5f);
+  const V3 ext = cb.hi - cb.lo;
+  const int axis = ext.x >= ext.y && ext.x >= ext.z ? 0 : (ext.y >= ext.z ? 1 : 2);
+  std::sort(items.begin() + begin, items.begin() + end, [&](const TlasItem& a, const TlasItem& b) {
+    return comp(a.box.lo + a.box.hi, axis) < comp(b.box.lo + b.box.hi, axis); });
+  const uint32_t mid = begin + (end - begin) / 2;
+  const uint32_t l = rc_tlas_rec(sc, items, begin, mid), r = rc_tlas_rec(sc, items, mid, end);
+  rc_tlas_node_t n{};
+  Box b; 
+  b.grow(V3{sc.tlas[l].aabbMin[0], sc.tlas[l].aabbMin[1], sc.tlas[l].aabbMin[2]}); b.grow(V3{sc.tlas[l].aabbMax[0], sc.tlas[l].aabbMax[1], sc.tlas[l].aabbMax[2]});
+  b.grow(V3{sc.tlas[r].aabbMin[0], sc.tlas[r].aabbMin[1], sc.tlas[r].aabbMin[2]}); b.grow(V3{sc.tlas[r].aabbMax[0], sc.tlas[r].aabbMax[1], sc.tlas[r].aabbMax[2]});
+  n.aabbMin[0] = b.lo.x; n.aabbMin[1] = b.lo.y; n.aabbMin[2] = b.lo.z;
+  n.aabbMax[0] = b.hi.x; n.aabbMax[1] = b.hi.y; n.aabbMax[2] = b.hi.z;
+  n.leftRight = (r << 16) | l;    // common.h:72-74 (16-bit indices)
+  n.blasIdx = 0;
+  sc.tlas.push_back(n);
+  return (uint32_t)sc.tlas.size() - 1;
+}
+
+RcScene* build_rc_scene(std::vector<Mesh>& meshes, const float* reflectivity) {
+  auto sc = new RcScene();
+  if (meshes.size() > 0x7fff) { delete sc; return nullptr; }   // TLAS child indices are 16 bit
+  std::vector<TlasItem> items;
+  uint32_t tri_off = 0, bvh_off = 0;
+  Box world;
+  for (size_t mi = 0; mi < meshes.size(); ++mi) {
+    Mesh& m = meshes[mi];
+    const uint32_t n = (uint32_t)m.tri.size();
+    sc->tri.insert(sc->tri.end(), m.tri.begin(), m.tri.end());
+    std::vector<rt_triex_t> ex(m.triEx);
+    BlasBuilder bb(sc->tri.data() + tri_off, ex.data(), n, 2);
+    for (uint32_t j = 0; j < n; ++j) {
+      rc_triex_t e;
+      std::memcpy(e.N0, ex[j].N0, sizeof e.N0); std::memcpy(e.N1, ex[j].N1, sizeof e.N1); std::memcpy(e.N2, ex[j].N2, sizeof e.N2);
+      std::memcpy(e.uv0, ex[j].uv0, sizeof e.uv0); std::memcpy(e.uv1, ex[j].uv1, sizeof e.uv1); std::memcpy(e.uv2, ex[j].uv2, sizeof e.uv2);
+      sc->triEx.push_back(e);
+    }
+    sc->max_depth = std::max(sc->max_depth, bb.max_depth_);
+    const uint32_t nn = (uint32_t)bb.nodes_.size();
+    sc->bvh.resize(bvh_off + nn);
+    for (uint32_t i = 0; i < nn; ++i) {
+      const WideNode& w = bb.nodes_[i];
+      rc_bvh_node_t& q = sc->bvh[bvh_off + i];
+      q.aabbMin[0] = w.box.lo.x; q.aabbMin[1] = w.box.lo.y; q.aabbMin[2] = w.box.lo.z;
+      q.aabbMax[0] = w.box.hi.x; q.aabbMax[1] = w.box.hi.y; q.aabbMax[2] = w.box.hi.z;
+      if (w.triCount == 0) { q.leftFirst = w.leftFirst; q.triCount = 0; }               // children left, left + 1 (render.h:103-104)
+      else { q.leftFirst = w.leftFirst + tri_off; q.triCount = w.triCount; }            // index into triIdx
+    }
+    rc_blas_t b{};
+    std::memcpy(b.transform, m.transform, sizeof b.transform);
+    if (!invert4(m.transform, b.invTransform)) { delete sc; return nullptr; }
+    b.bvh_offset = bvh_off;
+    b.tex_offset = sc->tex.size();
+    if (!m.textures.empty()) {
+      b.tex_width = m.tex_dims[0].first; b.tex_height = m.tex_dims[0].second;
+      const uint8_t* p = (const uint8_t*)m.textures[0].data();
+      sc->tex.insert(sc->tex.end(), p, p + m.textures[0].size() * 4);
+    } else {
+      const uint32_t px[4] = {0xC8C8C8u, 0xB4B4B4u, 0xB4B4B4u, 0xC8C8C8u};
+      b.tex_width = 2; b.tex_height = 2;
+      sc->tex.insert(sc->tex.end(), (const uint8_t*)px, (const uint8_t*)px + sizeof px);
+    }
+    b.reflectivity = reflectivity ? reflectivity[mi] : 0.0f;
+    sc->blas.push_back(b);
+    TlasItem it; it.blasIdx = (uint32_t)mi;
+    const Box& rb = bb.nodes_[0].box;
+    for (int c = 0; c < 8; ++c) {
+      V3 p{c & 1 ? rb.hi.x : rb.lo.x, c & 2 ? rb.hi.y : rb.lo.y, c & 4 ? rb.hi.z : rb.lo.z};
+      it.box.grow(xform_point(m.transform, p));
+    }
+    world.grow(it.box);
+    items.push_back(it);
+    tri_off += n; bvh_off += nn;
+  }
+  sc->triIdx.resize(tri_off);
+  for (uint32_t i = 0; i < tri_off; ++i) sc->triIdx[i] = i;
+  sc->tlas.emplace_back();            // index 0 is never a child: leftRight == 0 means "leaf" (common.h:68)
+  std::memset(&sc->tlas[0], 0, sizeof(rc_tlas_node_t));
+  sc->tlas_root = rc_tlas_rec(*sc, items, 0, (uint32_t)items.size());
   sc->bounds[0] = world.lo.x; sc->bounds[1] = world.lo.y; sc->bounds[2] = world.lo.z;
   sc->bounds[3] = world.hi.x; sc->bounds[4] = world.hi.y; sc->bounds[5] = world.hi.z;
   return sc;
@@ -1061,6 +1183,53 @@ void* vxs_scene_load_obj(const char* path, uint32_t instances) {
 }
 
 void vxs_scene_destroy(void* h) { delete (Scene*)h; }
+
+// software-twin scenes (raycast formats).  name / a / b / seed as vxs_scene_create_procedural; `copies` instances of the
+// mesh side by side along z, reflectivity[i] per instance (may be NULL)
+void* vxs_rc_scene_create_procedural(const char* name, uint32_t a, uint32_t b, uint32_t seed, uint32_t copies, const float* reflectivity) {
+  read_knobs();
+  std::string n(name ? name : "");
+  Mesh m0;
+  if (n == "cornell") m0 = make_cornell();
+  else if (n == "blob") m0 = make_blob(a, seed);
+  else if (n == "atrium") m0 = make_atrium(a, seed);
+  else if (n == "hairball") m0 = make_hairball(a, b, seed);
+  else return nullptr;
+  if (copies == 0) copies = 1;
+  Box mb;
+  for (const rt_tri_t& t : m0.tri) { mb.grow(tv(t.v0)); mb.grow(tv(t.v1)); mb.grow(tv(t.v2)); }
+  std::vector<Mesh> meshes(copies, m0);
+  for (uint32_t i = 0; i < copies; ++i) {
+    if (m0.textures.size() > 1) {   // vary the instance texture
+      meshes[i].textures[0] = m0.textures[i % m0.textures.size()];
+      meshes[i].tex_dims[0] = m0.tex_dims[i % m0.tex_dims.size()];
+    }
+    meshes[i].transform[11] = ((float)i - 0.5f * (float)(copies - 1)) * (mb.hi.z - mb.lo.z) * 1.15f;   // row-major: translation in column 3
+  }
+  return build_rc_scene(meshes, reflectivity);
+}
+void vxs_rc_scene_destroy(void* h) { delete (RcScene*)h; }
+// which: 0 tlas 1 blas 2 bvh 3 tri 4 triEx 5 triIdx 6 tex ; returns bytes
+uint64_t vxs_rc_scene_buffer(void* h, int which, const void** ptr) {
+  auto s = (RcScene*)h;
+  if (!s || !ptr) return 0;
+  switch (which) {
+  case 0: *ptr = s->tlas.data(); return s->tlas.size() * sizeof(rc_tlas_node_t);
+  case 1: *ptr = s->blas.data(); return s->blas.size() * sizeof(rc_blas_t);
+  case 2: *ptr = s->bvh.data(); return s->bvh.size() * sizeof(rc_bvh_node_t);
+  case 3: *ptr = s->tri.data(); return s->tri.size() * sizeof(rt_tri_t);
+  case 4: *ptr = s->triEx.data(); return s->triEx.size() * sizeof(rc_triex_t);
+  case 5: *ptr = s->triIdx.data(); return s->triIdx.size() * sizeof(uint32_t);
+  case 6: *ptr = s->tex.data(); return s->tex.size();
+  }
+  *ptr = nullptr;
+  return 0;
+}
+void vxs_rc_scene_info(void* h, uint32_t* out2, float* bounds6) {
+  auto s = (RcScene*)h;
+  if (out2) { out2[0] = s->tlas_root; out2[1] = s->max_depth; }
+  if (bounds6) std::memcpy(bounds6, s->bounds, sizeof s->bounds);
+}
 
 // which: 0 tlas 1 blas 2 bvh 3 tri 4 triEx 5 mat 6 tex 7 triIdx ; returns bytes
 uint64_t vxs_scene_buffer(void* h, int which, const void** ptr) {

@@ -125,3 +125,45 @@ def image_load(path):
 
 def load_obj(path, instances=1):
     return _from_handle(_load().vxs_scene_load_obj(str(path).encode(), instances), str(path))
+
+
+RC_BUFFERS = ("tlas", "blas", "bvh", "tri", "triEx", "triIdx", "tex")
+
+
+def rc_procedural(name, a=0, b=0, seed=1, copies=1, reflectivity=None):
+    """Procedural scene in the formats of the software twin (tests/regression/raycast/common.h): dict of uint8 arrays
+    tlas / blas / bvh / tri / triEx / triIdx / tex plus 'tlas_root', 'bounds', 'max_depth'."""
+    L = _load()
+    L.vxs_rc_scene_create_procedural.restype = C.c_void_p
+    L.vxs_rc_scene_create_procedural.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.vxs_rc_scene_destroy.argtypes = [C.c_void_p]
+    L.vxs_rc_scene_buffer.restype = C.c_uint64
+    L.vxs_rc_scene_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.vxs_rc_scene_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    refl = None
+    if reflectivity is not None:
+        refl = np.ascontiguousarray(list(reflectivity) + [0.0] * max(0, copies - len(reflectivity)), np.float32)
+    h = L.vxs_rc_scene_create_procedural(name.encode(), a, b, seed, copies, refl.ctypes.data if refl is not None else None)
+    if not h:
+        raise RuntimeError("raycast-format scene construction failed: %s" % name)
+    try:
+        out = {}
+        for i, k in enumerate(RC_BUFFERS):
+            p = C.c_void_p()
+            n = L.vxs_rc_scene_buffer(h, i, C.byref(p))
+            out[k] = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy() if n else np.zeros(0, np.uint8)
+        info = (C.c_uint32 * 2)()
+        bounds = (C.c_float * 6)()
+        L.vxs_rc_scene_info(h, info, bounds)
+        out["tlas_root"] = int(info[0])
+        out["max_depth"] = int(info[1])
+        out["bounds"] = np.array(list(bounds), np.float32)
+        return out
+    finally:
+        L.vxs_rc_scene_destroy(h)
+
+
+def rc_camera_like_rtu(width, height):
+    """cam14 (pos, forward, right, up, viewplane) that frames what the RTU kernel's fixed camera sees
+    (raytracing/kernel.cpp:28-39: eye (0,100,0), looking along +x, u in [-W/H, W/H], v in [-1, 1])."""
+    return np.array([0, 100, 0, 1, 0, 0, 0, 0, 1, 0, 1, 0, 2.0 * width / height, 2.0], np.float32)
