@@ -371,6 +371,9 @@ __device__ __forceinline__ void generate_ray(float u, float v,
   dx = vx * inv; dy = vy * inv; dz = vz * inv;
 }
 
+#ifndef RT_TRI_PREFETCH
+#define RT_TRI_PREFETCH 1
+#endif
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 6
 #endif
@@ -730,10 +733,21 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
           }
           const float cdx = __uint_as_float(CTX(0)), cdy = __uint_as_float(CTX(1)), cdz = __uint_as_float(CTX(2));
           bool stop = false;
+          // ray buffers (incoherent rays, latency-bound leaves): the next triangle's 48 bytes are requested before the
+          // current one is tested, +3 %; camera tiles lose 1.5 % to the extra registers, so they load in place
+          constexpr bool PREFETCH = JOB == JOB_TRACE && RT_TRI_PREFETCH;
+          float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+          if (PREFETCH) { const float4* tp0 = sc.tri_w + (size_t)leftFirst * 3; n0 = tp0[0]; n1 = tp0[1]; n2 = tp0[2]; }
           for (uint32_t i = 0; i < triCount; ++i) {
             const uint32_t triIdx = leftFirst + i;
-            const float4* tp = sc.tri_w + (size_t)triIdx * 3;
-            const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            float4 t0, t1, t2;
+            if (PREFETCH) {
+              t0 = n0; t1 = n1; t2 = n2;
+              if (i + 1u < triCount) { const float4* tn = sc.tri_w + (size_t)(triIdx + 1u) * 3; n0 = tn[0]; n1 = tn[1]; n2 = tn[2]; }
+            } else {
+              const float4* tp = sc.tri_w + (size_t)triIdx * 3;
+              t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
+            }
             if (STATS) fx.tri++;
             float bx, by, bz;
             const float d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
