@@ -398,7 +398,7 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #define RT_LEAF_MIN 1          // render jobs: lanes of a tile reach their leaves together anyway
 #endif
 #ifndef RT_TRACE_LEAF_MIN
-#define RT_TRACE_LEAF_MIN 16   // incoherent rays: +3.5 %
+#define RT_TRACE_LEAF_MIN 24   // incoherent rays: +3.5 % at 16, another 1 % at 24
 #endif
 #ifndef RT_UNORDERED_OCCLUSION
 #define RT_UNORDERED_OCCLUSION 1
