@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd "$ROOT"
 python -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.txt" 2>&1 || { tail -5 "$OUT/pytest_gpu.txt"; exit 1; }
 tail -1 "$OUT/pytest_gpu.txt"
-python bench.py  > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
 cat "$OUT/bench.json"
 python bench.py --frames-in-flight 1 --no-cpu-baseline > "$OUT/bench_serial.json" 2>> "$OUT/bench.err" || exit 1
 cat "$OUT/bench_serial.json"
