@@ -395,3 +395,24 @@ def test_trace_fetch_counters_equal_oracle_counts(vrt, po, gpu_device):
     assert c["node_fetches"] == st["node_reads"] and c["inst_fetches"] == st["inst_reads"] and c["tri_fetches"] == st["tri_reads"]
     assert c["bytes"] == 48 * n + 52 * (st["node_reads"] + st["inst_reads"]) + 36 * st["tri_reads"]
     assert np.array_equal(_bits(_hits_np(out)[:n]), _bits(hits))
+
+
+def test_learned_tile_order_does_not_change_results(vrt, po, gpu_device):
+    """From the second frame of a window on, a context with one frame in flight starts its most expensive tiles
+    first (cost learned from the frame before; frames of >= 20000 tiles only).  The order of tiles cannot change a
+    pixel: frames 1..4 of a 1920x1080 window are identical, and a band of rows equals the oracle."""
+    sc = vrt.scene.procedural("atrium", 5, 0, 3)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    w, h = 1916, 1076        # partial tiles on both edges, 32400 tiles
+    p = vrt.rtapi.default_shade_params()
+    p.light_pos[:] = (300.0, 480.0, 60.0)
+    frames = [gpu_render(vrt, ds, w, h, shadow=1, params=p) for _ in range(4)]
+    for px, hits, col, n in frames[1:]:
+        np.testing.assert_array_equal(px, frames[0][0])
+        assert np.array_equal(_bits(hits), _bits(frames[0][1])) and n == frames[0][3]
+    y0, y1 = 500, 508
+    rpx, rhits, _ = po.render(sc, w, h, po.shade_params(light_pos=tuple(p.light_pos)), y0=y0, y1=y1)
+    assert np.array_equal(_bits(frames[3][1][y0:y1]), _bits(rhits.reshape(h, w)[y0:y1]))
+    band = [gpu_render(vrt, ds, w, h, y0=40, y1=1000, shadow=1, params=p)[0] for _ in range(3)]   # another window: order relearned
+    for b in band:
+        np.testing.assert_array_equal(b[40:1000], frames[0][0][40:1000])

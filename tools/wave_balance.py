@@ -12,7 +12,7 @@ L = vrt.rtapi._lib()
 L.vxrt_render_wave_log.restype = C.c_int
 L.vxrt_render_wave_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vrt.rtapi.ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 for shadow in (1,):
-    for it in range(2):
+    for it in range(3):   # the third frame runs with the tile order learned from the second
         cnt = torch.zeros(8, dtype=torch.int64, device="cuda:0")
         log = torch.zeros((4 * 8 * 256, 13), dtype=torch.int64, device="cuda:0")
         assert L.vxrt_render_wave_log(ds.accel, W, H, 0, H, C.byref(p), shadow, px.data_ptr(), cnt.data_ptr(), log.data_ptr(), None) == 0
