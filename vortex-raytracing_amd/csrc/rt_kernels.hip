@@ -384,10 +384,11 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 // A fixed grid of wavefronts pulls jobs (pixels of 8x8 tiles, or rays of a ray buffer) from a
 // sharded queue, so the launch ends within one job batch of the last job instead of within the
 // slowest tile of a static tile->wavefront map (per-tile clocks showed half-empty CUs for the
-// second half of a frame).  Lanes that finish a ray take the next job once RT_REFILL_MIN lanes are
-// idle: 64 (whole tiles) for rendering, because coherent camera rays lose more from sharing a
-// wavefront with another tile than they gain from refilled lanes; fewer for incoherent ray buffers.
-// Primary and occlusion rays of different pixels share a wavefront (any-hit is a per-lane flag).
+// second half of a frame).  Idle lanes take new jobs once RT_DEAD_MAX (rendering) / RT_TRACE_DEAD_MAX
+// (ray buffers) lanes of the wavefront are not traversing: 64 = whole tiles for rendering, because
+// coherent camera rays lose more from sharing a wavefront with another tile than they gain from refilled
+// lanes; 16 for incoherent ray buffers.  A tile's lanes trace the primary ray, then (shadow jobs) the
+// occlusion ray of the same pixel; any-hit is a per-lane flag.
 // Rendering is deferred: this kernel leaves 24-byte hit records, rt_shade_kernel makes pixels.
 // Per-ray semantics -- and therefore results -- do not depend on the schedule.
 // ---------------------------------------------------------------------------------------------
@@ -416,11 +417,11 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #define QUEUE_SHARDS 8u     // one device-scope counter saturates near 90 dequeues/us
 #endif
 #define QUEUE_STRIDE 32u    // one 128-byte line per shard counter
-#ifndef LDS_STACK
 // per-frame control block: [0] deferral count (own 128-byte line), then the queue counters of the main
 // launch, of the EXACT launch over the deferred list and of the a-priori EXACT launch
 #define CTL_QUEUE_DWORDS (QUEUE_SHARDS * QUEUE_STRIDE)
 #define CTL_DWORDS (32u + 3u * CTL_QUEUE_DWORDS)
+#ifndef LDS_STACK
 #define LDS_STACK 8         // stack levels kept in LDS per lane (4 KiB per wavefront); deeper ones go to scratch
 #endif
 
@@ -444,7 +445,7 @@ struct PersistArgs {
   // render jobs, optional: longest-processing-time-first order learned from the previous frame of this context
   // (tile_order[queue position] = tile, sorted by cost within each shard's band) and where this frame's cost goes
   const uint32_t* tile_order; uint32_t* tile_cost;
-  unsigned long long* wave_log;   // STATS only, optional: per wavefront {first clock, last clock, rays started, iterations, node-body runs, lanes in them, leaf-body runs, lanes in them, node-body runs where no lane's node has a 3rd/4th child, ... a 4th child}
+  unsigned long long* wave_log;   // STATS only, optional: 13 u64 per wavefront (see vxrt_render_wave_log in the header)
 };
 
 __device__ __forceinline__ bool is_node_desc(uint32_t d) { return d < 0x80000000u; }
@@ -1207,7 +1208,7 @@ __global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_
   const float po[3] = {px, py, pz};
   const int ev[3] = {(int)(int8_t)(w[3] & 0xff), (int)(int8_t)((w[3] >> 8) & 0xff), (int)(int8_t)((w[3] >> 16) & 0xff)};
   const uint8_t* bytes = (const uint8_t*)w;
-  uint32_t kinds = 0, pay[4] = {DESC_NONE, DESC_NONE, DESC_NONE, DESC_NONE};   // complete descriptors of the children
+  uint32_t pay[4] = {DESC_NONE, DESC_NONE, DESC_NONE, DESC_NONE};   // complete descriptors of the children
   uint8_t qb[24];
   for (int k = 0; k < 4; ++k) {
     const uint8_t* c = bytes + 24 + 7 * k;
@@ -1233,21 +1234,19 @@ __global__ void accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_
     if (is_tlas) {
       if (c_ld != 0xffffffffu) {
         if (c_ld >= n_blas || c_ld >= 0x3FFFFFF0u) { atomicOr(status, STATUS_BAD_SCENE); continue; }
-        kinds |= 3u << (2 * k); pay[k] = DESC(DK_INST, c_ld);
-      } else { kinds |= 1u << (2 * k); pay[k] = DESC(DK_TLAS, ci + bias); }
+        pay[k] = DESC(DK_INST, c_ld);
+      } else pay[k] = DESC(DK_TLAS, ci + bias);
     } else {
       if (c_ld != 0u) {
         if ((uint64_t)c_lf + c_ld > n_tris) { atomicOr(status, STATUS_BAD_SCENE); continue; }
-        kinds |= 2u << (2 * k);
         pay[k] = DESC(DK_LEAF, (c_ld <= LEAF_MAX_INLINE && c_lf <= LEAF_FIRST_MASK) ? ((c_ld << LEAF_FIRST_BITS) | c_lf) : ci);   // else by reference
         if (!(c_ld <= LEAF_MAX_INLINE && c_lf <= LEAF_FIRST_MASK) && ci > LEAF_FIRST_MASK) { atomicOr(status, STATUS_BAD_SCENE); pay[k] = DESC_NONE; }
-      } else { kinds |= 1u << (2 * k); pay[k] = DESC(DK_BLAS, ci + bias); }
+      } else pay[k] = DESC(DK_BLAS, ci + bias);
     }
   }
   uint32_t qw[6];
   for (int v = 0; v < 6; ++v) qw[v] = (uint32_t)qb[4 * v] | ((uint32_t)qb[4 * v + 1] << 8) | ((uint32_t)qb[4 * v + 2] << 16) | ((uint32_t)qb[4 * v + 3] << 24);
   uint4* o = out + (size_t)i * CNODE_VEC4;
-  (void)kinds;
   o[0] = make_uint4(w[0], w[1], w[2], __float_as_uint(ldexpf(1.0f, ev[0])));
   o[1] = make_uint4(qw[0], qw[1], qw[2], qw[3]);
   o[2] = make_uint4(qw[4], qw[5], pay[0], pay[1]);
