@@ -259,11 +259,11 @@ typedef struct vxrc_params {     /* the fields of raycast/common.h:126-150 kerne
 int vxrc_render(const vxrc_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                 const vxrc_params_t* params, uint32_t* dst, float* colors, void* stream);
 
-/* Diagnostic variant of vxrt_render_stats: additionally logs per wavefront of the main traversal
- * launch {first clock, last clock (100 MHz constant clock), rays started, loop iterations, runs of the
- * node body, lanes active in them, runs of the leaf body, lanes active in them, node-body runs in which
- * no lane's node has a 3rd or 4th child, ... a 4th child, shader clocks in the node body, in the instance + leaf part,
- * in the whole kernel} into wave_log, a device u64[13 * 4 * 8 * 256] array, to study load balance and lane occupancy of the launch. */
+/* Diagnostic variant of vxrt_render_stats: additionally logs 13 u64 per wavefront of the main traversal launch into
+ * wave_log (device u64[13 * 4 * 8 * 256]): [0] first and [1] last 100 MHz clock, [2] rays started, [3] loop iterations,
+ * [4] runs of the node body and [5] lanes active in them, [6] runs of the leaf body and [7] lanes active in them,
+ * [8..9] reserved, [10] shader clocks inside the node body, [11] inside the instance + leaf part, [12] of the whole
+ * wavefront -- to study load balance and lane occupancy of the launch (tools/wave_balance.py). */
 int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                          unsigned long long* counters, unsigned long long* wave_log, void* stream);

@@ -31,6 +31,5 @@ for shadow in (1,):
           % (it / len(lg), nx / it, nl / max(nx, 1), lx / it, ll / max(lx, 1)))
     print("rays %d -> node steps/ray %.2f, leaf visits/ray %.2f; wave-level node runs/ray %.3f leaf runs/ray %.3f"
           % (rays.sum(), nl / rays.sum(), ll / rays.sum(), nx * 64 / rays.sum(), lx * 64 / rays.sum()))
-    print("node-body runs with no 3rd/4th child in any lane: %.3f; no 4th child: %.3f" % (lg[:, 8].sum() / nx, lg[:, 9].sum() / nx))
     tn, tl, tt = lg[:, 10].sum(), lg[:, 11].sum(), lg[:, 12].sum()
     print("shader clocks: node body %.3f, instance+leaf part %.3f, rest (fetch, finish, loop control) %.3f of the wave lifetime" % (tn / tt, tl / tt, 1 - (tn + tl) / tt))
