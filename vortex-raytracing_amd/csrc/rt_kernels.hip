@@ -1762,7 +1762,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   // and only for frames of more than LPT_MIN_TILES tiles: below, the sort launch costs more than the shorter tail saves
   // (1024x1024, 86 % background: -5 %; 1920x1080: +9 %; 3840x2160: +4 %; the sort on a side stream instead: worse, the
   // two extra event hops cost more than the kernel)
-  const bool lpt = lpt_on && (!stats || wave_log) && a->n_ctx == 1 && n_tiles >= LPT_MIN_TILES;
+  const bool lpt = lpt_on && (!stats || wave_log) && a->n_ctx == 1 && n_tiles >= LPT_MIN_TILES;   // (with frames in flight: no difference, measured)
   if (lpt) {
     if (c->lpt_cap < n_tiles) {
       if (hipStreamSynchronize(s) != hipSuccess) return -1;
