@@ -238,6 +238,14 @@ int vxrt_render_ao(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_
                    const vxrt_shade_params_t* params, const vxrt_ao_params_t* ao, uint32_t* dst, float* colors,
                    uint32_t* unoccluded, unsigned long long* rays_traced, void* stream);
 
+/* One diffuse bounce (extension for BASELINE config 3, "1 bounce diffuse"; absent from the reference): per pixel with
+ * a primary hit one cosine-weighted ray about the shading normal -- the vxrt_render_ao recipe with spp = 1, sample 0,
+ * no tmax -- traced for its closest hit; pixel = Lambert colour of the primary hit + albedo * (Lambert colour of the
+ * bounce hit | background).  Defined by oracle/rt_oracle.c:orc_render_gi, reproducible bit for bit. */
+int vxrt_render_diffuse_bounce(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                               const vxrt_shade_params_t* params, uint32_t seed, uint32_t* dst, float* colors,
+                               unsigned long long* rays_traced, void* stream);
+
 /* ---- software twin: the reference's raycast test (tests/regression/raycast) ----
  * Buffers in the reference's formats (raycast/common.h): tlas_node_t 32 B, blas_node_t 160 B (transform,
  * invTransform, bvh_offset@128, tex_offset@136, tex_width@144, tex_height@148, reflectivity@152),

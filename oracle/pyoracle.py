@@ -374,6 +374,22 @@ def render_ao(scene, w, h, params=None, spp=4, radius=10.0, seed=0, y0=0, y1=Non
     return px, col.reshape(h, w, 3), cnt, int(n.value)
 
 
+def render_gi(scene, w, h, params=None, seed=0, y0=0, y1=None):
+    """orc_render_gi: primary hit + one cosine-weighted diffuse bounce.  Returns pixels, colours, rays traced."""
+    y1 = h if y1 is None else y1
+    params = params or shade_params()
+    px = np.zeros((h, w), np.uint32)
+    col = np.zeros((h * w, 3), np.float32)
+    n = C.c_uint64(0)
+    b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")}
+    L = orc()
+    L.orc_render_gi.restype = C.c_int
+    L.orc_render_gi.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 7 + [C.POINTER(ShadeParams), C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.orc_render_gi(w, h, y0, y1, _p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(b["triEx"]), _p(b["mat"]),
+                    _p(b["tex"]), C.byref(params), seed, _p(px), _p(col), C.byref(n))
+    return px, col.reshape(h, w, 3), int(n.value)
+
+
 def shade(scene, rays, hits, params=None):
     params = params or shade_params()
     rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

@@ -478,7 +478,7 @@ static f3 diffuse_lighting(f3 pixel, f3 normal, f3 diffuse_color, f3 ambient, f3
 static void shade_terms(const float ray6[6], const orc_hit_t* hit,
                         const orc_blas_t* blas_ptr, const orc_triex_t* triEx_ptr, const orc_material_t* mat_ptr,
                         const uint8_t* tex_ptr, const orc_shade_params_t* p, int occluded,
-                        f3* out_term, float* out_refl, f3* out_I, f3* out_N) {
+                        f3* out_term, float* out_refl, f3* out_I, f3* out_N, f3* out_albedo) {
   float throughput = 1.0f;
   f3 orig = f3_make(ray6[0], ray6[1], ray6[2]);
   f3 dir = f3_make(ray6[3], ray6[4], ray6[5]);
@@ -523,6 +523,7 @@ static void shade_terms(const float ray6[6], const orc_hit_t* hit,
   *out_term = f3_add(f3_make(0, 0, 0), f3_scale(f3_scale(diffuse, throughput), 1 - reflectivity)); /* :87 */
   *out_refl = reflectivity;
   *out_I = I; *out_N = N;
+  if (out_albedo) *out_albedo = texColor;
 }
 
 void orc_shade(const float ray6[6], const orc_hit_t* hit,
@@ -535,7 +536,7 @@ void orc_shade(const float ray6[6], const orc_hit_t* hit,
   }
   f3 radiance, I, N;
   float throughput = 1.0f, reflectivity;
-  shade_terms(ray6, hit, blas_ptr, triEx_ptr, mat_ptr, tex_ptr, p, 0, &radiance, &reflectivity, &I, &N);
+  shade_terms(ray6, hit, blas_ptr, triEx_ptr, mat_ptr, tex_ptr, p, 0, &radiance, &reflectivity, &I, &N, NULL);
   throughput *= reflectivity;                                                          /* :90 */
   /* :95-121: secondary ray only if reflectivity > 0 && bounce+1 < max_depth (orc_render_ex follows it);
    * this entry point is the else arm, which is all the shipped scene builder reaches (scene.cpp:96) */
@@ -576,7 +577,7 @@ static f3 radiance_of(const orc_node_t* tlas, const orc_blas_t* blas, const orc_
   int occ = shadow ? occluded_toward_light(tlas, blas, bvh, tri, ray6, hit.dist, p, n_rays) : 0;
   f3 radiance, I, N;
   float throughput = 1.0f, reflectivity;
-  shade_terms(ray6, &hit, blas, triEx, mat, tex, p, occ, &radiance, &reflectivity, &I, &N);
+  shade_terms(ray6, &hit, blas, triEx, mat, tex, p, occ, &radiance, &reflectivity, &I, &N, NULL);
   throughput *= reflectivity;                                                          /* :90 */
   if (reflectivity > 0.0f && bounce + 1 < p->max_depth) {                              /* :95 */
     f3 dir = f3_make(ray6[3], ray6[4], ray6[5]);
@@ -721,7 +722,7 @@ int orc_render_ao(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
       } else {
         f3 term, I, N;
         float refl;
-        shade_terms(ray, &hit, blas, triEx, mat, tex, p, 0, &term, &refl, &I, &N);
+        shade_terms(ray, &hit, blas, triEx, mat, tex, p, 0, &term, &refl, &I, &N, NULL);
         orc_shade(ray, &hit, blas, triEx, mat, tex, p, col);
         float If[3] = {I.x, I.y, I.z}, Nf[3] = {N.x, N.y, N.z};
         for (uint32_t s = 0; s < spp; ++s) {
@@ -738,6 +739,47 @@ int orc_render_ao(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
       out_pixels[idx] = orc_pack_rgb8(col);
       if (out_color) { out_color[3 * idx] = col[0]; out_color[3 * idx + 1] = col[1]; out_color[3 * idx + 2] = col[2]; }
       if (out_unoccluded) out_unoccluded[idx] = open;
+    }
+  }
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * One diffuse bounce (extension; BASELINE config 3 says "1 bounce diffuse", the reference has no such pass).
+ * Per pixel with a primary hit: one cosine-weighted ray about the viewer-facing shading normal -- the AO
+ * recipe above with spp = 1, sample 0 and no tmax -- traced for its closest hit;
+ *   pixel = Lambert colour of the primary hit + albedo(primary) * (Lambert colour of the bounce hit | background)
+ * where "Lambert colour" is closest.cpp's else arm (orc_shade) and albedo its texColor (:72-77).
+ * ------------------------------------------------------------------------------------------- */
+int orc_render_gi(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
+                  const orc_node_t* tlas, const orc_blas_t* blas, const orc_node_t* bvh,
+                  const orc_tri_t* tri, const orc_triex_t* triEx, const orc_material_t* mat,
+                  const uint8_t* tex, const orc_shade_params_t* p, uint32_t user_seed,
+                  uint32_t* out_pixels, float* out_color, uint64_t* n_rays) {
+  if (n_rays) *n_rays = 0;
+  for (uint32_t y = y0; y < y1; ++y) {
+    for (uint32_t x = 0; x < w; ++x) {
+      float ray[6], col[3];
+      orc_generate_ray(x, y, w, h, ray);
+      orc_hit_t hit;
+      orc_trace_canonical(tlas, blas, bvh, tri, ray, 1, NULL, &hit, NULL, 0);
+      if (n_rays) ++*n_rays;
+      orc_shade(ray, &hit, blas, triEx, mat, tex, p, col);
+      if (hit.dist != ORC_LARGE_FLOAT) {
+        f3 term, I, N, albedo;
+        float refl;
+        shade_terms(ray, &hit, blas, triEx, mat, tex, p, 0, &term, &refl, &I, &N, &albedo);
+        float If[3] = {I.x, I.y, I.z}, Nf[3] = {N.x, N.y, N.z}, b[6], c1[3];
+        orc_ao_ray(x, y, w, 1, 0, user_seed, If, Nf, ray + 3, b);
+        orc_hit_t bh;
+        orc_trace_canonical(tlas, blas, bvh, tri, b, 1, NULL, &bh, NULL, 0);
+        if (n_rays) ++*n_rays;
+        orc_shade(b, &bh, blas, triEx, mat, tex, p, c1);
+        col[0] = col[0] + albedo.x * c1[0]; col[1] = col[1] + albedo.y * c1[1]; col[2] = col[2] + albedo.z * c1[2];
+      }
+      uint64_t idx = (uint64_t)x + (uint64_t)y * w;
+      out_pixels[idx] = orc_pack_rgb8(col);
+      if (out_color) { out_color[3 * idx] = col[0]; out_color[3 * idx + 1] = col[1]; out_color[3 * idx + 2] = col[2]; }
     }
   }
   return 0;

@@ -145,6 +145,13 @@ int orc_render_ao(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
                   uint32_t* out_pixels, float* out_color /* may be NULL */, uint32_t* out_unoccluded /* may be NULL */,
                   uint64_t* n_rays /* may be NULL */);
 
+/* One cosine-weighted diffuse bounce per primary hit (extension; definition in rt_oracle.c). */
+int orc_render_gi(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
+                  const orc_node_t* tlas, const orc_blas_t* blas, const orc_node_t* bvh,
+                  const orc_tri_t* tri, const orc_triex_t* triEx, const orc_material_t* mat,
+                  const uint8_t* tex, const orc_shade_params_t* p, uint32_t user_seed,
+                  uint32_t* out_pixels, float* out_color /* may be NULL */, uint64_t* n_rays /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

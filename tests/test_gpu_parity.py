@@ -416,3 +416,28 @@ def test_learned_tile_order_does_not_change_results(vrt, po, gpu_device):
     band = [gpu_render(vrt, ds, w, h, y0=40, y1=1000, shadow=1, params=p)[0] for _ in range(3)]   # another window: order relearned
     for b in band:
         np.testing.assert_array_equal(b[40:1000], frames[0][0][40:1000])
+
+
+def test_diffuse_bounce_pass_matches_oracle(vrt, po, gpu_device):
+    """vxrt_render_diffuse_bounce (extension for BASELINE config 3's "1 bounce diffuse"): same trig-free sampling
+    recipe as the AO pass, one closest-hit bounce ray per primary hit; pixels, colours and ray totals equal the checker's."""
+    import torch
+    from scenes import mirror_hall
+    b = mirror_hall(vrt, 0.0, 0.0)
+    ds = vrt.tracer.DeviceScene(b, gpu_device)
+    w, h = 152, 96
+    p = vrt.rtapi.default_shade_params()
+    p.light_pos[:] = (150.0, 220.0, -60.0)
+    px = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
+    col = torch.zeros(h * w * 3, dtype=torch.float32, device=gpu_device)
+    nr = torch.zeros(1, dtype=torch.int64, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.render_diffuse_bounce(ds.accel, w, h, 0, h, p, px.data_ptr(), seed=11, colors_ptr=col.data_ptr(), rays_ptr=nr.data_ptr(), stream=s)
+    assert vrt.rtapi.status(s) == 0
+    pp = po.shade_params(light_pos=tuple(p.light_pos))
+    rpx, rcol, rn = po.render_gi(b, w, h, pp, seed=11)
+    assert int(nr.item()) == rn > w * h
+    np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3), rcol, rtol=COLOR_RTOL)
+    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), rpx)
+    _, _, direct = po.render(b, w, h, pp)
+    assert (rcol >= direct - 1e-7).all() and (rcol > direct + 1e-3).any()      # the bounce only adds light

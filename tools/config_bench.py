@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The other BASELINE.json configurations, measured once each on one MI355X (they are parity-test cases, not the
-bench line): prints one JSON object per configuration.  usage: python tools/config_bench.py [2] [4] [5] [--hair-strands N]"""
+bench line): prints one JSON object per configuration.  usage: python tools/config_bench.py [2] [3] [4] [5] [6] [--hair-strands N]   (6 = the raycast software twin)"""
 import argparse, importlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -42,7 +42,7 @@ def render_cfg(tag, scene, W, H, light, steps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("configs", nargs="*", type=int, default=[2, 4, 5])
+    ap.add_argument("configs", nargs="*", type=int, default=[2, 3, 4, 5, 6])
     ap.add_argument("--hair-strands", type=int, default=20000)   # x 250 segments x 2 = 10 M triangles
     a = ap.parse_args()
     out = []
@@ -73,6 +73,23 @@ def main():
         out.append({"config": "configs[4]: hairball, 1920x1080, 16 spp AO (tmax = 0.25 scene radius)", "tris": sc.n_tris, "bvh_nodes": sc.n_bvh_nodes,
                     "bvh_depth": sc.info.get("max_depth"), "host_build_s": round(build_s, 1), "rays_per_frame": rays,
                     "ms_per_frame": round(ms, 3), "mrays_s": round(rays / ms / 1e3, 1)})
+    if 3 in a.configs:
+        # configs[2] as worded ("1 bounce diffuse"): primary + one cosine-weighted closest-hit bounce per hit
+        sc = vrt.scene.procedural("atrium", 8, 0, 3)
+        ds = vrt.tracer.DeviceScene(sc, dev)
+        W, H = 1920, 1080
+        p = rtapi.default_shade_params()
+        p.light_pos[:] = (300.0, 480.0, 60.0)
+        px = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        rtapi.render_diffuse_bounce(ds.accel, W, H, 0, H, p, px.data_ptr(), seed=3, rays_ptr=cnt.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        assert rtapi.status(s) == 0
+        rays = int(cnt.item())
+        ms = timed(lambda: rtapi.render_diffuse_bounce(ds.accel, W, H, 0, H, p, px.data_ptr(), seed=3, stream=s), 20)
+        out.append({"config": "configs[2] as worded: Sponza-class, 1920x1080, primary + 1 diffuse bounce (incoherent closest-hit rays)", "tris": sc.n_tris,
+                    "rays_per_frame": rays, "ms_per_frame_serial": round(ms, 4), "mrays_s": round(rays / ms / 1e3, 1)})
     if 6 in a.configs:
         # software twin (tests/regression/raycast) on the same geometry in its own formats: BVH2, per-instance texture
         t0 = time.time()

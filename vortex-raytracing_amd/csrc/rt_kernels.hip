@@ -263,7 +263,7 @@ __device__ void shade_terms(const SceneDev& sc, const ShadeParams& p, float ox, 
                             float dx, float dy, float dz, const HitRec& hit, bool occluded,
                             float& r, float& g, float& b, float& refl_out,
                             float& Ix_o, float& Iy_o, float& Iz_o, float& Nx_o, float& Ny_o, float& Nz_o,
-                            unsigned* textured = nullptr) {
+                            unsigned* textured = nullptr, float* albedo3 = nullptr) {
   const uint32_t* bp = sc.blas + (size_t)hit.blasIdx * (RT_BLAS_STRIDE / 4);
   const rt_triex_t te = sc.triEx[hit.triIdx];
   const rt_material_t* mat = sc.mat + te.texId;
@@ -318,6 +318,7 @@ __device__ void shade_terms(const SceneDev& sc, const ShadeParams& p, float ox, 
   b = 0.0f + thr * db * (1 - refl);
   refl_out = refl;
   Ix_o = Ix; Iy_o = Iy; Iz_o = Iz; Nx_o = Nx; Ny_o = Ny; Nz_o = Nz;
+  if (albedo3) { albedo3[0] = cr; albedo3[1] = cg; albedo3[2] = cb; }   // texColor (:72-77)
 }
 
 // closest.cpp:57-127 without a secondary ray (reflectivity <= 0 or bounce + 1 >= max_depth) / miss.cpp:9-14
@@ -1037,7 +1038,7 @@ __device__ __forceinline__ float random_float(uint32_t& s) {   // common.h:137-1
 __global__ __launch_bounds__(256) void rt_ao_prepare_kernel(SceneDev sc, ShadeParams p, uint64_t n, uint32_t W, uint32_t y0,
     const float* __restrict__ utab, const float* __restrict__ vtab, const HitRec* __restrict__ hb,
     float4* __restrict__ geo, float4* __restrict__ nrm, float4* __restrict__ col, uint32_t* __restrict__ cnt,
-    uint32_t* __restrict__ list, uint32_t* hdr, uint32_t* ctl_reset) {
+    uint32_t* __restrict__ list, uint32_t* hdr, uint32_t* ctl_reset, float4* __restrict__ alb /* optional: albedo of the hit */) {
   if (ctl_reset && blockIdx.x == 0)
     for (uint32_t i = threadIdx.x; i < CTL_DWORDS; i += 256u) ctl_reset[i] = 0u;
   const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -1055,13 +1056,14 @@ __global__ __launch_bounds__(256) void rt_ao_prepare_kernel(SceneDev sc, ShadePa
       geo[t] = make_float4(0.f, 0.f, 0.f, 0.f);
       nrm[t] = make_float4(0.f, 0.f, 1.f, 0.f);
     } else {
-      float refl, Ix, Iy, Iz, Nx, Ny, Nz;
-      shade_terms<false>(sc, p, ox, oy, oz, dx, dy, dz, h, false, r, g, b, refl, Ix, Iy, Iz, Nx, Ny, Nz);
+      float refl, Ix, Iy, Iz, Nx, Ny, Nz, a3[3];
+      shade_terms<false>(sc, p, ox, oy, oz, dx, dy, dz, h, false, r, g, b, refl, Ix, Iy, Iz, Nx, Ny, Nz, nullptr, a3);
       float thr = 1.0f;
       thr *= refl;
       r = r + p.bg[0] * thr; g = g + p.bg[1] * thr; b = b + p.bg[2] * thr;
       geo[t] = make_float4(Ix, Iy, Iz, 1.0f);
       nrm[t] = make_float4(Nx, Ny, Nz, 0.f);
+      if (alb) alb[t] = make_float4(a3[0], a3[1], a3[2], 0.f);
       hit = true;
     }
     col[t] = make_float4(r, g, b, 0.f);
@@ -1178,6 +1180,41 @@ __global__ __launch_bounds__(1024) void lpt_order_kernel(const uint32_t* __restr
   }
   __syncthreads();
   for (uint32_t t = lo + threadIdx.x; t < hi; t += 1024u) order[lo + atomicAdd(&hist[2047u - cls(cost[t])], 1u)] = t;
+}
+
+// One diffuse bounce (extension for BASELINE config 3; recipe in oracle/rt_oracle.c:orc_render_gi): the bounce rays are
+// the AO rays of sample 0 with spp = 1 and no tmax, traced for their closest hit.  Listed pixel i: colour += albedo *
+// (Lambert colour of the bounce hit | background).
+__global__ __launch_bounds__(256) void rt_gi_accumulate_kernel(SceneDev sc, ShadeParams p, uint64_t cap, const uint32_t* __restrict__ list,
+    const uint32_t* __restrict__ hdr, const float* __restrict__ rays, const HitRec* __restrict__ bhits, const float4* __restrict__ alb,
+    float4* __restrict__ col) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= hdr[1] || i >= cap) return;
+  const uint32_t t = list[i];
+  const float* rp = rays + (size_t)i * 6;
+  const HitRec h = bhits[i];
+  float r, g, b;
+  shade_eval<false>(sc, p, rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], h, h.dist != RT_LARGE_FLOAT, false, r, g, b);
+  const float4 a = alb[t];
+  float4 c = col[t];
+  c.x = c.x + a.x * r; c.y = c.y + a.y * g; c.z = c.z + a.z * b;
+  col[t] = c;
+}
+
+__global__ __launch_bounds__(256) void rt_gi_final_kernel(uint64_t n, uint32_t W, uint32_t y0, const float4* __restrict__ geo, const float4* __restrict__ col,
+    uint32_t* __restrict__ dst, float* __restrict__ colors_out, unsigned long long* rays_traced) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  bool hit = false;
+  if (t < n) {
+    const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
+    const size_t e = (size_t)x + (size_t)y * W;
+    const float4 c = col[t];
+    hit = geo[t].w != 0.f;
+    dst[e] = pack_rgb8(c.x, c.y, c.z);
+    if (colors_out) { colors_out[3 * e] = c.x; colors_out[3 * e + 1] = c.y; colors_out[3 * e + 2] = c.z; }
+  }
+  const unsigned long long m = __ballot(hit);
+  if (rays_traced && (threadIdx.x & 63u) == 0u && m) atomicAdd(rays_traced, (unsigned long long)__popcll(m));
 }
 
 __global__ void add_counter_kernel(unsigned long long* c, unsigned long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(c, v); }
@@ -1371,7 +1408,7 @@ struct FrameCtx {
   // tile cost of the last frame and the order derived from it (render jobs, see lpt_order_kernel)
   uint32_t* tile_cost = nullptr; uint32_t* tile_order = nullptr; uint32_t lpt_cap = 0; uint32_t lpt_key[6] = {0, 0, 0, 0, 0, 0}; bool lpt_valid = false;
   // ambient-occlusion pass (allocated on first use), one entry per pixel of the window
-  float4* ao_geo = nullptr; float4* ao_nrm = nullptr; float4* ao_col = nullptr; uint32_t* ao_cnt = nullptr;
+  float4* ao_geo = nullptr; float4* ao_nrm = nullptr; float4* ao_col = nullptr; float4* ao_alb = nullptr; uint32_t* ao_cnt = nullptr;
   uint32_t* ao_list = nullptr; uint32_t* ao_hdr = nullptr;   // pixels with a hit; [0] their number, [1] rays of the current batch
   float* ao_rays = nullptr; float* ao_tmax = nullptr; HitRec* ao_hits = nullptr; uint64_t ao_cap = 0, ao_ray_cap = 0;
   hipStream_t side = nullptr;
@@ -1403,7 +1440,7 @@ static void accel_free(vxrt_accel* a) {
   (void)hipFree(a->uvtab); (void)hipFree(a->apriori);
   for (FrameCtx& c : a->ctx) {
     (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount); (void)hipFree(c.tile_cost); (void)hipFree(c.tile_order);
-    (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits); (void)hipFree(c.ao_list); (void)hipFree(c.ao_hdr);
+    (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_alb); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits); (void)hipFree(c.ao_list); (void)hipFree(c.ao_hdr);
     for (FrameCtx::Level& l : c.lv) {
       (void)hipFree(l.rays); (void)hipFree(l.hits); (void)hipFree(l.parent); (void)hipFree(l.term); (void)hipFree(l.col);
       (void)hipFree(l.srays); (void)hipFree(l.stmax); (void)hipFree(l.shits);
@@ -1662,12 +1699,14 @@ static int render_bounce_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p
 // the device, their occlusion rays are generated in batches of whole samples (<= AO_BATCH_RAYS rays) and each
 // batch is one any-hit launch whose job count stays in device memory.  No host synchronisation.
 #define AO_BATCH_RAYS (32ull << 20)
+#define VXRT_AO_MODE_DIFFUSE_BOUNCE 1u   // internal: vxrt_ao_params_t::reserved
 static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, uint32_t width, uint32_t y0, uint32_t y1,
                           const vxrt_ao_params_t* ao, const float* utab, const float* vtab, uint32_t* dst, float* colors,
                           uint32_t* unoccluded, unsigned long long* rays_traced, hipStream_t s) {
   const SceneDev& sc = a->dev;
   const uint64_t n = (uint64_t)width * (y1 - y0);
-  if (n > 0x7fffffffull || ao->spp == 0) return -1;
+  const bool gi = ao->reserved == VXRT_AO_MODE_DIFFUSE_BOUNCE;   // one closest-hit bounce ray instead of spp occlusion rays
+  if (n > 0x7fffffffull || ao->spp == 0 || (gi && ao->spp != 1)) return -1;
   uint32_t ns = (uint32_t)std::min<uint64_t>(ao->spp, std::max<uint64_t>(1, AO_BATCH_RAYS / n));   // samples per batch
   const uint64_t ray_cap = n * ns;
   if (ray_cap > 0x7fffffffull) return -1;
@@ -1675,6 +1714,7 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const uint64_t have = c->ao_cap, rhave = c->ao_ray_cap;
     bool ok = grow_buf((void**)&c->ao_geo, have, n, 16) && grow_buf((void**)&c->ao_nrm, have, n, 16) && grow_buf((void**)&c->ao_col, have, n, 16) &&
+              grow_buf((void**)&c->ao_alb, have, n, 16) &&
               grow_buf((void**)&c->ao_cnt, have, n, 4) && grow_buf((void**)&c->ao_list, have, n, 4) && grow_buf((void**)&c->ao_hdr, c->ao_hdr ? 1 : 0, 1, 8) &&
               grow_buf((void**)&c->ao_rays, rhave, ray_cap, 24) && grow_buf((void**)&c->ao_tmax, rhave, ray_cap, 4) &&
               grow_buf((void**)&c->ao_hits, rhave, ray_cap, sizeof(HitRec));
@@ -1684,9 +1724,18 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
   const dim3 block(256), grid((uint32_t)((n + 255) / 256)), rgrid((uint32_t)((ray_cap + 255) / 256));
   if (hipMemsetAsync(c->ao_hdr, 0, 8, s) != hipSuccess) return -1;
   hipLaunchKernelGGL(rt_ao_prepare_kernel, grid, block, 0, s, sc, p, n, width, y0, utab, vtab, (const HitRec*)c->hitbuf,
-                     c->ao_geo, c->ao_nrm, c->ao_col, c->ao_cnt, c->ao_list, c->ao_hdr, c->ctl);
+                     c->ao_geo, c->ao_nrm, c->ao_col, c->ao_cnt, c->ao_list, c->ao_hdr, c->ctl, gi ? c->ao_alb : (float4*)nullptr);
   if (hipGetLastError() != hipSuccess) return -1;
   c->ctl_dirty = false;
+  if (gi) {
+    hipLaunchKernelGGL(rt_ao_rays_kernel, rgrid, block, 0, s, ray_cap, width, y0, utab, vtab, (const float4*)c->ao_geo, (const float4*)c->ao_nrm,
+                       (const uint32_t*)c->ao_list, c->ao_hdr, 1u, 0u, 1u, ao->seed, RT_LARGE_FLOAT, c->ao_rays, c->ao_tmax);
+    if (trace_on_ctx(a, c, c->ao_rays, n, nullptr, c->ao_hits, VXRT_MODE_CLOSEST, s, c->ao_hdr + 1) != 0) return -1;
+    hipLaunchKernelGGL(rt_gi_accumulate_kernel, rgrid, block, 0, s, sc, p, ray_cap, (const uint32_t*)c->ao_list, (const uint32_t*)c->ao_hdr,
+                       (const float*)c->ao_rays, (const HitRec*)c->ao_hits, (const float4*)c->ao_alb, c->ao_col);
+    hipLaunchKernelGGL(rt_gi_final_kernel, grid, block, 0, s, n, width, y0, (const float4*)c->ao_geo, (const float4*)c->ao_col, dst, colors, rays_traced);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   for (uint32_t s0 = 0; s0 < ao->spp; s0 += ns) {
     const uint32_t k = std::min(ns, ao->spp - s0);
     hipLaunchKernelGGL(rt_ao_rays_kernel, rgrid, block, 0, s, ray_cap, width, y0, utab, vtab, (const float4*)c->ao_geo, (const float4*)c->ao_nrm,
@@ -1871,10 +1920,18 @@ int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, u
   return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream, wave_log);
 }
 
+int vxrt_render_diffuse_bounce(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                               const vxrt_shade_params_t* params, uint32_t seed, uint32_t* dst, float* colors,
+                               unsigned long long* rays_traced, void* stream) {
+  vxrt_ao_params_t gi{};
+  gi.spp = 1; gi.radius = RT_LARGE_FLOAT; gi.seed = seed; gi.reserved = VXRT_AO_MODE_DIFFUSE_BOUNCE;
+  return render_common(accel, width, height, y0, y1, params, 0, dst, nullptr, colors, rays_traced, false, stream, nullptr, &gi, nullptr);
+}
+
 int vxrt_render_ao(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                    const vxrt_shade_params_t* params, const vxrt_ao_params_t* ao, uint32_t* dst, float* colors,
                    uint32_t* unoccluded, unsigned long long* rays_traced, void* stream) {
-  if (!ao || ao->spp == 0 || ao->spp > 4096 || !(ao->radius > 0.0f)) return -1;
+  if (!ao || ao->spp == 0 || ao->spp > 4096 || !(ao->radius > 0.0f) || ao->reserved != 0) return -1;
   return render_common(accel, width, height, y0, y1, params, 0, dst, nullptr, colors, rays_traced, false, stream, nullptr, ao, unoccluded);
 }
 

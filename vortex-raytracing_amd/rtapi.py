@@ -151,6 +151,16 @@ def render_ao(accel, width, height, y0, y1, params, spp, radius, dst_ptr, seed=0
                                 unoccluded_ptr, rays_ptr, stream), "vxrt_render_ao")
 
 
+def render_diffuse_bounce(accel, width, height, y0, y1, params, dst_ptr, seed=0, colors_ptr=None, rays_ptr=None, stream=None):
+    """vxrt_render_diffuse_bounce: primary hit + one cosine-weighted closest-hit bounce."""
+    L = _lib()
+    L.vxrt_render_diffuse_bounce.restype = C.c_int
+    L.vxrt_render_diffuse_bounce.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ShadeParams), C.c_uint32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    check(L.vxrt_render_diffuse_bounce(accel, width, height, y0, y1, C.byref(params), int(seed), dst_ptr, colors_ptr, rays_ptr, stream),
+          "vxrt_render_diffuse_bounce")
+
+
 STAT_KEYS = ("rays", "node_fetches", "inst_fetches", "tri_fetches", "shaded_hits", "textured_hits", "pixels")
 
 
