@@ -372,6 +372,9 @@ __device__ __forceinline__ void generate_ray(float u, float v,
   dx = vx * inv; dy = vy * inv; dz = vz * inv;
 }
 
+#ifndef RT_LEAF_HELPERS
+#define RT_LEAF_HELPERS 1   // 1: render jobs (+1.5 %), 2: ray-buffer jobs too (no gain there: they prefetch instead)
+#endif
 #ifndef RT_TRI_PREFETCH
 #define RT_TRI_PREFETCH 1
 #endif
@@ -479,6 +482,9 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
   const uint32_t per_shard = (EXACT || A.total_dev) ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
 
   __shared__ uint2 s_stk[4][LDS_STACK][64];   // stack levels below the register top, 8 B entries, conflict-free rows
+  __shared__ uint8_t s_pair[4][2][64];        // leaf helpers (RT_LEAF_HELPERS): owner lane by rank, helper lane by rank
+  uint8_t* const pair_o = &s_pair[threadIdx.x >> 6][0][0];
+  uint8_t* const pair_h = &s_pair[threadIdx.x >> 6][1][0];
   __shared__ uint32_t s_ctx[4][9][64];        // 0-2 active dir, 3-5 hit bx/by/bz, 6 hit blasIdx, 7 hit triIdx, 8 blasIdx
   uint2* const lstk = &s_stk[threadIdx.x >> 6][0][lane];
   uint32_t* const ctx = &s_ctx[threadIdx.x >> 6][0][lane];
@@ -748,46 +754,111 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
       if (leafm != 0ull && ((uint32_t)__popcll(leafm) >= (JOB == JOB_TRACE ? RT_TRACE_LEAF_MIN : RT_LEAF_MIN) || __ballot(is_node_desc(cur) || is_inst_desc(cur)) == 0ull)) {
         // ---- BLAS leaf (:123-161): triangles in index order, strict '<' ----
         if (STATS && A.wave_log) { ++wl_leaf_x; wl_leaf_l += (unsigned)__popcll(leafm); }
-        if (is_leaf_desc(cur)) {
-          if (STATS) fx.node++;
-          uint32_t leftFirst = cur & LEAF_FIRST_MASK, triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
-          if (triCount == 0u) {   // leaf with more than 15 triangles: range kept in the reference node
-            const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS;
-            leftFirst = rn[4]; triCount = rn[5];
-          }
-          const float cdx = __uint_as_float(CTX(0)), cdy = __uint_as_float(CTX(1)), cdz = __uint_as_float(CTX(2));
-          bool stop = false;
-          // ray buffers (incoherent rays, latency-bound leaves): the next triangle's 48 bytes are requested before the
-          // current one is tested, +3 %; camera tiles lose 1.5 % to the extra registers, so they load in place
-          constexpr bool PREFETCH = JOB == JOB_TRACE && RT_TRI_PREFETCH;
-          float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
-          if (PREFETCH) { const float4* tp0 = sc.tri_w + (size_t)leftFirst * 3; n0 = tp0[0]; n1 = tp0[1]; n2 = tp0[2]; }
-          for (uint32_t i = 0; i < triCount; ++i) {
-            const uint32_t triIdx = leftFirst + i;
-            float4 t0, t1, t2;
-            if (PREFETCH) {
-              t0 = n0; t1 = n1; t2 = n2;
-              if (i + 1u < triCount) { const float4* tn = sc.tri_w + (size_t)(triIdx + 1u) * 3; n0 = tn[0]; n1 = tn[1]; n2 = tn[2]; }
-            } else {
-              const float4* tp = sc.tri_w + (size_t)triIdx * 3;
-              t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
+        constexpr bool HELP = RT_LEAF_HELPERS && !STATS && (JOB != JOB_TRACE || RT_LEAF_HELPERS > 1);   // (the counting build keeps the reference's triangle-test count)
+        if (!HELP) {
+          if (is_leaf_desc(cur)) {
+            if (STATS) fx.node++;
+            uint32_t leftFirst = cur & LEAF_FIRST_MASK, triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
+            if (triCount == 0u) {   // leaf with more than 15 triangles: range kept in the reference node
+              const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS;
+              leftFirst = rn[4]; triCount = rn[5];
             }
-            if (STATS) fx.tri++;
-            float bx, by, bz;
-            const float d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
-            if (d < hitd) {
-              hitd = d;
-              CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(5) = __float_as_uint(bz);
-              CTX(6) = CTX(8); CTX(7) = triIdx;
-              flags |= F_FOUND;
-              if (flags & F_ANYHIT) { stop = true; break; }
-              // the reference re-descends from the root with the shrunken hit.dist; if any box on the
-              // current path no longer passes `d < hit.dist` it abandons this subtree
-              if (!(path_m < hitd)) break;
+            const float cdx = __uint_as_float(CTX(0)), cdy = __uint_as_float(CTX(1)), cdz = __uint_as_float(CTX(2));
+            bool stop = false;
+            // ray buffers (incoherent rays, latency-bound leaves): the next triangle's 48 bytes are requested before the
+            // current one is tested, +3 %; camera tiles lose 1.5 % to the extra registers, so they load in place
+            constexpr bool PREFETCH = JOB == JOB_TRACE && RT_TRI_PREFETCH;
+            float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+            if (PREFETCH) { const float4* tp0 = sc.tri_w + (size_t)leftFirst * 3; n0 = tp0[0]; n1 = tp0[1]; n2 = tp0[2]; }
+            for (uint32_t i = 0; i < triCount; ++i) {
+              const uint32_t triIdx = leftFirst + i;
+              float4 t0, t1, t2;
+              if (PREFETCH) {
+                t0 = n0; t1 = n1; t2 = n2;
+                if (i + 1u < triCount) { const float4* tn = sc.tri_w + (size_t)(triIdx + 1u) * 3; n0 = tn[0]; n1 = tn[1]; n2 = tn[2]; }
+              } else {
+                const float4* tp = sc.tri_w + (size_t)triIdx * 3;
+                t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
+              }
+              if (STATS) fx.tri++;
+              float bx, by, bz;
+              const float d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
+              if (d < hitd) {
+                hitd = d;
+                CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(5) = __float_as_uint(bz);
+                CTX(6) = CTX(8); CTX(7) = triIdx;
+                flags |= F_FOUND;
+                if (flags & F_ANYHIT) { stop = true; break; }
+                // the reference re-descends from the root with the shrunken hit.dist; if any box on the
+                // current path no longer passes `d < hit.dist` it abandons this subtree
+                if (!(path_m < hitd)) break;
+              }
+            }
+            if (stop) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
+            else pop_next();
+          }
+        } else {
+          // Lanes without a leaf (they did their node step already, or hold no ray) test the SECOND triangle of a lane that
+          // has one, in the same pass in which the owners test their first: the leaf body runs at ~18 of 64 lanes and leaves
+          // hold two triangles on average, so one pass replaces two.  ray_tri does not depend on hit.dist, and the owner
+          // applies the two results in index order with the reference's accept / abandon rules, so nothing changes.
+          // Owner -> helper: origin and first triangle by ds_bpermute, direction from the owner's LDS slots.
+          const bool owner = is_leaf_desc(cur);
+          uint32_t leftFirst = 0u, triCount = 0u;
+          if (owner) {
+            leftFirst = cur & LEAF_FIRST_MASK; triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
+            if (triCount == 0u) {   // leaf with more than 15 triangles: range kept in the reference node
+              const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS;
+              leftFirst = rn[4]; triCount = rn[5];
             }
           }
-          if (stop) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
-          else pop_next();
+          const bool want = owner && triCount >= 2u;
+          const unsigned long long wantm = __ballot(want), freem = ~leafm;
+          const unsigned long long lt = (1ull << lane) - 1ull;
+          const uint32_t nw = (uint32_t)__popcll(wantm), nf = (uint32_t)__popcll(freem);
+          const uint32_t wr = (uint32_t)__popcll(wantm & lt), fr = (uint32_t)__popcll(freem & lt);
+          const bool served = want && wr < nf;
+          const bool helper = !owner && fr < nw;
+          if (served) pair_o[wr] = (uint8_t)lane;
+          if (helper) pair_h[fr] = (uint8_t)lane;
+          const int own = helper ? (int)pair_o[fr] : (int)lane;
+          const float tox = __shfl(arx, own), toy = __shfl(ary, own), toz = __shfl(arz, own);   // (all lanes take part)
+          const uint32_t tfirst = __shfl(leftFirst, own);
+          float p_d = RT_LARGE_FLOAT, p_bx = 0.f, p_by = 0.f, p_bz = 0.f;   // this lane's triangle of the common pass
+          if (owner || helper) {
+            const uint32_t* octx = &s_ctx[threadIdx.x >> 6][0][own];
+            const float cdx = __uint_as_float(octx[0]), cdy = __uint_as_float(octx[64]), cdz = __uint_as_float(octx[128]);
+            const float4* tp = sc.tri_w + (size_t)(tfirst + (helper ? 1u : 0u)) * 3;
+            const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            p_d = ray_tri(tox, toy, toz, cdx, cdy, cdz, t0, t1, t2, p_bx, p_by, p_bz);
+          }
+          const int hl = served ? (int)pair_h[wr] : (int)lane;
+          const float h_d = __shfl(p_d, hl), h_bx = __shfl(p_bx, hl), h_by = __shfl(p_by, hl), h_bz = __shfl(p_bz, hl);
+          if (owner) {
+            const float cdx = __uint_as_float(CTX(0)), cdy = __uint_as_float(CTX(1)), cdz = __uint_as_float(CTX(2));
+            bool stop = false;
+            for (uint32_t i = 0; i < triCount; ++i) {
+              const uint32_t triIdx = leftFirst + i;
+              float d, bx, by, bz;
+              if (i == 0u) { d = p_d; bx = p_bx; by = p_by; bz = p_bz; }
+              else if (i == 1u && served) { d = h_d; bx = h_bx; by = h_by; bz = h_bz; }
+              else {
+                const float4* tp = sc.tri_w + (size_t)triIdx * 3;
+                const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
+              }
+              if (d < hitd) {
+                hitd = d;
+                CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(5) = __float_as_uint(bz);
+                CTX(6) = CTX(8); CTX(7) = triIdx;
+                flags |= F_FOUND;
+                if (flags & F_ANYHIT) { stop = true; break; }
+                if (!(path_m < hitd)) break;   // abandon rule, as above
+              }
+            }
+            if (stop) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
+            else pop_next();
+          }
         }
       }
       if (STATS && A.wave_log) { const unsigned long long t1 = __builtin_readcyclecounter(); wl_tl += t1 - wl_t0; }
