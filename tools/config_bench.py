@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The other BASELINE.json configurations, measured once each on one MI355X (they are parity-test cases, not the
-bench line): prints one JSON object per configuration.  usage: python tools/config_bench.py [2] [3] [4] [5] [6] [--hair-strands N]   (6 = the raycast software twin)"""
+bench line): prints one JSON object per configuration.  usage: python tools/config_bench.py [2] [3] [4] [5] [6] [--hair-strands N]   (6 = the raycast software twin, 7 = the vx_* call sequence)"""
 import argparse, importlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -42,7 +42,7 @@ def render_cfg(tag, scene, W, H, light, steps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("configs", nargs="*", type=int, default=[2, 3, 4, 5, 6])
+    ap.add_argument("configs", nargs="*", type=int, default=[2, 3, 4, 5, 6, 7])
     ap.add_argument("--hair-strands", type=int, default=20000)   # x 250 segments x 2 = 10 M triangles
     a = ap.parse_args()
     out = []
@@ -105,6 +105,38 @@ def main():
         out.append({"config": "software twin (raycast): Sponza-class BVH2, 1920x1080, primary rays, 1 spp", "tris": sc["tri"].size // 36,
                     "bvh2_nodes": sc["bvh"].size // 32, "bvh2_depth": sc["max_depth"], "host_build_s": round(build_s, 1),
                     "ms_per_frame": round(ms, 3), "mrays_s": round(W * H / ms / 1e3, 1)})
+    if 7 in a.configs:
+        # the drop-in call sequence itself: vx_upload_bytes(kernel_arg) + vx_start + vx_ready_wait (+ vx_copy_from_dev), serial frames
+        sc = vrt.scene.procedural("atrium", 8, 0, 3)
+        W, H = 1920, 1080
+        tr = vrt.tracer.Tracer(W, H)
+        tr.init(sc)
+        t0 = time.time()
+        tr.setup(light_pos=(300.0, 480.0, 60.0), shadow=True)
+        upload_s = time.time() - t0
+        d = tr.dev
+        tr.run()
+        rays = d.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0)
+        def frame(copy):
+            args = d.upload_bytes(tr.kernel_arg)
+            d.start(tr.krnl, args)
+            d.ready_wait(vrt.runtime.VX_MAX_TIMEOUT)
+            if copy:
+                tr.bufs["out"].read()
+            args.free()
+        res = {}
+        for copy in (False, True):
+            for _ in range(5):
+                frame(copy)
+            t0 = time.time()
+            n = 100
+            for _ in range(n):
+                frame(copy)
+            res[copy] = (time.time() - t0) / n * 1e3
+        tr.close()
+        out.append({"config": "drop-in vx_* sequence (ctypes host): Sponza-class, 1920x1080, primary + 1 shadow ray, serial frames", "rays_per_frame": int(rays),
+                    "scene_upload_s": round(upload_s, 3), "ms_per_frame_start_wait": round(res[False], 4), "ms_per_frame_with_copy_from_dev": round(res[True], 4),
+                    "mrays_s_start_wait": round(rays / res[False] / 1e3, 1), "mrays_s_with_copy": round(rays / res[True] / 1e3, 1)})
     for o in out:
         print(json.dumps(o), flush=True)
 

@@ -22,10 +22,14 @@
 #include "../../include/vortex_hip.h"
 #include "rt_types.h"
 
+extern "C" uint32_t* vxrt_status_word_device(void);   // rt_kernels.hip
+
 namespace {
 
 constexpr uint64_t kUserBase = 0x10000;      // USER_BASE_ADDR (hw/VX_config.toml), runtime/simx/vortex.cpp:52
 constexpr uint64_t kBlockAlign = 64;         // CACHE_BLOCK_SIZE (runtime/common/common.h:29)
+constexpr uint64_t kSlotBytes = 4096;         // small-buffer slab slots
+constexpr uint32_t kSlotsPerSlab = 256;
 constexpr uint64_t kShadowMax = 64 * 1024;   // buffers up to this size keep a host shadow (args, sbt, kernel tags)
 constexpr const char* kTagPrefix = "VXHIP1:";
 
@@ -41,6 +45,7 @@ struct Alloc {
   uint64_t span = 0;        // block-aligned span in the address space
   void* dptr = nullptr;     // hipMalloc'ed backing store (span bytes)
   bool reserved = false;    // created by mem_reserve (kernel images)
+  bool pooled = false;      // dptr is a slot of the small-buffer slab (no hipMalloc/hipFree of its own)
   uint64_t version = 0;     // bumped by every copy_to_dev into this allocation
   std::vector<uint8_t> shadow;  // host copy for small buffers
 };
@@ -63,6 +68,11 @@ struct vx_device {
   std::unordered_map<uint32_t, uint32_t> dcrs;
   unsigned long long* d_rays = nullptr;
   unsigned long long last_rays = 0;
+  unsigned long long* h_back = nullptr;   // pinned: [0] rays, [1] status word of the run, copied back by the stream itself
+  // small buffers (kernel_arg_t, SBT, kernel selector images: re-allocated per run by the reference host, tracer.cpp:
+  // 272-281) come from slabs of kSlotBytes slots instead of one hipMalloc/hipFree each
+  std::vector<void*> slabs;
+  std::vector<void*> free_slots;
   float last_ms = 0.f;
   hipDeviceProp_t prop{};
   // acceleration layout of the scene last started, rebuilt only when one of the four traversal
@@ -82,6 +92,8 @@ struct vx_device {
     if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
     if (hipEventCreate(&ev_begin) != hipSuccess || hipEventCreate(&ev_end) != hipSuccess) return -1;
     if (hipMalloc((void**)&d_rays, sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipHostMalloc((void**)&h_back, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return -1;
+    h_back[0] = h_back[1] = 0;
     return 0;
   }
 
@@ -89,8 +101,10 @@ struct vx_device {
     (void)hipSetDevice(hip_dev);
     if (stream) (void)hipStreamSynchronize(stream);   // simx dtor waits for the run (vortex.cpp:69-71)
     if (accel) (void)vxrt_accel_destroy(accel);
-    for (auto& kv : allocs) if (kv.second.dptr) (void)hipFree(kv.second.dptr);
+    for (auto& kv : allocs) if (kv.second.dptr && !kv.second.pooled) (void)hipFree(kv.second.dptr);
+    for (void* sl : slabs) (void)hipFree(sl);
     if (d_rays) (void)hipFree(d_rays);
+    if (h_back) (void)hipHostFree(h_back);
     if (ev_begin) (void)hipEventDestroy(ev_begin);
     if (ev_end) (void)hipEventDestroy(ev_end);
     if (stream) (void)hipStreamDestroy(stream);
@@ -109,9 +123,27 @@ struct vx_device {
 
   int back(Alloc& a) {
     (void)hipSetDevice(hip_dev);
-    if (hipMalloc(&a.dptr, a.span) != hipSuccess) { VXLOG("hipMalloc(%llu) failed", (unsigned long long)a.span); return -1; }
+    if (a.span <= kSlotBytes) {
+      if (free_slots.empty()) {
+        void* slab = nullptr;
+        if (hipMalloc(&slab, (size_t)kSlotBytes * kSlotsPerSlab) != hipSuccess) { VXLOG("hipMalloc(slab) failed"); return -1; }
+        slabs.push_back(slab);
+        for (uint32_t i = 0; i < kSlotsPerSlab; ++i) free_slots.push_back((char*)slab + (size_t)(kSlotsPerSlab - 1 - i) * kSlotBytes);
+      }
+      a.dptr = free_slots.back();
+      free_slots.pop_back();
+      a.pooled = true;
+    } else if (hipMalloc(&a.dptr, a.span) != hipSuccess) { VXLOG("hipMalloc(%llu) failed", (unsigned long long)a.span); return -1; }
     if (a.size <= kShadowMax) a.shadow.assign(a.size, 0);
     return 0;
+  }
+
+  // does the acceleration layout of the last run point into this allocation?
+  bool accel_uses(const Alloc& a) const {
+    if (!accel) return false;
+    const uint64_t lo = (uint64_t)a.dptr, hi = lo + a.span;
+    for (int i : {0, 2, 4, 6, 8, 9, 10}) if (accel_key[i] >= lo && accel_key[i] < hi && accel_key[i] != 0) return true;
+    return false;
   }
 
   int mem_alloc(uint64_t size, uint64_t* va_out) {
@@ -144,8 +176,9 @@ struct vx_device {
     if (it == allocs.end()) return -1;
     wait_idle();
     (void)hipSetDevice(hip_dev);
-    if (accel) { (void)vxrt_accel_destroy(accel); accel = nullptr; }   // may reference this buffer
-    if (it->second.dptr) (void)hipFree(it->second.dptr);
+    if (accel_uses(it->second)) { (void)vxrt_accel_destroy(accel); accel = nullptr; }   // it references this buffer
+    if (it->second.pooled) free_slots.push_back(it->second.dptr);
+    else if (it->second.dptr) (void)hipFree(it->second.dptr);
     used -= it->second.span;
     allocs.erase(it);
     return 0;
@@ -183,12 +216,22 @@ struct vx_device {
     }
   }
 
+  // rays counter and status word travel back in the stream, so joining a run costs no extra synchronous copy
+  int enqueue_readback() {
+    uint32_t* st = vxrt_status_word_device();
+    if (!st) return -1;
+    h_back[1] = 0;
+    if (hipMemcpyAsync(&h_back[0], d_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(&h_back[1], st, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+    return 0;
+  }
+
   void finish_run() {
     if (!run_pending) return;
     run_pending = false;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) { last_ms = ms; have_timing = true; }
-    (void)hipMemcpy(&last_rays, d_rays, sizeof(last_rays), hipMemcpyDeviceToHost);
+    last_rays = h_back[0];   // copied back by the stream at the end of the run (enqueue_readback)
   }
 
   int upload(uint64_t va, const void* src, uint64_t size) {
@@ -325,6 +368,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
                        (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, nullptr, d_rays, stream);
   if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
   if (rc != 0) { VXLOG("start: launch rejected (shape check)"); return -1; }
+  if (enqueue_readback() != 0) return -1;
   run_pending = true;
   return 0;
 }
@@ -387,6 +431,7 @@ int vx_device::start_raycast(uint64_t args_va) {
   const int rc = vxrc_render(&sc, ka.dst_width, ka.dst_height, y0, y1, &pr, (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, stream);
   if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
   if (rc != 0) { VXLOG("start: raycast launch rejected (shape check)"); return -1; }
+  if (enqueue_readback() != 0) return -1;
   run_pending = true;
   return 0;
 }
@@ -399,14 +444,18 @@ int vx_device::ready_wait(uint64_t timeout_ms) {
     hipError_t q = hipStreamQuery(stream);
     if (q == hipSuccess) break;
     if (q != hipErrorNotReady) { VXLOG("ready_wait: %s", hipGetErrorString(q)); return -1; }
-    const auto el = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
-    if ((uint64_t)el >= timeout_ms) return -1;
-    std::this_thread::sleep_for(std::chrono::microseconds(50));
+    const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    if ((uint64_t)us >= timeout_ms * 1000ull) return -1;
+    if (us > 2000) std::this_thread::sleep_for(std::chrono::microseconds(20));   // frames take well under 2 ms: poll those without sleeping
   }
   finish_run();
-  uint32_t st = 0;
-  if (vxrt_status(stream, &st) != 0) return -1;
-  if (st != 0) { VXLOG("kernel reported status 0x%x (traversal stack overflow: BVH deeper than %d levels)", st, RT_MAX_LEVELS); return -1; }
+  const uint32_t st = (uint32_t)h_back[1];
+  if (st != 0) {
+    uint32_t cleared = 0;
+    (void)vxrt_status(stream, &cleared);   // read-and-clear, so that the next run starts clean
+    VXLOG("kernel reported status 0x%x (bit 0: traversal stack overflow, BVH deeper than %d levels; bit 2: index outside the scene buffers)", st, RT_MAX_LEVELS);
+    return -1;
+  }
   return 0;
 }
 
