@@ -289,6 +289,10 @@ int vxrt_status(void* stream, uint32_t* status);
 /* Raw device pointer behind a vx_buffer_h of the hip backend (for zero-copy hand-off to RCCL). */
 int vx_hip_buffer_device_ptr(vx_buffer_h hbuffer, void** dev_ptr);
 
+/* Host-side counters of a hip-backend device: which 0 = acceleration layouts built by vx_start so far (one per scene upload,
+ * not one per run), 1 = hipMalloc calls made for buffers (buffers up to 4 KB share slabs). */
+int vx_hip_device_stat(vx_device_h hdevice, uint32_t which, uint64_t* value);
+
 const char* vxrt_version(void);
 
 #ifdef __cplusplus

@@ -135,3 +135,22 @@ def test_mirror_bounce_through_vx_api(vrt, po, gpu_device):
     flat, _, _ = po.render(b, w, h, po.shade_params(light_pos=(150.0, 220.0, -60.0)))
     assert not np.array_equal(px, flat)
     tr.close()
+
+
+def test_runs_do_not_rebuild_or_reallocate(vrt, gpu_device):
+    """The reference host re-uploads kernel_arg_t for every run (tracer.cpp:272-281: vx_upload_bytes -> a new buffer) and
+    our mirror frees the previous one: neither may cost an acceleration-layout build or a hipMalloc per run."""
+    sc = vrt.scene.procedural("blob", 3, 0, 1)
+    tr = vrt.tracer.Tracer(96, 64)
+    tr.init(sc)
+    tr.setup()
+    first = tr.run()
+    builds, mallocs = tr.dev.hip_stat(0), tr.dev.hip_stat(1)
+    assert builds == 1
+    for _ in range(5):
+        assert np.array_equal(tr.run(), first)
+    assert tr.dev.hip_stat(0) == 1 and tr.dev.hip_stat(1) == mallocs
+    tr.setup(light_pos=(100.0, 300.0, 50.0))     # re-uploads the scene buffers: one rebuild, no new device allocations
+    tr.run()
+    assert tr.dev.hip_stat(0) == 2 and tr.dev.hip_stat(1) == mallocs
+    tr.close()

@@ -73,6 +73,7 @@ struct vx_device {
   // 272-281) come from slabs of kSlotBytes slots instead of one hipMalloc/hipFree each
   std::vector<void*> slabs;
   std::vector<void*> free_slots;
+  uint64_t n_accel_builds = 0, n_hip_mallocs = 0;   // vx_hip_device_stat
   float last_ms = 0.f;
   hipDeviceProp_t prop{};
   // acceleration layout of the scene last started, rebuilt only when one of the four traversal
@@ -127,13 +128,17 @@ struct vx_device {
       if (free_slots.empty()) {
         void* slab = nullptr;
         if (hipMalloc(&slab, (size_t)kSlotBytes * kSlotsPerSlab) != hipSuccess) { VXLOG("hipMalloc(slab) failed"); return -1; }
+        ++n_hip_mallocs;
         slabs.push_back(slab);
         for (uint32_t i = 0; i < kSlotsPerSlab; ++i) free_slots.push_back((char*)slab + (size_t)(kSlotsPerSlab - 1 - i) * kSlotBytes);
       }
       a.dptr = free_slots.back();
       free_slots.pop_back();
       a.pooled = true;
-    } else if (hipMalloc(&a.dptr, a.span) != hipSuccess) { VXLOG("hipMalloc(%llu) failed", (unsigned long long)a.span); return -1; }
+    } else {
+      if (hipMalloc(&a.dptr, a.span) != hipSuccess) { VXLOG("hipMalloc(%llu) failed", (unsigned long long)a.span); return -1; }
+      ++n_hip_mallocs;
+    }
     if (a.size <= kShadowMax) a.shadow.assign(a.size, 0);
     return 0;
   }
@@ -358,6 +363,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
                             ((uint64_t)sc.n_bvh_nodes << 32) | sc.n_tris};
   if (!accel || std::memcmp(key, accel_key, sizeof key) != 0) {
     if (accel) { (void)vxrt_accel_destroy(accel); accel = nullptr; }
+    ++n_accel_builds;
     if (vxrt_accel_build(&sc, stream, &accel) != 0) { VXLOG("start: scene rejected (malformed BVH: index out of range, wrong node kind or child not after parent)"); return -1; }
     std::memcpy(accel_key, key, sizeof key);
   }
@@ -468,6 +474,16 @@ extern "C" int vx_hip_buffer_device_ptr(vx_buffer_h hbuffer, void** dev_ptr) {
   if (!a) return -1;
   *dev_ptr = (char*)a->dptr + (b->addr - a->va);
   return 0;
+}
+
+extern "C" int vx_hip_device_stat(vx_device_h hdevice, uint32_t which, uint64_t* value) {
+  if (!hdevice || !value) return -1;
+  auto d = (vx_device*)hdevice;
+  switch (which) {
+  case 0: *value = d->n_accel_builds; return 0;
+  case 1: *value = d->n_hip_mallocs; return 0;
+  }
+  return -1;
 }
 
 extern "C" int vx_dev_init(callbacks_t* cb) {

@@ -55,6 +55,8 @@ def hip_lib():
     global _hip
     if _hip is None:
         _hip = C.CDLL(lib_path("libvortex-hip.so"), mode=C.RTLD_GLOBAL)
+        _hip.vx_hip_device_stat.restype = C.c_int
+        _hip.vx_hip_device_stat.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
         _hip.vx_hip_buffer_device_ptr.restype = C.c_int
         _hip.vx_hip_buffer_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     return _hip
@@ -109,6 +111,12 @@ class Device:
         if self.handle:
             check(lib().vx_dev_close(self.handle), "vx_dev_close")
             self.handle = None
+
+    def hip_stat(self, which):
+        """vx_hip_device_stat: 0 = acceleration layouts built, 1 = hipMalloc calls for buffers"""
+        v = C.c_uint64()
+        check(hip_lib().vx_hip_device_stat(self.handle, which, C.byref(v)), "vx_hip_device_stat")
+        return int(v.value)
 
     def caps(self, caps_id):
         v = C.c_uint64()
