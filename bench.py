@@ -308,7 +308,10 @@ def main():
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "rt_persistent_kernel<JOB_RENDER%s> (+ EXACT launches + rt_shade_kernel)" % ("_SHADOW" if shadow else ""),
                 "kernel_ms": round(kern_ms, 4), "kernel_ms_overlapped": round(ovl_ms, 4), "kernel_ms_isolated": round(iso_ms, 4),
-                "frames_in_flight": nfl}
+                "frames_in_flight": nfl,
+                "note": "algorithmic bytes are SURVEY s8d's per-ray formula (52 B per node, 36 B per triangle the reference would fetch); the scene is "
+                        "cache-resident (traffic = measured HBM bytes per step), so achieved can exceed the HBM peak; the kernel's own limit is VALU issue "
+                        "(88 % for an isolated launch, 69 % active lanes: profiles/r01_k_pmc.txt, DESIGN.md s4)"}
         if bytes_launch:
             ach = bytes_launch / (kern_ms * 1e-3) / 1e9
             roof.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
