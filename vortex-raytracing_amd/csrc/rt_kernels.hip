@@ -1426,7 +1426,9 @@ static uint32_t* status_word() {
 }
 
 #define LPT_MIN_TILES 20000u
+#ifndef EXACT_GRID
 #define EXACT_GRID 128   // workgroups of the EXACT launch (it sees a fraction of a percent of the rays)
+#endif
 
 // grid of a persistent launch: what the device holds at once (occupancy x CUs, queried once per kernel
 // and device), capped by the job count
