@@ -149,7 +149,8 @@ def main():
     nfl = max(1, min(8, a.frames_in_flight))
     # frame i goes to stream i % nfl and framebuffer i % nfl; the accel keeps nfl frame contexts
     streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(nfl - 1)]
-    frames = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(max(2, nfl))]
+    # (with several ranks a framebuffer stays busy until its gather has run: twice as many, so that rendering never waits for the link)
+    frames = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(max(2, nfl) * (2 if world > 1 else 1))]
     counters = torch.zeros(8, dtype=torch.int64, device=dev)
 
     def launch(buf, count_ptr=None, st=None):
