@@ -97,6 +97,10 @@ int vx_dev_init(callbacks_t* callbacks);
 #define VX_DCR_HIP_ROW_END 0x7F1
 /* Backend extension: 0 = closest-hit only (reference behaviour), 1 = +1 shadow ray toward light_pos. */
 #define VX_DCR_HIP_SHADOW_RAYS 0x7F2
+/* Backend extension: tile-row stride of the row window.  0/1 = the contiguous rows [ROW_BEGIN, ROW_END); n > 1 = this device
+ * renders the 8-row tile rows phase, phase + n, phase + 2n, ... of the frame with phase = ROW_BEGIN / 8 (< n): the split of one
+ * frame over n GPUs that balances them (see vxrt_render_interleaved). */
+#define VX_DCR_HIP_ROW_STRIDE 0x7F3
 
 /* CSRs answered by mpm_query (read by vx_dump_perf at vx_dev_close: stub/perf.cpp:195-227). */
 #define VX_CSR_MPM_BASE 0xB00
@@ -180,7 +184,10 @@ typedef struct {
 /* Device-side acceleration layout built ONCE per scene from the reference-format buffers above
  * (compact 64-byte nodes with inlined leaf / instance descriptors, edge-form triangles).  The build
  * validates every index the traversal can follow and fails (-1) on a malformed tree instead of
- * letting a kernel fault.  The vxrt_scene_t buffers must stay alive and unchanged while the accel
+ * letting a kernel fault; so are the indices shading follows (every triangle's texId < n_mats; a textured material's
+ * texels inside [tex, tex + tex_bytes) with non-zero dimensions).  With RT_TOP_NODES > 0 (build flag) the first internal
+ * nodes in breadth-first order are also laid out as an image each workgroup stages in LDS.
+ * The vxrt_scene_t buffers must stay alive and unchanged while the accel
  * is in use (shading reads blas/triEx/mat/tex from them).  Synchronous with respect to `stream`. */
 typedef struct vxrt_accel vxrt_accel_t;
 int vxrt_accel_build(const vxrt_scene_t* scene, void* stream, vxrt_accel_t** out);
@@ -200,13 +207,22 @@ int vxrt_accel_frames_in_flight(vxrt_accel_t* accel, uint32_t n);
  * closest/miss shade -> RGB8 pack -> dst[x + y*W] (kernel.cpp:95-106).  `dst` points at pixel
  * (0,0) of the full W x H frame.  shadow != 0 adds one occlusion ray per hit (extension).
  * rays_traced (device u64, may be NULL) is atomically incremented by the number of rays traced.
- * Two launches on `stream`: the persistent traversal kernel leaves 24-byte hit records in a W*H
- * buffer owned by the accel, the shading kernel turns them into pixels; one render may be in
- * flight per accel at a time. */
+ * Two launches on `stream`: the persistent traversal kernel leaves 24-byte hit records (tile-major, one
+ * contiguous 1,536-byte block per 8x8 tile, written once) in a buffer owned by the frame context, the shading
+ * kernel turns them into pixels.
+ * hits (optional): the pixel's closest-hit record in pixel order; with shadow != 0, bit 31 of blasIdx is set
+ * when the pixel's occlusion ray was blocked (mask it off to compare with a closest-hit record). */
 int vxrt_render(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                 const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                 vxrt_hit_t* hits /* optional, W*H */, float* colors /* optional, 3*W*H */,
                 unsigned long long* rays_traced, void* stream);
+
+/* One rank's share of a frame split over `stride` devices: the 8-row tile rows phase, phase + stride, ... (phase < stride).
+ * Same contract as vxrt_render otherwise (dst points at pixel (0,0) of the full frame and only this share's rows are
+ * written).  Interleaving balances the ranks: the cost of a tile varies 4x over the frame, mostly with image height. */
+int vxrt_render_interleaved(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t phase, uint32_t stride,
+                            const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits,
+                            float* colors, unsigned long long* rays_traced, void* stream);
 
 /* vxrt_render with the fetch counters compiled in (diagnostic build of the same kernel, never
  * timed): counters = device u64[7]: rays, node fetches, instance fetches, triangle fetches,

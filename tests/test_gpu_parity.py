@@ -46,7 +46,11 @@ def gpu_render(vrt, dscene, w, h, y0=0, y1=None, shadow=0, params=None):
     params = params or vrt.rtapi.default_shade_params()
     vrt.rtapi.render(dscene.accel, w, h, y0, y1, params, px.data_ptr(), shadow, hits.data_ptr(), col.data_ptr(), cnt.data_ptr(), stream)
     assert vrt.rtapi.status(stream) == 0
-    return (px.cpu().numpy().view(np.uint32), _hits_np(hits).reshape(h, w), col.cpu().numpy().reshape(h, w, 3), int(cnt.item()))
+    hn = _hits_np(hits).reshape(h, w).copy()
+    # with shadow != 0 the optional hit output carries the occlusion result in bit 31 of blasIdx (include/vortex_hip.h)
+    gpu_render.occluded = (hn["blasIdx"] >> 31).astype(bool)
+    hn["blasIdx"] &= 0x7FFFFFFF
+    return (px.cpu().numpy().view(np.uint32), hn, col.cpu().numpy().reshape(h, w, 3), int(cnt.item()))
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -198,36 +202,50 @@ def test_malformed_trees_are_rejected_at_build_time(vrt, golden, gpu_device):
     torch.cuda.synchronize()
 
 
-def test_shadow_rays_extension(vrt, po, gpu_device):
-    """primary + 1 shadow ray (BASELINE config 2/3; no reference counterpart): occlusion is decided
-    by the same traversal oracle in any-hit mode, shading drops the direct term when occluded."""
-    sc = vrt.scene.procedural("blob", 4, 0, 1)
-    ds = vrt.tracer.DeviceScene(sc, gpu_device)
-    w, h = 128, 96
-    p = vrt.rtapi.default_shade_params()
-    p.light_pos[:] = (60.0, 260.0, -150.0)
-    px, hits, col, nrays = gpu_render(vrt, ds, w, h, shadow=1, params=p)
-    # oracle side: primary hits, then occlusion rays built exactly as the kernel documents them
-    pp = po.shade_params(light_pos=tuple(p.light_pos))
-    _, rhits, rcol = po.render(sc, w, h, pp)
-    assert np.array_equal(_bits(hits), _bits(rhits))
-    hit_mask = rhits["dist"].reshape(-1) < 1e29
-    assert nrays == w * h + int(hit_mask.sum())
-    rays = po.camera_rays(w, h)
+def _occlusion_oracle(po, sc, w, h, pp, rhits):
+    """Occluded set of a frame decided by the faithful restatement in any-hit mode: occlusion rays built exactly as the
+    kernel documents them (origin I + 0.001 L, direction L, tmax |light - I|; shadow_ray in csrc/rt_kernels.hip)."""
     f = np.float32
+    hit_mask = rhits["dist"].reshape(-1) < 1e29
+    rays = po.camera_rays(w, h)
     I = (rays[:, :3] + rays[:, 3:] * rhits["dist"].reshape(-1, 1).astype(f)).astype(f)
     L = (np.array(pp.light_pos[:], f)[None] - I).astype(f)
     dist = np.sqrt((L[:, 0] * L[:, 0] + L[:, 1] * L[:, 1]).astype(f) + (L[:, 2] * L[:, 2]).astype(f)).astype(f)
     Ln = (L * (f(1.0) / dist)[:, None]).astype(f)
     srays = np.concatenate([(I + (Ln * f(0.001)).astype(f)).astype(f), Ln], 1).astype(f)[hit_mask]
     occ, _ = po.trace_faithful(sc, srays, tmax=dist[hit_mask], any_hit=True)
-    occluded = occ["dist"] < 1e29
-    assert occluded.any() and (~occluded).any()
-    # lit pixels equal the unshadowed oracle colour; occluded ones are darker or equal
-    col = col.reshape(-1, 3)[hit_mask]
-    rcol = rcol.reshape(-1, 3)[hit_mask]
-    np.testing.assert_allclose(col[~occluded], rcol[~occluded], rtol=COLOR_RTOL)
-    assert (col[occluded] <= rcol[occluded] + 1e-7).all()
+    out = np.zeros(w * h, bool)
+    out[hit_mask] = occ["dist"] < 1e29
+    return out.reshape(h, w), hit_mask.reshape(h, w)
+
+
+@pytest.mark.parametrize("scene_args,w,h,light", [(("blob", 4, 0, 1), 128, 96, (60.0, 260.0, -150.0)),
+                                                  (("atrium", 5, 0, 3), 200, 112, (300.0, 480.0, 60.0))])
+def test_shadow_rays_extension(vrt, po, gpu_device, scene_args, w, h, light):
+    """primary + 1 shadow ray (the headline workload's shape; BASELINE configs 2/3; no reference counterpart).  Two-sided:
+    the whole frame -- pixels, colours, hit records, ray total -- equals the restatement's frame with the shadow extension,
+    and the set of occluded pixels the kernel reports equals what the faithful traversal restatement decides in any-hit
+    mode.  The timed kernel takes the UNORDERED any-hit path for these rays; which triangle is met first cannot change
+    the boolean, and this test is what pins that."""
+    sc = vrt.scene.procedural(*scene_args)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    p = vrt.rtapi.default_shade_params()
+    p.light_pos[:] = light
+    px, hits, col, nrays = gpu_render(vrt, ds, w, h, shadow=1, params=p)
+    occ_gpu = gpu_render.occluded
+    pp = po.shade_params(light_pos=tuple(p.light_pos))
+    rpx, rhits, rcol, rn = po.render_ex(sc, w, h, pp, 1)
+    assert np.array_equal(_bits(hits), _bits(rhits))
+    assert nrays == rn == w * h + int((rhits["dist"] < 1e29).sum())
+    occ_ref, hit_mask = _occlusion_oracle(po, sc, w, h, pp, rhits)
+    assert occ_ref.any() and (hit_mask & ~occ_ref).any()
+    np.testing.assert_array_equal(occ_gpu, occ_ref)
+    np.testing.assert_array_equal(px, rpx)
+    np.testing.assert_allclose(col, rcol, rtol=COLOR_RTOL, atol=0)
+    # and the shadow really changes the frame: an occluded pixel with N.L > 0 is darker than the unshadowed restatement
+    _, _, ucol = po.render(sc, w, h, pp)
+    assert (col[occ_ref] <= ucol[occ_ref] + 1e-7).all() and (col[occ_ref] < ucol[occ_ref] - 1e-4).any()
+    np.testing.assert_allclose(col[~occ_ref], ucol[~occ_ref], rtol=COLOR_RTOL, atol=0)
 
 
 def test_fetch_counters_equal_oracle_counts(vrt, po, gpu_device):

@@ -33,3 +33,6 @@ for shadow in (1,):
           % (rays.sum(), nl / rays.sum(), ll / rays.sum(), nx * 64 / rays.sum(), lx * 64 / rays.sum()))
     tn, tl, tt = lg[:, 10].sum(), lg[:, 11].sum(), lg[:, 12].sum()
     print("shader clocks: node body %.3f, instance+leaf part %.3f, rest (fetch, finish, loop control) %.3f of the wave lifetime" % (tn / tt, tl / tt, 1 - (tn + tl) / tt))
+    print("node steps served from the LDS top-of-tree image: %.3f of lane node steps; node-body runs with every node lane at the SAME node: %.3f"
+          % (lg[:, 8].sum() / max(nl, 1), lg[:, 9].sum() / max(nx, 1)))
+    print("shader clocks per node-body run %.0f, per instance+leaf run %.0f, per iteration %.0f" % (tn / max(nx, 1), tl / max(lx, 1), tt / max(it, 1)))

@@ -13,7 +13,7 @@ entry raises if the HIP library is missing or no device is present.
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_DIR = os.environ.get("VXRT_LIB_DIR") or os.path.join(PKG_DIR, "lib")   # (override: A/B of prebuilt kernel variants, tools/build_variants.py)
 VXBIN_DIR = os.path.join(PKG_DIR, "vxbin")
 REPO_DIR = os.path.dirname(PKG_DIR)
 

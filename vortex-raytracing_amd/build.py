@@ -23,7 +23,9 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
 
 # -ffp-contract=off is part of the numerical contract of the hit path
-HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: under plain -O3 the SLP vectoriser packs the slab arithmetic into v_pk_mul/add_f32 + v_mov shuffles, which
+# costs registers and 3 % of the frame (profiles/r02_a_variants.txt)
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 HIP_FLAGS += os.environ.get("VXRT_EXTRA_HIPFLAGS", "").split()   # experiments only (e.g. -DLDS_STACK=8)
 CXX_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall"]
 

@@ -57,6 +57,8 @@
 #define DESC_IDLE 0xFFFFFFFDu   // lane has no ray
 #define DESC_NONE 0xFFFFFFFFu   // compact node: empty child slot
 #define PAYLOAD_MASK 0x3FFFFFFFu
+#define DESC_TOP_FLAG 0x20000000u   // node descriptor: payload = slot of the LDS-staged top-of-tree image (kernels with USE_TOP only)
+#define DESC_TOP_SLOT 0x0000FFFFu
 #define LEAF_FIRST_BITS 26
 #define LEAF_FIRST_MASK 0x03FFFFFFu
 #define LEAF_MAX_INLINE 15u
@@ -76,6 +78,13 @@ struct SceneDev {
   const rt_triex_t* triEx;
   const rt_material_t* mat;
   const uint8_t* tex;
+  // top of the tree for LDS staging (accel_top_kernel): the first n_top internal nodes in breadth-first order from the
+  // TLAS root, as four planes of n_top uint4 (q0[], q1[], q2[], q3[]: conflict-free ds_read_b128 for neighbouring slots);
+  // child descriptors inside the image and the *_top roots address staged nodes by slot (DESC_TOP_FLAG)
+  const uint4* top_img;
+  uint32_t n_top;
+  uint32_t tlas_root_top;
+  const uint32_t* blas_root_top;
 };
 
 struct HitRec { float dist, bx, by, bz; uint32_t blasIdx, triIdx; };
@@ -193,10 +202,9 @@ __device__ __forceinline__ float child_box(const uint32_t* pl, float px, float p
 
 // Box tests of the <=4 children of an internal node.
 template <bool EXACT, bool LDEXP>
-__device__ __forceinline__ void eval_children(const uint4* __restrict__ np, const uint32_t* __restrict__ ref_node,
+__device__ __forceinline__ void eval_children(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const uint32_t* __restrict__ ref_node,
                                               float rox, float roy, float roz, float rix, float riy, float riz,
                                               float hit_dist, Cand* c) {
-  const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
   const float px = __uint_as_float(q0.x), py = __uint_as_float(q0.y), pz = __uint_as_float(q0.z);
   // plane scales 2^e as floats (fma decode); the ldexp decode takes the exponents from the reference node
   const float sx = __uint_as_float(q0.w), sy = __uint_as_float(q3.z), sz = __uint_as_float(q3.w);
@@ -428,11 +436,35 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #ifndef LDS_STACK
 #define LDS_STACK 8         // stack levels kept in LDS per lane (4 KiB per wavefront); deeper ones go to scratch
 #endif
+#ifndef RT_WG_WAVES
+#define RT_WG_WAVES 4       // wavefronts per workgroup of the persistent kernels (the staged top of the tree is shared by them)
+#endif
+#define RT_WG_THREADS (64 * RT_WG_WAVES)
+#ifndef RT_TOP_NODES
+#define RT_TOP_NODES 0      // internal nodes of the top of the tree staged in LDS per workgroup (64 B each); 0 = off
+#endif
+#define RT_TOP_MAX 1024
+static_assert(RT_TOP_NODES <= RT_TOP_MAX, "top-of-tree image");
 
 enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2 };
 
+// Hit records of a frame window are kept TILE-MAJOR between the traversal and the shading pass: record of pixel (x, y) =
+// tile * 64 + lane of the 8x8 tile grid that starts at row y0, i.e. the job id of the traversal kernel.  A wavefront
+// therefore writes the 64 records of its tile as one contiguous, 128-byte aligned 1,536-byte block, once (the occlusion
+// result is folded into bit 31 of blasIdx before the record is written): no cache line is shared between wavefronts, so no
+// XCD writes a partial line back (round 1 wrote pixel-major records + an atomicOr per occluded pixel: 121 MB of HBM
+// writes per 1080p frame for 50 MB of records, profiles/r01_k_pmc.txt).
+// `lr` = local row of the window: rows are counted through the window's tile rows (8 each) in order.
+__device__ __forceinline__ size_t hit_index(uint32_t x, uint32_t lr, uint32_t tiles_x) {
+  return ((size_t)(lr >> 3) * tiles_x + (x >> 3)) * 64u + ((lr & 7u) << 3) + (x & 7u);
+}
+// frame row of local row lr: the window's k-th tile row is frame rows y0 + k * row_step ... + 7 (row_step = 8 for a contiguous
+// window, 8 * stride for the interleaved tile rows of vxrt_render_interleaved)
+__device__ __forceinline__ uint32_t frame_row(uint32_t lr, uint32_t y0, uint32_t row_step) { return y0 + (lr >> 3) * row_step + (lr & 7u); }
+
 struct PersistArgs {
   uint32_t W, H, y0, y1, tiles_x;
+  uint32_t row_step;              // frame rows between two consecutive tile rows of the window: 8, or 8 * stride (interleaved)
   uint32_t total;                 // number of jobs (tiles*64 pixels, or rays); an upper bound when total_dev is set
   const uint32_t* total_dev;      // optional: the job count lives in device memory (produced by an earlier kernel of the stream)
   HitRec* hits;                   // render: W*H hit records (occlusion in bit 31 of blasIdx); trace: n records
@@ -462,6 +494,7 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 #define F_ANYHIT 2u
 #define F_SHADOW 8u      // render job is in its occlusion-ray phase
 #define F_WORLD 16u      // the active ray registers hold the world-space ray (TLAS level)
+#define F_RESUMED 32u    // EXACT launch: occlusion ray handed over by the main launch (its primary hit record is in memory)
 
 // Register budget is the lever here (profiles/r01_c_*: at 4 waves/SIMD the VALU pipe idles 58 % of
 // the time waiting on dependent loads), so a lane keeps in VGPRs only what every step touches: the
@@ -471,7 +504,9 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 // next to the stack; the world ray is not stored at all - it is re-derived from the job (ray buffer,
 // camera tables, or the pixel's primary hit record) on the rare TLAS-level steps.
 template <int JOB, bool STATS, bool LDEXP, bool EXACT>
-__global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+  constexpr int WG_WAVES = EXACT ? 4 : RT_WG_WAVES;
+  constexpr bool USE_TOP = RT_TOP_NODES > 0 && !EXACT && !LDEXP;   // (the ldexp decode reads exponents from the reference node by index)
   constexpr uint32_t DEAD_MAX = JOB == JOB_TRACE ? RT_TRACE_DEAD_MAX : RT_DEAD_MAX;
   // render-with-shadow jobs: retire finished primary rays (their lanes continue with the occlusion ray
   // of the same pixel - same traversal code, so no phase mixing) before the whole tile is done
@@ -481,14 +516,26 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
   const uint32_t n_jobs = EXACT ? min(*A.defer_count, A.defer_cap) : (A.total_dev ? min(*A.total_dev, A.total) : A.total);
   const uint32_t per_shard = (EXACT || A.total_dev) ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
 
-  __shared__ uint2 s_stk[4][LDS_STACK][64];   // stack levels below the register top, 8 B entries, conflict-free rows
-  __shared__ uint8_t s_pair[4][2][64];        // leaf helpers (RT_LEAF_HELPERS): owner lane by rank, helper lane by rank
+  __shared__ uint2 s_stk[WG_WAVES][LDS_STACK][64];   // stack levels below the register top, 8 B entries, conflict-free rows
+  __shared__ uint8_t s_pair[WG_WAVES][2][64];        // leaf helpers (RT_LEAF_HELPERS): owner lane by rank, helper lane by rank
   uint8_t* const pair_o = &s_pair[threadIdx.x >> 6][0][0];
   uint8_t* const pair_h = &s_pair[threadIdx.x >> 6][1][0];
-  __shared__ uint32_t s_ctx[4][9][64];        // 0-2 active dir, 3-5 hit bx/by/bz, 6 hit blasIdx, 7 hit triIdx, 8 blasIdx
+  // 0-2 active dir, 3-4 hit bx/by (bz = 1 - bx - by is re-derived when the record is written), 5 distance of the pixel's
+  // primary hit while its occlusion ray is traced, 6 hit blasIdx, 7 hit triIdx, 8 blasIdx
+  __shared__ uint32_t s_ctx[WG_WAVES][9][64];
   uint2* const lstk = &s_stk[threadIdx.x >> 6][0][lane];
   uint32_t* const ctx = &s_ctx[threadIdx.x >> 6][0][lane];
 #define CTX(i) ctx[(i) * 64]
+  // top of the tree staged in LDS (north_star: "BVH nodes staged through LDS"): the first levels are what every ray of every
+  // tile walks, and a ds_read_b128 does not queue behind the CU's vector-memory pipeline
+  __shared__ uint4 s_top[USE_TOP ? 4 : 1][USE_TOP ? RT_TOP_NODES : 1];
+  const uint32_t n_top = USE_TOP ? min(sc.n_top, (uint32_t)RT_TOP_NODES) : 0u;
+  if (USE_TOP && n_top) {
+    for (uint32_t i = threadIdx.x; i < 4u * n_top; i += (uint32_t)(64 * WG_WAVES)) s_top[i / n_top][i % n_top] = sc.top_img[(size_t)(i / n_top) * RT_TOP_NODES + (i % n_top)];
+    __syncthreads();
+  }
+  const uint32_t root_desc = (USE_TOP && n_top) ? sc.tlas_root_top : sc.tlas_root;
+  const uint32_t* const blas_roots = (USE_TOP && n_top) ? sc.blas_root_top : sc.blas_root;
 
   // ---- per-lane ray state in registers ----
   float arx = 0, ary = 0, arz = 0, aix = 0, aiy = 0, aiz = 0;   // active ray: origin, 1/direction
@@ -514,7 +561,7 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
   auto pixel_of = [&](uint32_t r, uint32_t& x, uint32_t& y) {
     const uint32_t tile = r >> 6, l = r & 63u;
     x = (tile % A.tiles_x) * 8u + (l & 7u);
-    y = A.y0 + (tile / A.tiles_x) * 8u + (l >> 3);
+    y = A.y0 + (tile / A.tiles_x) * A.row_step + (l >> 3);
   };
   // the lane's world-space ray, re-derived from its job (deterministic: same bits every time)
   auto world_ray = [&](float& ox, float& oy, float& oz, float& dx, float& dy, float& dz, float& tmax_) {
@@ -528,7 +575,7 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
       pixel_of(job, x, y);
       generate_ray(A.utab[x], A.vtab[y], ox, oy, oz, dx, dy, dz);
       if (JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW)) {
-        const float pd = A.hits[(size_t)x + (size_t)y * A.W].dist;   // primary hit of this pixel, written before the occlusion ray started
+        const float pd = __uint_as_float(CTX(5));   // distance of this pixel's primary hit
         float sox, soy, soz, sdx, sdy, sdz, sdist;
         shadow_ray(p, ox, oy, oz, dx, dy, dz, pd, sox, soy, soz, sdx, sdy, sdz, sdist);
         ox = sox; oy = soy; oz = soz; dx = sdx; dy = sdy; dz = sdz;
@@ -537,9 +584,17 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
     }
   };
   // main launch only: hand this lane's ray (in its current phase) over to the EXACT launch
-  auto defer = [&]() {
+  auto defer = [&](bool counted) {
     const uint32_t slot = atomicAdd(A.defer_count, 1u);
     if (slot < A.defer_cap) A.defer_list[slot] = job | ((flags & F_SHADOW) ? 0x80000000u : 0u);
+    if (JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW)) {
+      // the EXACT launch resumes this pixel's occlusion ray from the primary hit record in memory
+      HitRec h;
+      h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;
+      h.dist = __uint_as_float(CTX(5)); h.blasIdx = CTX(6); h.triIdx = CTX(7);
+      A.hits[job] = h;
+    }
+    if (counted) nrays--;   // the EXACT launch counts the ray when it starts it again
     cur = DESC_IDLE;
   };
   // TLAS leaf (rt_traversal.cpp:109-121): fetch the instance record, move the ray to object space
@@ -561,11 +616,11 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
     aix = 1.0f / cdx; aiy = 1.0f / cdy; aiz = 1.0f / cdz;
     const bool s2 = (aix - aix == 0.0f) && (aiy - aiy == 0.0f) && (aiz - aiz == 0.0f) && aix != 0.0f && aiy != 0.0f && aiz != 0.0f &&
                     (arx - arx == 0.0f) && (ary - ary == 0.0f) && (arz - arz == 0.0f);
-    if (!EXACT && !s2) { defer(); return; }   // object-space ray can produce NaN slabs: restart it in the EXACT launch
+    if (!EXACT && !s2) { defer(true); return; }   // object-space ray can produce NaN slabs: restart it in the EXACT launch
     flags &= ~F_WORLD;
     CTX(0) = __float_as_uint(cdx); CTX(1) = __float_as_uint(cdy); CTX(2) = __float_as_uint(cdz);
     CTX(8) = blasIdx;
-    cur = sc.blas_root[blasIdx];   // BLAS root: same level, path_m unchanged
+    cur = blas_roots[blasIdx];   // BLAS root: same level, path_m unchanged
   };
   // (re)start the lane's traversal at the TLAS root (rt_traversal.cpp:39-40) with world ray (o, d)
   auto start_ray = [&](float ox, float oy, float oz, float dx, float dy, float dz, float tmax_, bool any_) {
@@ -574,19 +629,19 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
     // the fast slab forms are exact only if no slab product can be NaN (finite non-zero 1/d, finite origin)
     const bool safe = (aix - aix == 0.0f) && (aiy - aiy == 0.0f) && (aiz - aiz == 0.0f) && aix != 0.0f && aiy != 0.0f && aiz != 0.0f &&
                       (ox - ox == 0.0f) && (oy - oy == 0.0f) && (oz - oz == 0.0f);
-    flags = (flags & F_SHADOW) | F_WORLD | (any_ ? F_ANYHIT : 0u);
+    flags = (flags & (F_SHADOW | F_RESUMED)) | F_WORLD | (any_ ? F_ANYHIT : 0u);
     if (!EXACT && !safe) {
       // camera rays with a zero direction component are known before the launch (u == 0 or v == 0): the
       // host lists them and a concurrent EXACT launch traces them; everything else is deferred
-      if (JOB != JOB_TRACE && !(flags & F_SHADOW)) cur = DESC_IDLE; else defer();
+      if (JOB != JOB_TRACE && !(flags & F_SHADOW)) cur = DESC_IDLE; else defer(false);
       return;
     }
     hitd = tmax_; path_m = -__builtin_inff(); sp = 0; tos_d = DESC_DONE;
-    cur = sc.tlas_root;
+    cur = root_desc;
     nrays++;
     // single-instance scenes (the reference's default): the TLAS root is the instance leaf, enter it
     // right away with the ray at hand instead of re-deriving it in the instance step
-    if (is_inst_desc(sc.tlas_root)) enter_instance(sc.tlas_root & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz);
+    if (is_inst_desc(root_desc)) enter_instance(root_desc & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz);
   };
   auto push = [&](uint32_t d, float m) {
     if (tos_d != DESC_DONE) {
@@ -653,7 +708,11 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
           if (rank < avail) {
             job = loc_next + rank + loc_off;
             flags = 0;
-            if (EXACT) { const uint32_t wd = A.defer_list[job]; job = wd & 0x7fffffffu; if (wd >> 31) flags = F_SHADOW; }
+            if (EXACT) {
+              const uint32_t wd = A.defer_list[job];
+              job = wd & 0x7fffffffu;
+              if (wd >> 31) { flags = F_SHADOW | F_RESUMED; if (JOB == JOB_RENDER_SHADOW) CTX(5) = __float_as_uint(A.hits[job].dist); }
+            }
             float ox, oy, oz, dx, dy, dz, tm;
             if (JOB == JOB_TRACE) {
               world_ray(ox, oy, oz, dx, dy, dz, tm);
@@ -687,6 +746,8 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
         ++wl_iter;
         if (nm) {
           ++wl_node_x; wl_node_l += (unsigned)__popcll(nm);
+          const uint32_t c0 = __shfl(cur, __ffsll((long long)nm) - 1);
+          if (__ballot(is_node_desc(cur) && cur == c0) == nm) ++wl_no3;   // every node lane of the wavefront is at the same node
         }
       }
       if (STATS && A.wave_log) wl_t0 = __builtin_readcyclecounter();
@@ -700,12 +761,26 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
           flags |= F_WORLD;
         }
         const uint32_t ni = cur & PAYLOAD_MASK;
-        const uint4* np = sc.nodes_c + (size_t)ni * CNODE_VEC4;
+        uint4 q0, q1, q2, q3;
+        if (USE_TOP && (cur & DESC_TOP_FLAG)) {
+          // (volatile, LDS-typed pointer: through plain pointers the compiler merges the two arms into FLAT loads of a
+          // selected address -- thirteen flat_load instead of four ds_read_b128 / global_load_dwordx4)
+          typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) const volatile u32x4_t lds_u32x4_t;
+          lds_u32x4_t* tp = (lds_u32x4_t*)&s_top[0][0] + (cur & DESC_TOP_SLOT);
+          const u32x4_t t0 = tp[0], t1 = tp[RT_TOP_NODES], t2 = tp[2 * RT_TOP_NODES], t3 = tp[3 * RT_TOP_NODES];
+          q0 = make_uint4(t0.x, t0.y, t0.z, t0.w); q1 = make_uint4(t1.x, t1.y, t1.z, t1.w);
+          q2 = make_uint4(t2.x, t2.y, t2.z, t2.w); q3 = make_uint4(t3.x, t3.y, t3.z, t3.w);
+          if (STATS && A.wave_log) ++wl_no23;
+        } else {
+          const uint4* np = sc.nodes_c + (size_t)ni * CNODE_VEC4;
+          q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+        }
         const uint32_t* ref_node = nullptr;
         if (LDEXP) ref_node = top ? sc.ref_tlas + (size_t)ni * RT_NODE_DWORDS : sc.ref_bvh + (size_t)(ni - sc.n_tlas) * RT_NODE_DWORDS;
         if (STATS) fx.node++;
         Cand c[4];
-        eval_children<EXACT, LDEXP>(np, ref_node, arx, ary, arz, aix, aiy, aiz, hitd, c);
+        eval_children<EXACT, LDEXP>(q0, q1, q2, q3, ref_node, arx, ary, arz, aix, aiy, aiz, hitd, c);
         if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && !STATS && __all((flags & F_ANYHIT) != 0u)) {   // STATS keeps the reference's order, hence its fetch counts
           // occlusion rays of a frame only feed a boolean (is anything hit before the light?): the set
           // of triangles an any-hit traversal can reach does not depend on the visiting order, so the
@@ -785,9 +860,9 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
               const float d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
               if (d < hitd) {
                 hitd = d;
-                CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(5) = __float_as_uint(bz);
-                CTX(6) = CTX(8); CTX(7) = triIdx;
                 flags |= F_FOUND;
+                // (a frame's occlusion ray only feeds a boolean; slots 3-7 keep the pixel's primary hit meanwhile)
+                if (!(JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW))) { CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(6) = CTX(8); CTX(7) = triIdx; }
                 if (flags & F_ANYHIT) { stop = true; break; }
                 // the reference re-descends from the root with the shrunken hit.dist; if any box on the
                 // current path no longer passes `d < hit.dist` it abandons this subtree
@@ -849,9 +924,9 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
               }
               if (d < hitd) {
                 hitd = d;
-                CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(5) = __float_as_uint(bz);
-                CTX(6) = CTX(8); CTX(7) = triIdx;
                 flags |= F_FOUND;
+                // (a frame's occlusion ray only feeds a boolean; slots 3-7 keep the pixel's primary hit meanwhile)
+                if (!(JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW))) { CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(6) = CTX(8); CTX(7) = triIdx; }
                 if (flags & F_ANYHIT) { stop = true; break; }
                 if (!(path_m < hitd)) break;   // abandon rule, as above
               }
@@ -876,35 +951,43 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
     if (cur == DESC_DONE) {
       const bool found = (flags & F_FOUND) != 0u;
       HitRec h; h.dist = RT_LARGE_FLOAT; h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0;
-      if (found) {
-        h.dist = hitd; h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = __uint_as_float(CTX(5));
-        h.blasIdx = CTX(6); h.triIdx = CTX(7);
-      }
       if (JOB == JOB_TRACE) {
+        if (found) {
+          h.dist = hitd; h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;   // rt_traversal.cpp:311-313
+          h.blasIdx = CTX(6); h.triIdx = CTX(7);
+        }
         A.hits[job] = h;
         cur = DESC_IDLE;
-      } else {
+      } else if (!(flags & F_SHADOW)) {
         // deferred shading: finishing a ray costs one store, not a chain of dependent loads
-        uint32_t x, y;
-        pixel_of(job, x, y);
-        const size_t idx = (size_t)x + (size_t)y * A.W;
-        if (!(flags & F_SHADOW)) {
-          A.hits[idx] = h;
-          if (STATS && found) nhit++;
-          if (JOB == JOB_RENDER_SHADOW && found) {
-            // continue this lane with the pixel's occlusion ray
-            float ox, oy, oz, dx, dy, dz, sox, soy, soz, sdx, sdy, sdz, sdist;
-            generate_ray(A.utab[x], A.vtab[y], ox, oy, oz, dx, dy, dz);
-            shadow_ray(p, ox, oy, oz, dx, dy, dz, hitd, sox, soy, soz, sdx, sdy, sdz, sdist);
-            flags = F_SHADOW;
-            start_ray(sox, soy, soz, sdx, sdy, sdz, sdist, true);
-          } else {
-            cur = DESC_IDLE;
-          }
+        if (STATS && found) nhit++;
+        if (JOB == JOB_RENDER_SHADOW && found) {
+          // continue this lane with the pixel's occlusion ray; the record is written when that ray has finished
+          uint32_t x, y;
+          pixel_of(job, x, y);
+          float ox, oy, oz, dx, dy, dz, sox, soy, soz, sdx, sdy, sdz, sdist;
+          generate_ray(A.utab[x], A.vtab[y], ox, oy, oz, dx, dy, dz);
+          shadow_ray(p, ox, oy, oz, dx, dy, dz, hitd, sox, soy, soz, sdx, sdy, sdz, sdist);
+          CTX(5) = __float_as_uint(hitd);
+          flags = F_SHADOW;
+          start_ray(sox, soy, soz, sdx, sdy, sdz, sdist, true);
         } else {
-          if (found) atomicOr(&A.hits[idx].blasIdx, 0x80000000u);   // occluded
+          if (found) {
+            h.dist = hitd; h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;
+            h.blasIdx = CTX(6); h.triIdx = CTX(7);
+          }
+          A.hits[job] = h;   // tile-major: job = tile * 64 + lane
           cur = DESC_IDLE;
         }
+      } else if (EXACT && (flags & F_RESUMED)) {
+        // occlusion ray handed over by the main launch: the record is in memory already, only the result is added
+        if (found) A.hits[job].blasIdx |= 0x80000000u;
+        cur = DESC_IDLE;
+      } else {
+        h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;
+        h.dist = __uint_as_float(CTX(5)); h.blasIdx = CTX(6) | (found ? 0x80000000u : 0u); h.triIdx = CTX(7);   // found = occluded
+        A.hits[job] = h;
+        cur = DESC_IDLE;
       }
     }
   }
@@ -913,8 +996,9 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
   if (STATS && A.wave_log && !EXACT) {
     unsigned s = nrays;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    for (int o = 32; o > 0; o >>= 1) wl_no23 += __shfl_down(wl_no23, o);   // node steps served from the LDS image, all lanes
     if (lane == 0) {
-      unsigned long long* w = A.wave_log + 13ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+      unsigned long long* w = A.wave_log + 13ull * (blockIdx.x * (uint32_t)WG_WAVES + (threadIdx.x >> 6));
       w[0] = t_first; w[1] = wall_clock64(); w[2] = s; w[8] = wl_no23; w[9] = wl_no3; w[10] = wl_tn; w[11] = wl_tl; w[12] = __builtin_readcyclecounter() - wl_tstart;
       w[3] = wl_iter; w[4] = wl_node_x; w[5] = wl_node_l; w[6] = wl_leaf_x; w[7] = wl_leaf_l;
     }
@@ -933,8 +1017,8 @@ __global__ __launch_bounds__(256, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persisten
 // Deferred shading pass: one thread per pixel of rows [y0,y1), x fastest, so hit records are read
 // and pixels written fully coalesced.
 template <bool STATS>
-__global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams p, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
-                                                      const float* __restrict__ utab, const float* __restrict__ vtab,
+__global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams p, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1, uint32_t row_step,
+                                                      uint32_t n_rows, const float* __restrict__ utab, const float* __restrict__ vtab,
                                                       const HitRec* __restrict__ hb, uint32_t* __restrict__ dst,
                                                       HitRec* __restrict__ hits, float* __restrict__ colors,
                                                       unsigned long long* counters, uint32_t* __restrict__ ctl_reset) {
@@ -943,13 +1027,14 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
   if (ctl_reset && blockIdx.x == 0)
     for (uint32_t i = threadIdx.x; i < CTL_DWORDS; i += 256u) ctl_reset[i] = 0u;
   const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  const uint64_t n = (uint64_t)W * (y1 - y0);
+  const uint64_t n = (uint64_t)W * n_rows;   // local rows of the window (its tile rows x 8; rows past y1 are skipped)
   unsigned ntex = 0, npix = 0;
-  if (t < n) {
-    const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
+  const uint32_t x = (uint32_t)(t % W), lr = (uint32_t)(t / W), y = frame_row(lr, y0, row_step);
+  if (t < n && y < y1) {
     const size_t idx = (size_t)x + (size_t)y * W;
-    HitRec h = hb[idx];
-    const bool occ = (h.blasIdx & 0x80000000u) != 0u;
+    HitRec h = hb[hit_index(x, lr, (W + 7u) >> 3)];   // tile-major, 192 contiguous bytes per 8 pixels of a row
+    const uint32_t occ_bit = h.blasIdx & 0x80000000u;
+    const bool occ = occ_bit != 0u;
     h.blasIdx &= 0x7fffffffu;
     const bool found = h.dist != RT_LARGE_FLOAT;
     float ox, oy, oz, dx, dy, dz;
@@ -957,7 +1042,7 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
     float r, g, b;
     shade_eval<STATS>(sc, p, ox, oy, oz, dx, dy, dz, h, found, occ, r, g, b, &ntex);
     dst[idx] = pack_rgb8(r, g, b);
-    if (hits) hits[idx] = h;
+    if (hits) { HitRec o = h; o.blasIdx |= occ_bit; hits[idx] = o; }   // bit 31 of blasIdx: the pixel's occlusion ray was blocked
     if (colors) { colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b; }
     npix = 1;
   }
@@ -1002,11 +1087,11 @@ __global__ __launch_bounds__(256) void rt_shade_bounce_kernel(SceneDev sc, Shade
   if (LEVEL0) {
     const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
     e = (size_t)x + (size_t)y * W;
-    h = hb[e];
+    h = hb[hit_index(x, y - y0, (W + 7u) >> 3)];
     occ = (h.blasIdx & 0x80000000u) != 0u;
+    if (hits_out) hits_out[e] = h;
     h.blasIdx &= 0x7fffffffu;
     generate_ray(utab[x], vtab[y], ox, oy, oz, dx, dy, dz);
-    if (hits_out) hits_out[e] = h;
   } else {
     const float* rp = rays + e * 6;
     ox = rp[0]; oy = rp[1]; oz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5];
@@ -1116,8 +1201,7 @@ __global__ __launch_bounds__(256) void rt_ao_prepare_kernel(SceneDev sc, ShadePa
   bool hit = false;
   if (t < n) {
     const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
-    const size_t e = (size_t)x + (size_t)y * W;
-    HitRec h = hb[e];
+    HitRec h = hb[hit_index(x, y - y0, (W + 7u) >> 3)];
     h.blasIdx &= 0x7fffffffu;
     float ox, oy, oz, dx, dy, dz;
     generate_ray(utab[x], vtab[y], ox, oy, oz, dx, dy, dz);
@@ -1401,6 +1485,77 @@ __global__ void accel_roots_kernel(const uint32_t* __restrict__ tlas, const uint
   }
 }
 
+// Top of the tree for LDS staging: breadth-first from the TLAS root through the instance roots, the first `cap` internal
+// nodes get slots 0..n-1 (so the levels every ray walks come first).  The image holds their compact nodes as four planes of
+// `cap` uint4 with the child descriptors of staged children rewritten to DESC_TOP_FLAG | slot; the *_top roots likewise.
+// The global compact nodes stay untouched: kernels that do not stage (EXACT, ldexp decode) start from the plain roots and
+// never meet a slot descriptor.  One wavefront; a few hundred nodes, once per scene.
+__global__ __launch_bounds__(64) void accel_top_kernel(const uint4* __restrict__ nodes_c, uint32_t tlas_root, const uint32_t* __restrict__ blas_root,
+                                                       uint32_t n_blas, uint32_t cap, uint4* __restrict__ img, uint32_t* __restrict__ out_n,
+                                                       uint32_t* __restrict__ tlas_root_top, uint32_t* __restrict__ blas_root_top) {
+  __shared__ uint32_t q[RT_TOP_MAX];
+  __shared__ uint32_t n_s;
+  const uint32_t lane = threadIdx.x;
+  auto find = [&](uint32_t idx, uint32_t n) -> uint32_t {   // wave-wide search; returns slot or 0xFFFFFFFF
+    uint32_t hit = 0xFFFFFFFFu;
+    for (uint32_t b = 0; b < n; b += 64u) {
+      const unsigned long long m = __ballot(b + lane < n && q[b + lane] == idx);
+      if (m) { hit = b + (uint32_t)__ffsll((long long)m) - 1u; break; }
+    }
+    return hit;
+  };
+  uint32_t n = 0;
+  auto push = [&](uint32_t d) {   // wave-uniform d
+    if (!is_node_desc(d)) return;
+    const uint32_t idx = d & PAYLOAD_MASK;
+    if (n >= cap || find(idx, n) != 0xFFFFFFFFu) return;
+    if (lane == 0) q[n] = idx;
+    ++n;
+    __syncthreads();
+  };
+  if (is_inst_desc(tlas_root)) push(blas_root[tlas_root & PAYLOAD_MASK]); else push(tlas_root);
+  for (uint32_t head = 0; head < n && n < cap; ++head) {
+    const uint4* np = nodes_c + (size_t)q[head] * CNODE_VEC4;
+    const uint4 q2 = np[2], q3 = np[3];
+    const uint32_t d[4] = {q2.z, q2.w, q3.x, q3.y};
+    for (int k = 0; k < 4; ++k) {
+      if (is_inst_desc(d[k])) push(blas_root[d[k] & PAYLOAD_MASK]); else push(d[k]);
+    }
+  }
+  __syncthreads();
+  auto patch = [&](uint32_t d) -> uint32_t {
+    if (!is_node_desc(d)) return d;
+    const uint32_t slot = find(d & PAYLOAD_MASK, n);
+    return slot == 0xFFFFFFFFu ? d : ((d & 0xC0000000u) | DESC_TOP_FLAG | slot);
+  };
+  for (uint32_t sidx = 0; sidx < n; ++sidx) {
+    const uint4* np = nodes_c + (size_t)q[sidx] * CNODE_VEC4;
+    uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    q2.z = patch(q2.z); q2.w = patch(q2.w); q3.x = patch(q3.x); q3.y = patch(q3.y);
+    if (lane == 0) { img[sidx] = q0; img[cap + sidx] = q1; img[2 * (size_t)cap + sidx] = q2; img[3 * (size_t)cap + sidx] = q3; }
+  }
+  for (uint32_t j = 0; j < n_blas; ++j) {
+    const uint32_t v = patch(blas_root[j]);
+    if (lane == 0) blas_root_top[j] = v;
+  }
+  const uint32_t tr = patch(tlas_root);
+  if (lane == 0) { *tlas_root_top = tr; *out_n = n; }
+  (void)n_s;
+}
+
+// shading inputs (closest.cpp:52-77 dereferences them unchecked; here a scene that would read outside its buffers is rejected
+// when the acceleration layout is built): every triangle's texId names a material, and every textured material's texels lie
+// inside the texture buffer with non-zero dimensions (texSample takes `% width`, rtx_shading.h:9-10)
+__global__ void accel_check_shading_kernel(const rt_triex_t* __restrict__ triEx, uint32_t n_tris, const rt_material_t* __restrict__ mat, uint32_t n_mats,
+                                           uint64_t tex_bytes, int have_tex, uint32_t* status) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_tris && triEx[i].texId >= n_mats) atomicOr(status, STATUS_BAD_SCENE);
+  if (i < n_mats && mat[i].diffuse_tex_id >= 0) {
+    const uint64_t w = mat[i].tex_width, h = mat[i].tex_height, off = mat[i].tex_offset;
+    if (!have_tex || w == 0 || h == 0 || (off & 3u) != 0 || off > tex_bytes || w * h > (tex_bytes - off) / 4u) atomicOr(status, STATUS_BAD_SCENE);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host entry points (C ABI, include/vortex_hip.h level 2)
 // ---------------------------------------------------------------------------------------------
@@ -1433,7 +1588,7 @@ static uint32_t* status_word() {
 // grid of a persistent launch: what the device holds at once (occupancy x CUs, queried once per kernel
 // and device), capped by the job count
 template <class K>
-static uint32_t persistent_grid(K kernel, uint64_t jobs) {
+static uint32_t persistent_grid(K kernel, uint64_t jobs, int wg_threads = RT_WG_THREADS) {
   static std::mutex mu;
   static std::map<std::pair<const void*, int>, uint64_t> cache;
   int dev = 0;
@@ -1446,14 +1601,14 @@ static uint32_t persistent_grid(K kernel, uint64_t jobs) {
   }
   if (!g) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, wg_threads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     g = (uint64_t)per_cu * (uint64_t)cus;
     if (getenv("VXRT_DEBUG")) fprintf(stderr, "[vxrt] persistent grid: %d blocks/CU x %d CUs\n", per_cu, cus);
     std::lock_guard<std::mutex> lk(mu);
     cache[{(const void*)kernel, dev}] = g;
   }
-  const uint64_t need = (jobs + 255) / 256;
+  const uint64_t need = (jobs + (uint64_t)wg_threads - 1) / (uint64_t)wg_threads;
   if (g > need) g = need;
   return (uint32_t)(g ? g : 1);
 }
@@ -1486,13 +1641,14 @@ struct FrameCtx {
   float* ao_rays = nullptr; float* ao_tmax = nullptr; HitRec* ao_hits = nullptr; uint64_t ao_cap = 0, ao_ray_cap = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr;
-  bool busy = false;
+  bool busy = false, inited = false;
 };
 
 struct vxrt_accel {
   SceneDev dev{};
   vxrt_scene_t ref{};
   void* nodes_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr;
+  void* top_img = nullptr; uint32_t* top_roots = nullptr;   // LDS-staged top of the tree: image; [0] n, [1] TLAS root, [2..] BLAS roots
   FrameCtx ctx[MAX_FRAMES_IN_FLIGHT];
   uint32_t n_ctx = 1, next_ctx = 0;
   float* uvtab = nullptr;      // camera tables: u[W] then v[H]
@@ -1500,7 +1656,7 @@ struct vxrt_accel {
   // camera pixels whose primary ray has a zero direction component (u == 0 or v == 0): listed on the
   // host per (W, H, y0, y1) and traced by an EXACT launch on a side stream, concurrently with the main one
   uint32_t* apriori = nullptr; // [0] count, [1..] job ids
-  uint32_t ap_count = 0, ap_key[4] = {0, 0, 0, 0};
+  uint32_t ap_count = 0, ap_key[5] = {0, 0, 0, 0, 0};
   uint64_t ap_cap = 0;
   float max_reflectivity = 0.0f;   // over the instance records: > 0 enables the mirror-bounce path
   int device = 0;
@@ -1510,6 +1666,7 @@ static void accel_free(vxrt_accel* a) {
   if (!a) return;
   (void)hipDeviceSynchronize();
   (void)hipFree(a->nodes_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
+  (void)hipFree(a->top_img); (void)hipFree(a->top_roots);
   (void)hipFree(a->uvtab); (void)hipFree(a->apriori);
   for (FrameCtx& c : a->ctx) {
     (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount); (void)hipFree(c.tile_cost); (void)hipFree(c.tile_order);
@@ -1529,13 +1686,18 @@ static void accel_free(vxrt_accel* a) {
 // next frame context, ordered on `s` behind its previous use
 static FrameCtx* acquire_ctx(vxrt_accel* a, hipStream_t s) {
   FrameCtx& c = a->ctx[a->next_ctx++ % a->n_ctx];
-  if (!c.side) {
-    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.ev_side, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipMalloc((void**)&c.ctl, CTL_DWORDS * sizeof(uint32_t)) != hipSuccess) return nullptr;
+  if (!c.inited) {   // (a failed attempt is completed by the next one: every piece is created only if still missing)
+    // the side stream carries the small EXACT launch over the a-priori list: highest priority, so that its few workgroups are
+    // placed before the main launch fills every CU (an EXACT workgroup cannot co-reside with a full persistent grid: LDS)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (!c.side && hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
+    if (!c.ev_in && hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (!c.ev_side && hipEventCreateWithFlags(&c.ev_side, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (!c.ev_done && hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (!c.ctl && hipMalloc((void**)&c.ctl, CTL_DWORDS * sizeof(uint32_t)) != hipSuccess) return nullptr;
     if (hipMemset(c.ctl, 0, CTL_DWORDS * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    c.inited = true;
   }
   if (c.busy && hipStreamWaitEvent(s, c.ev_done, 0) != hipSuccess) return nullptr;
   if (c.ctl_dirty) {
@@ -1589,7 +1751,12 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   uint32_t* d_ranges = nullptr;
   uint32_t* d_status = nullptr;
   uint32_t* d_troot = nullptr;
+  constexpr uint32_t TOP_CAP = RT_TOP_NODES;
+  // slot descriptors use bit 29 of the payload: only scenes whose compact index space stays below it are staged
+  const bool stage_top = TOP_CAP > 0 && (uint64_t)s->n_tlas_nodes + s->n_bvh_nodes < DESC_TOP_FLAG;
   bool ok = hipMalloc(&a->nodes_c, ((size_t)s->n_tlas_nodes + s->n_bvh_nodes) * CNODE_VEC4 * 16) == hipSuccess &&
+            (!stage_top || (hipMalloc(&a->top_img, (size_t)TOP_CAP * CNODE_VEC4 * 16) == hipSuccess &&
+                            hipMalloc((void**)&a->top_roots, ((size_t)s->n_blas + 2) * sizeof(uint32_t)) == hipSuccess)) &&
             hipMalloc(&a->tri_w, (size_t)s->n_tris * WTRI_FLOATS * 4) == hipSuccess &&
             hipMalloc(&a->blas_root, (size_t)s->n_blas * sizeof(uint32_t)) == hipSuccess &&
             hipMalloc((void**)&d_ranges, bases.size() * 8) == hipSuccess &&
@@ -1609,9 +1776,24 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
     hipLaunchKernelGGL(accel_tris_kernel, dim3((s->n_tris + 255) / 256), dim3(256), 0, st, (const float*)s->tri, s->n_tris, (float4*)a->tri_w);
     hipLaunchKernelGGL(accel_roots_kernel, dim3((s->n_blas + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->tlas, (const uint32_t*)s->bvh,
                        (const uint32_t*)s->blas, s->n_tlas_nodes, s->n_bvh_nodes, s->n_blas, s->n_tris, d_troot, (uint32_t*)a->blas_root, d_status);
+    if (s->triEx && s->mat && s->n_mats) {
+      const uint32_t nchk = std::max(s->n_tris, s->n_mats);
+      hipLaunchKernelGGL(accel_check_shading_kernel, dim3((nchk + 255) / 256), dim3(256), 0, st, (const rt_triex_t*)s->triEx, s->n_tris,
+                         (const rt_material_t*)s->mat, s->n_mats, (uint64_t)s->tex_bytes, s->tex ? 1 : 0, d_status);
+    }
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
          hipMemcpy(&hstatus, d_status, 4, hipMemcpyDeviceToHost) == hipSuccess &&
          hipMemcpy(&troot, d_troot, 4, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  uint32_t n_top = 0, troot_top = troot;
+  if (ok && stage_top && (hstatus & (STATUS_BAD_SCENE | STATUS_FMA_DECODE_DIFFERS)) == 0) {
+    ok = hipMemsetAsync(a->top_img, 0, (size_t)TOP_CAP * CNODE_VEC4 * 16, st) == hipSuccess;
+    hipLaunchKernelGGL(accel_top_kernel, dim3(1), dim3(64), 0, st, (const uint4*)a->nodes_c, troot, (const uint32_t*)a->blas_root, s->n_blas, TOP_CAP,
+                       (uint4*)a->top_img, a->top_roots, a->top_roots + 1, a->top_roots + 2);
+    uint32_t hdr[2] = {0, DESC_DONE};
+    ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+         hipMemcpy(hdr, a->top_roots, sizeof hdr, hipMemcpyDeviceToHost) == hipSuccess;
+    n_top = hdr[0]; troot_top = hdr[1];
   }
   (void)hipFree(d_ranges); (void)hipFree(d_status); (void)hipFree(d_troot);
   if (!ok || (hstatus & STATUS_BAD_SCENE) != 0) { accel_free(a); return -1; }   // malformed tree: rejected before any traversal
@@ -1621,6 +1803,9 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   a->dev.ref_bvh = (const uint32_t*)s->bvh;
   a->dev.blas = (const uint32_t*)s->blas; a->dev.triEx = (const rt_triex_t*)s->triEx;
   a->dev.mat = (const rt_material_t*)s->mat; a->dev.tex = (const uint8_t*)s->tex;
+  a->dev.top_img = (const uint4*)a->top_img; a->dev.n_top = n_top; a->dev.tlas_root_top = troot_top;
+  a->dev.blas_root_top = n_top ? a->top_roots + 2 : (const uint32_t*)a->blas_root;
+  if (getenv("VXRT_DEBUG")) fprintf(stderr, "[vxrt] accel: %u top-of-tree nodes staged for LDS (cap %u)\n", n_top, TOP_CAP);
   *out = a;
   return 0;
 }
@@ -1680,7 +1865,7 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   X.total_dev = nullptr;   // the EXACT launch takes its count from the deferral list
   ShadeParams p{};
 #define LAUNCH_T(ST, LD) do { \
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, false>, n)), dim3(256), 0, s, a->dev, p, A); \
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, false>, n)), dim3(RT_WG_THREADS), 0, s, a->dev, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X); } while (0)
   if (stats_counters) { if (a->dev.exact_decode) LAUNCH_T(true, true); else LAUNCH_T(true, false); }
   else                { if (a->dev.exact_decode) LAUNCH_T(false, true); else LAUNCH_T(false, false); }
@@ -1825,9 +2010,10 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
 static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits, float* colors,
                          unsigned long long* counters, bool stats, void* stream, unsigned long long* wave_log = nullptr,
-                         const vxrt_ao_params_t* ao = nullptr, uint32_t* unoccluded = nullptr) {
+                         const vxrt_ao_params_t* ao = nullptr, uint32_t* unoccluded = nullptr, uint32_t stride = 1) {
   if (!a || !params || !dst) return -1;
   if (ao && (stats || shadow)) return -1;
+  if (stride == 0 || (stride > 1 && ((y0 & 7u) != 0 || ao))) return -1;   // interleaved tile rows: tile-aligned start, plain frames only
   if (!a->ref.triEx || !a->ref.mat || a->ref.n_mats == 0) return -1;  // shading needs them (closest.cpp:52-55)
   if (width == 0 || height == 0 || y0 > y1 || y1 > height) return -1;
   if (stats && !counters) return -1;
@@ -1840,7 +2026,9 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     p.lpos[i] = params->light_pos[i]; p.bg[i] = params->background[i];
   }
   p.max_depth = params->max_depth;
-  const uint32_t tiles_x = (width + 7) / 8, tiles_y = (y1 - y0 + 7) / 8;
+  // tile rows of the window: every stride-th tile row of [y0, y1) starting with the one at y0
+  const uint32_t tiles_x = (width + 7) / 8, tiles_y = ((y1 - y0 + 7) / 8 + stride - 1) / stride;
+  const uint32_t row_step = 8u * stride;
   const uint64_t n_tiles64 = (uint64_t)tiles_x * tiles_y;
   if (n_tiles64 > 0x1ffffffull) return -1;
   const uint32_t n_tiles = (uint32_t)n_tiles64;
@@ -1850,7 +2038,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   FrameCtx* c = acquire_ctx(a, s);
   if (!c) return -1;
   // hit-record buffer between the two passes (one per frame in flight)
-  const uint64_t pixels = (uint64_t)width * height;
+  const uint64_t pixels = (uint64_t)tiles_x * ((height + 7) / 8 + 1) * 64u;   // tile-major records of any row window of the frame
   if (c->hitbuf_pixels < pixels) {
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     (void)hipFree(c->hitbuf);
@@ -1871,7 +2059,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     a->uv_w = width; a->uv_h = height;
   }
   PersistArgs A{};
-  A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.total = n_tiles * 64u;
+  A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.row_step = row_step; A.total = n_tiles * 64u;
   A.hits = (HitRec*)c->hitbuf; A.counters = counters; A.status = st; A.wave_log = wave_log;
   A.utab = a->uvtab; A.vtab = a->uvtab + width;
   if (ensure_defer(c, A.total, s) != 0) return -1;
@@ -1893,17 +2081,17 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
       if (hipMalloc((void**)&c->tile_cost, (size_t)n_tiles * 4) != hipSuccess || hipMalloc((void**)&c->tile_order, (size_t)n_tiles * 4) != hipSuccess) return -1;
       c->lpt_cap = n_tiles;
     }
-    const uint32_t key[6] = {width, height, y0, y1, (uint32_t)shadow, ao ? 1u : 0u};
+    const uint32_t key[6] = {width, height, y0, y1, (uint32_t)shadow | (stride << 1), ao ? 1u : 0u};
     if (memcmp(key, c->lpt_key, sizeof key) != 0) { c->lpt_valid = false; memcpy(c->lpt_key, key, sizeof key); }
     A.tile_cost = c->tile_cost;
     A.tile_order = c->lpt_valid ? c->tile_order : nullptr;
   }
   // a-priori EXACT list (camera rays with u == 0 or v == 0), rebuilt only when the window changes
-  if (a->ap_key[0] != width || a->ap_key[1] != height || a->ap_key[2] != y0 || a->ap_key[3] != y1 || !a->apriori) {
+  if (a->ap_key[0] != width || a->ap_key[1] != height || a->ap_key[2] != y0 || a->ap_key[3] != y1 || a->ap_key[4] != stride || !a->apriori) {
     std::vector<uint32_t> list(1, 0u);
     for (uint32_t t = 0; t < n_tiles; ++t)
       for (uint32_t l = 0; l < 64; ++l) {
-        const uint32_t x = (t % tiles_x) * 8u + (l & 7u), y = y0 + (t / tiles_x) * 8u + (l >> 3);
+        const uint32_t x = (t % tiles_x) * 8u + (l & 7u), y = y0 + (t / tiles_x) * row_step + (l >> 3);
         if (x >= width || y >= y1) continue;
         const float u = (float)(((double)x * 2.0 - (double)width) / (double)height);
         const float v = (float)(((double)y * 2.0 - (double)height) / (double)height);
@@ -1919,7 +2107,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     }
     if (hipMemcpy(a->apriori, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
     a->ap_count = list[0];
-    a->ap_key[0] = width; a->ap_key[1] = height; a->ap_key[2] = y0; a->ap_key[3] = y1;
+    a->ap_key[0] = width; a->ap_key[1] = height; a->ap_key[2] = y0; a->ap_key[3] = y1; a->ap_key[4] = stride;
   }
   // EXACT launch over the a-priori list on the side stream (ordered after everything already queued on
   // `s`: it writes hit records the previous frame's shading pass may still be reading), concurrent with
@@ -1935,8 +2123,8 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = a->ap_count;
   }
 #define LAUNCH_P(J, ST, LD) do { \
-    if (side_launch) hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, side, sc, p, X0); \
-    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<J, ST, LD, false>, A.total)), block, 0, s, sc, p, A); \
+    if (side_launch) hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(std::min<uint32_t>(EXACT_GRID, (a->ap_count + 255u) / 256u)), block, 0, side, sc, p, X0); \
+    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<J, ST, LD, false>, A.total)), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, s, sc, p, X); } while (0)
 #define LAUNCH_PD(J, ST) do { if (sc.exact_decode) LAUNCH_P(J, ST, true); else LAUNCH_P(J, ST, false); } while (0)
   if (stats) { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, true); else LAUNCH_PD(JOB_RENDER, true); }
@@ -1956,14 +2144,14 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   }
   if (p.max_depth > 1 && a->max_reflectivity > 0.0f) {
     // reflective instances: the shading pass becomes the level-0 step of the mirror-bounce wavefront
-    if (stats) return -1;   // the counting build prices the single-level frame only
+    if (stats || stride > 1) return -1;   // the counting build prices the single-level frame only
     if (render_bounce_tail(a, c, p, width, y0, y1, shadow, A.utab, A.vtab, dst, (HitRec*)hits, colors, counters, s) != 0) return -1;
     return release_ctx(c, s);
   }
-  const uint64_t npx = (uint64_t)width * (y1 - y0);
+  const uint64_t npx = (uint64_t)width * tiles_y * 8u;
   dim3 sgrid((uint32_t)((npx + 255) / 256));
-  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl);
-  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl);
+  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl);
+  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl);
   if (hipGetLastError() != hipSuccess) return -1;
   c->ctl_dirty = false;
   return release_ctx(c, s);
@@ -1973,6 +2161,17 @@ int vxrt_render(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y
                 const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits,
                 float* colors, unsigned long long* rays_traced, void* stream) {
   return render_common(accel, width, height, y0, y1, params, shadow, dst, hits, colors, rays_traced, false, stream);
+}
+
+// Tile rows phase, phase + stride, phase + 2 stride, ... of the frame (8 rows each): what rank `phase` of `stride` ranks renders when one
+// frame is split over GPUs (bench.py --gpus N; DCR 0x7F3 through the vx_* boundary).  Interleaving balances the ranks -- the
+// cost of a tile varies 4x across the frame, mostly with height -- where contiguous bands do not.
+int vxrt_render_interleaved(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t phase, uint32_t stride,
+                            const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits,
+                            float* colors, unsigned long long* rays_traced, void* stream) {
+  if (stride == 0 || phase >= stride) return -1;
+  if ((uint64_t)phase * 8u >= height) return 0;   // more ranks than tile rows: nothing for this one
+  return render_common(accel, width, height, phase * 8u, height, params, shadow, dst, hits, colors, rays_traced, false, stream, nullptr, nullptr, nullptr, stride);
 }
 
 // Same launches as vxrt_render with the fetch counters compiled in (slower; never the timed path).

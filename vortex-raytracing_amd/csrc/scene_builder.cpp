@@ -717,8 +717,10 @@ Mesh make_cornell() {
   return m;
 }
 
-// config 2: "bunny-class" blob: subdivided icosahedron with radial harmonics
-Mesh make_blob(uint32_t subdiv, uint32_t seed) {
+// config 2: "bunny-class" blob: subdivided icosahedron with radial harmonics.  cx: distance of its centre along the fixed
+// camera's axis (kernel.cpp:28-39: eye (0,100,0) looking along +x, 45 degrees to the top and bottom frame edges); 220 leaves
+// it small in the frame (14 % of a square frame), 135 ("bunny") makes it fill the view as BASELINE config 2 means it
+Mesh make_blob(uint32_t subdiv, uint32_t seed, float cx = 220.0f) {
   Mesh m;
   m.mats = {make_mat(0.8f, 0.7f, 0.6f, 0)};
   add_texture(m, 256, 256, 2, seed);
@@ -753,7 +755,7 @@ Mesh make_blob(uint32_t subdiv, uint32_t seed) {
     return 80.0f * (1.0f + 0.15f * std::sin(5 * d.x + ph[0]) * std::sin(4 * d.y + ph[1]) + 0.10f * std::sin(9 * d.z + ph[2]) * std::sin(7 * d.x + ph[3]) +
                     0.05f * std::sin(17 * d.y + ph[4]) * std::sin(13 * d.z + ph[5]));
   };
-  const V3 c{220, 100, 0};
+  const V3 c{cx, 100, 0};
   std::vector<V3> p(v.size());
   for (size_t i = 0; i < v.size(); ++i) p[i] = c + v[i] * radius(v[i]);
   std::vector<V3> nrm(v.size(), V3{0, 0, 0});
@@ -815,11 +817,12 @@ Mesh make_atrium(uint32_t level, uint32_t seed) {
 }
 
 // config 5: hairball - `strands` splines of `segs` thin triangles pairs inside a sphere
-Mesh make_hairball(uint32_t strands, uint32_t segs, uint32_t seed) {
+// cx: distance of the centre from the camera; 260 = small in the frame, 150 ("hairball_fill") = the ball spans the 16:9 view
+Mesh make_hairball(uint32_t strands, uint32_t segs, uint32_t seed, float cx = 260.0f) {
   Mesh m;
   m.mats = {make_mat(0.85f, 0.75f, 0.55f, -1)};
   Rng rng(seed);
-  const V3 c{260, 100, 0};
+  const V3 c{cx, 100, 0};
   const float R = 120.0f;
   m.tri.reserve((size_t)strands * segs * 2);
   m.triEx.reserve((size_t)strands * segs * 2);
@@ -1086,7 +1089,8 @@ bool load_obj(const char* path, Mesh& m) {
 extern "C" {
 
 // name: "cornell" | "blob" (a = icosphere subdivisions) | "atrium" (a = level, 8 -> 1,048,576 tris)
-//       | "hairball" (a = strands, b = segments per strand)
+//       | "hairball" (a = strands, b = segments per strand) | "bunny" / "hairball_fill": the same two objects placed so that
+//       they fill the fixed camera's view (BASELINE configs 2 and 5 mean a framed object, not one in the distance)
 static void read_knobs() {
   if (const char* e = std::getenv("VXS_BINS")) { int v = std::atoi(e); if (v >= 2 && v <= kMaxBins) kBins = v; }
   if (const char* e = std::getenv("VXS_WIDEN")) kWiden = std::atoi(e);
@@ -1116,6 +1120,8 @@ void* vxs_scene_create_procedural(const char* name, uint32_t a, uint32_t b, uint
   else if (n == "blob") meshes[0] = make_blob(a, seed);
   else if (n == "atrium") meshes[0] = make_atrium(a, seed);
   else if (n == "hairball") meshes[0] = make_hairball(a, b, seed);
+  else if (n == "bunny") meshes[0] = make_blob(a, seed, 135.0f);                 // the blob framed to fill the view
+  else if (n == "hairball_fill") meshes[0] = make_hairball(a, b, seed, 150.0f);  // the hairball framed to fill the view
   else return nullptr;
   return build_scene(meshes);
 }
@@ -1194,6 +1200,8 @@ void* vxs_rc_scene_create_procedural(const char* name, uint32_t a, uint32_t b, u
   else if (n == "blob") m0 = make_blob(a, seed);
   else if (n == "atrium") m0 = make_atrium(a, seed);
   else if (n == "hairball") m0 = make_hairball(a, b, seed);
+  else if (n == "bunny") m0 = make_blob(a, seed, 135.0f);
+  else if (n == "hairball_fill") m0 = make_hairball(a, b, seed, 150.0f);
   else return nullptr;
   if (copies == 0) copies = 1;
   Box mb;

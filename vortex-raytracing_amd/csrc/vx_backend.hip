@@ -79,7 +79,7 @@ struct vx_device {
   // acceleration layout of the scene last started, rebuilt only when one of the four traversal
   // buffers was re-uploaded or re-pointed (key = device pointers + upload versions)
   vxrt_accel_t* accel = nullptr;
-  uint64_t accel_key[12] = {0};
+  uint64_t accel_key[14] = {0};
 
   int init() {
     const char* e = std::getenv("VORTEX_HIP_DEVICE");
@@ -299,7 +299,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   // shader binding table (tracer.cpp:244-250): [0]=miss [1]=closest [3]=anyhit
   {
     Alloc* sb = find(ka.sbt_addr, 32);
-    if (!sb || sb->shadow.empty()) { VXLOG("start: sbt_addr does not name a buffer"); return -1; }
+    if (!sb || sb->shadow.size() < (ka.sbt_addr - sb->va) + 32) { VXLOG("start: sbt_addr does not name a buffer of 4 entries"); return -1; }
     uint64_t sbt[4];
     std::memcpy(sbt, sb->shadow.data() + (ka.sbt_addr - sb->va), sizeof sbt);
     if (tag_of(sbt[0]) != "raytracing.miss" || tag_of(sbt[1]) != "raytracing.closest" || tag_of(sbt[3]) != "raytracing.anyhit") {
@@ -351,16 +351,19 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
     sp.light_pos[i] = ka.light_pos[i]; sp.background[i] = ka.background_color[i];
   }
   sp.max_depth = ka.max_depth;
-  uint32_t y0 = 0, y1 = 0, shadow = 0;
+  uint32_t y0 = 0, y1 = 0, shadow = 0, row_stride = 0;
   dcr(VX_DCR_HIP_ROW_BEGIN, &y0);
   dcr(VX_DCR_HIP_ROW_END, &y1);
   dcr(VX_DCR_HIP_SHADOW_RAYS, &shadow);
+  dcr(VX_DCR_HIP_ROW_STRIDE, &row_stride);
   if (y1 == 0 || y1 > ka.dst_height) y1 = ka.dst_height;
   if (y0 > y1) y0 = y1;
+  if (row_stride > 1 && ((y0 & 7u) != 0 || y0 / 8u >= row_stride)) { VXLOG("start: DCR 0x7F3 (tile-row stride) needs ROW_BEGIN = 8 * phase with phase < stride"); return -1; }
 
-  const uint64_t key[12] = {(uint64_t)sc.tlas, r_tlas.a->version, (uint64_t)sc.blas, r_blas.a->version, (uint64_t)sc.bvh, r_bvh.a->version,
+  // (triEx / mat versions: the build also validates the indices shading follows, so a re-upload of those rebuilds too)
+  const uint64_t key[14] = {(uint64_t)sc.tlas, r_tlas.a->version, (uint64_t)sc.blas, r_blas.a->version, (uint64_t)sc.bvh, r_bvh.a->version,
                             (uint64_t)sc.tri, r_tri.a->version, (uint64_t)sc.triEx, (uint64_t)sc.mat, (uint64_t)sc.tex,
-                            ((uint64_t)sc.n_bvh_nodes << 32) | sc.n_tris};
+                            ((uint64_t)sc.n_bvh_nodes << 32) | sc.n_tris, r_triex.a->version, r_mat.a->version ^ (sc.tex_bytes << 20)};
   if (!accel || std::memcmp(key, accel_key, sizeof key) != 0) {
     if (accel) { (void)vxrt_accel_destroy(accel); accel = nullptr; }
     ++n_accel_builds;
@@ -370,8 +373,9 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
 
   if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
   if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
-  int rc = vxrt_render(accel, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow,
-                       (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, nullptr, d_rays, stream);
+  uint32_t* dstp = (uint32_t*)((char*)r_dst.a->dptr + r_dst.off);
+  int rc = row_stride > 1 ? vxrt_render_interleaved(accel, ka.dst_width, ka.dst_height, y0 / 8u, row_stride, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream)
+                          : vxrt_render(accel, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream);
   if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
   if (rc != 0) { VXLOG("start: launch rejected (shape check)"); return -1; }
   if (enqueue_readback() != 0) return -1;

@@ -91,6 +91,16 @@ def render(accel, width, height, y0, y1, params, dst_ptr, shadow=0, hits_ptr=Non
                              colors_ptr, rays_ptr, stream), "vxrt_render")
 
 
+def render_interleaved(accel, width, height, phase, stride, params, dst_ptr, shadow=0, hits_ptr=None, colors_ptr=None, rays_ptr=None, stream=None):
+    """vxrt_render_interleaved: the tile rows phase, phase + stride, ... of the frame (one rank's share of a frame split over GPUs)."""
+    L = _lib()
+    L.vxrt_render_interleaved.restype = C.c_int
+    L.vxrt_render_interleaved.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ShadeParams), C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    check(L.vxrt_render_interleaved(accel, width, height, int(phase), int(stride), C.byref(params), int(shadow), dst_ptr, hits_ptr,
+                                    colors_ptr, rays_ptr, stream), "vxrt_render_interleaved")
+
+
 def trace_stats(accel, rays_ptr, n, hits_ptr, mode=0, tmax_ptr=None, stream=None):
     """vxrt_trace_stats: counting build of the ray-buffer traversal; returns counts and SURVEY s8d bytes per ray
     (24 B ray read + 52 B per node / instance record + 36 B per triangle + 24 B hit record written)."""

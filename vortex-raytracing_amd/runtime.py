@@ -10,7 +10,7 @@ from . import LIB_DIR, lib_path
 VX_MEM_READ, VX_MEM_WRITE, VX_MEM_READ_WRITE = 1, 2, 3
 VX_MAX_TIMEOUT = 24 * 60 * 60 * 1000
 VX_DCR_BASE_RTX_TLAS_PTR, VX_DCR_BASE_RTX_BLAS_PTR, VX_DCR_BASE_RTX_BVH_PTR, VX_DCR_BASE_RTX_TRI_PTR = 6, 7, 8, 9
-VX_DCR_HIP_ROW_BEGIN, VX_DCR_HIP_ROW_END, VX_DCR_HIP_SHADOW_RAYS = 0x7F0, 0x7F1, 0x7F2
+VX_DCR_HIP_ROW_BEGIN, VX_DCR_HIP_ROW_END, VX_DCR_HIP_SHADOW_RAYS, VX_DCR_HIP_ROW_STRIDE = 0x7F0, 0x7F1, 0x7F2, 0x7F3
 VX_CAPS_NUM_THREADS, VX_CAPS_NUM_WARPS, VX_CAPS_NUM_CORES = 1, 2, 3
 VX_CSR_MCYCLE, VX_CSR_MINSTRET = 0xB00, 0xB02
 

@@ -1,6 +1,8 @@
-"""Framebuffer sharding across GPUs: the scene is replicated, rows are split into
-contiguous bands aligned to the 8-row tile of the reference grid (kernel.cpp:128-133), each rank
-renders its band with no data-path collective, and one gather assembles the image on rank 0."""
+"""Framebuffer sharding across GPUs.  The scene is replicated; ONE frame is split by 8-row tile rows of the
+reference grid (kernel.cpp:128-133): rank r of N renders the tile rows r, r + N, r + 2N, ... (vxrt_render_interleaved / DCR
+0x7F3), with no data-path collective, and one gather assembles the image on rank 0.  Interleaving is what balances the ranks --
+the cost of a tile varies 4x over a frame, mostly with image height, so contiguous bands (row_bands, kept for callers that
+want them) finish at different times.  Strong scaling: the frame, and so the total work, is fixed as N grows."""
 import numpy as np
 
 TILE = 8
@@ -23,10 +25,73 @@ def max_band_rows(height, world):
     return max(y1 - y0 for y0, y1 in row_bands(height, world))
 
 
+def interleaved_tile_rows(height, rank, world):
+    """Tile rows of rank `rank`: rank, rank + world, ... below ceil(height / 8)."""
+    return list(range(rank, (height + TILE - 1) // TILE, world))
+
+
+def interleaved_rows(height, rank, world):
+    """Frame rows (numpy int array) rank `rank` renders."""
+    rows = [np.arange(t * TILE, min((t + 1) * TILE, height)) for t in interleaved_tile_rows(height, rank, world)]
+    return np.concatenate(rows) if rows else np.zeros(0, np.int64)
+
+
+def padded_share_rows(height, world):
+    """Rows of the equal-size buffer every rank contributes to the gather: ceil(tile rows / world) * 8."""
+    tiles = (height + TILE - 1) // TILE
+    return ((tiles + world - 1) // world) * TILE
+
+
+def extract_interleaved(frame, height, rank, world):
+    """The rows of rank `rank` out of its full-size frame buffer (torch tensor [height, width]) as one contiguous
+    [padded_share_rows, width] tensor (rows past the rank's share are zero)."""
+    import torch
+    width = frame.shape[1]
+    tiles = (height + TILE - 1) // TILE
+    per = (tiles + world - 1) // world
+    out = torch.zeros((per * TILE, width), dtype=frame.dtype, device=frame.device)
+    if height % TILE == 0 and tiles % world == 0:
+        # frame viewed as [per, world, 8, width]: this rank's share is one strided slice -> a single copy kernel
+        out.view(per, TILE, width).copy_(frame.view(per, world, TILE, width)[:, rank])
+        return out
+    for k, t in enumerate(interleaved_tile_rows(height, rank, world)):
+        y0, y1 = t * TILE, min((t + 1) * TILE, height)
+        out[k * TILE: k * TILE + (y1 - y0)] = frame[y0:y1]
+    return out
+
+
+def assemble_interleaved(parts, height, width, world):
+    """Full [height, width] frame from the `world` padded shares (list of [padded_share_rows, width] tensors, rank order)."""
+    import torch
+    tiles = (height + TILE - 1) // TILE
+    per = (tiles + world - 1) // world
+    if height % TILE == 0 and tiles % world == 0:
+        stack = torch.stack([p.view(per, TILE, width) for p in parts], dim=1)     # [per, world, 8, width]
+        return stack.reshape(height, width)
+    frame = torch.empty((height, width), dtype=parts[0].dtype, device=parts[0].device)
+    for r in range(world):
+        for k, t in enumerate(interleaved_tile_rows(height, r, world)):
+            y0, y1 = t * TILE, min((t + 1) * TILE, height)
+            frame[y0:y1] = parts[r][k * TILE: k * TILE + (y1 - y0)]
+    return frame
+
+
+def gather_interleaved(share, height, width, rank, world, group=None):
+    """share: this rank's padded share (extract_interleaved).  Returns the full frame on rank 0 (None elsewhere).  One
+    collective: gather of equal-size shares (RCCL over xGMI with backend 'nccl', gloo on CPU tensors)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return assemble_interleaved([share], height, width, 1)
+    out = [torch.empty_like(share) for _ in range(world)] if rank == 0 else None
+    dist.gather(share, out, dst=0, group=group)
+    if rank != 0:
+        return None
+    return assemble_interleaved(out, height, width, world)
+
+
 def gather_frame(band, height, width, rank, world, group=None):
-    """band: torch int32 tensor [rows_of_this_rank, width] on this rank's device.  Returns the full
-    [height, width] frame on rank 0 (None elsewhere).  One collective: gather of equal-size padded
-    bands (RCCL over xGMI with backend 'nccl', gloo on CPU)."""
+    """Contiguous-band variant: band = torch tensor [rows_of_this_rank, width] (row_bands).  Returns the full frame on rank 0."""
     import torch
     import torch.distributed as dist
     if world == 1:
