@@ -1,21 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the ray-tracing hot path on MI355X.
 
-Metric (BASELINE.json): Mrays/s (primary + shadow) at 1920x1080 on the 1M-triangle "Sponza-class"
-BVH.  A step = one frame of the RTU test on that scene: camera ray -> closest hit -> Lambert shade
-with one occlusion ray toward the light per hit -> RGB8, i.e. one vxrt_render call through the C ABI
-(persistent traversal launch + EXACT launches + shading pass) on this rank's GPU, scene already resident in
-HBM.  Frames are issued round robin on --frames-in-flight streams (default 4) so that the draining tail of
-one frame's persistent launch overlaps the next frame's; --frames-in-flight 1 gives strictly serial frames.
+Metric (BASELINE.json): Mrays/s (primary + shadow) at 1920x1080 on the 1M-triangle "Sponza-class" BVH.  A step = one frame of
+the RTU test on that scene: camera ray -> closest hit -> Lambert shade with one occlusion ray toward the light per hit -> RGB8,
+i.e. one vxrt_render call through the C ABI (persistent traversal launch + EXACT launches + shading pass), scene already
+resident in HBM.  Frames are issued round robin on --frames-in-flight streams (default 4) so that the draining tail of one
+frame's persistent launch overlaps the next frame's; --frames-in-flight 1 gives strictly serial frames.
 
-Multi-GPU (one process per GPU, torch.distributed over RCCL): the reference's own per-pixel
-`for s < samples_per_pixel` loop (kernel.cpp:67-80) is the data-parallel axis -- rank r traces
-sample r of every pixel (weak scaling: one full frame of rays per GPU and step, no data-path
-collective), then ONE gather over xGMI assembles the per-sample frames on rank 0 (north_star:
-"RCCL gather only for final image assembly").  `--shard rows` instead splits ONE frame into
-tile-aligned row bands (strong scaling).  value = rays traced by all ranks / max-over-ranks time.
+Multi-GPU (one process per GPU, torch.distributed over RCCL): ONE frame is split by 8-row tile rows of the reference grid
+(kernel.cpp:128-133) -- rank r renders the tile rows r, r + N, r + 2N, ... (vxrt_render_interleaved; interleaving balances the
+ranks, the cost of a tile varies 4x over the frame) with no data-path collective, and ONE gather over xGMI assembles the image
+on rank 0 on its own stream (north_star: "RCCL gather only for final image assembly").  STRONG scaling: the frame, and so the
+total work, is fixed as N grows; value = rays of the whole frame / max-over-ranks time.  `--shard rows` uses contiguous bands.
 
-Prints one JSON line (driver contract) with `roofline` and `cpu_baseline` objects.
+Prints one JSON line (driver contract) with `roofline` and `cpu_baseline` objects.  The roofline is the VALU roof: this
+traversal is cache-resident pointer chasing whose binding resource is vector-ALU issue, priced with the
+per-opcode SIMD cycles measured by tools/calibrate_valu.py; the algorithmic-bytes figure of SURVEY s8d is reported against the
+HBM and L2 peaks next to it, with the measured HBM traffic.
 """
 import argparse
 import importlib
@@ -28,6 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+L2_PEAK_GBS = 34500.0   # aggregate L2 (same guide): the level that serves this cache-resident scene
+SIMDS = 1024            # 256 CUs x 4
+CLOCK_GHZ = 2.4         # nominal shader clock; the calibration loops held 2.2-2.4 GHz under load
 
 
 def parse():
@@ -38,25 +42,28 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--level", type=int, default=8, help="atrium tessellation level; 8 -> 1,048,576 triangles")
-    ap.add_argument("--shard", choices=["samples", "rows"], default="samples")
+    ap.add_argument("--shard", choices=["tilerows", "rows"], default="tilerows",
+                    help="how ONE frame is split over the GPUs: interleaved 8-row tile rows (default) or contiguous row bands")
     ap.add_argument("--no-shadow", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-seconds of host work for cpu_baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU-seconds of host work for the main cpu_baseline leg")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="frames kept in flight on as many HIP streams (vxrt_accel_frames_in_flight); 1 = strictly serial frames")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
-                    help="gloo: rehearsal of the N>1 code path where ranks share one GPU (frames gathered through host memory)")
+                    help="gloo: rehearsal of the N>1 code path where ranks share one GPU (shares gathered through host memory)")
     ap.add_argument("--random-rays", type=int, default=16777216,
                     help="second leg (SURVEY s8d 'random rays vs fixed BVH'): N incoherent rays per GPU through vxrt_trace, reported under extras; 0 = skip")
     return ap.parse_args()
 
 
-def cpu_baseline(scene, w, h, budget_cpu_s):
-    """The reference's own BVHTraverser (oracle/_ref, kind 'reference') -- or, if that library is
-    absent or exceeds its watchdog, the C restatement (kind 'port') -- timed on this box's host cores
-    over a bounded sample of the same workload: the camera rays of the frame (closest hit only; the
-    reference has no shadow rays), repeated until about `budget_cpu_s` CPU-seconds are spent.
-    Checker code is used here as the thing timed for the reported baseline only, never for `value`."""
+def cpu_baseline(scene, vrt, w, h, light, budget_cpu_s):
+    """BASELINE.md s2, timed on this box's host cores, on BOUNDED samples of the same workload.  Checker code (oracle/_ref, or
+    the C restatement if that library is absent) is the thing timed here for the reported baseline only, never for `value`.
+      B2-N  (value)  the reference's own BVHTraverser (sim/simx/rt_traversal.cpp via oracle/_ref) on the frame's camera rays,
+                     closest hit, one traverser per thread over disjoint ray ranges, all host cores
+      B2-1           the same, one thread
+      B1             the reference's software ray caster (raycast render.h GenerateRay + Trace via oracle/_ref), one thread as
+                     written, render loop only, on the same geometry as BVH2 (primary rays + Lambert shade)"""
     import concurrent.futures as cf
     import numpy as np
     from oracle import pyoracle as po
@@ -68,41 +75,86 @@ def cpu_baseline(scene, w, h, budget_cpu_s):
     rays = po.camera_rays(w, h)
     img = po.Image(scene)
 
-    def run(fn, rays, repeats):
-        chunks = np.array_split(np.arange(len(rays)), cores * 8)
+    def run(fn, rays, repeats, threads):
+        chunks = np.array_split(np.arange(len(rays)), threads * 8)
         t0 = time.perf_counter()
         done = 0
-        with cf.ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL during the foreign call
+        with cf.ThreadPoolExecutor(threads) as ex:   # ctypes releases the GIL during the foreign call
             futs = [ex.submit(fn, img, rays[c]) for _ in range(repeats) for c in chunks]
             for f in futs:
                 try:
-                    out, _ = f.result(timeout=max(5.0, 8 * budget_cpu_s / cores - (time.perf_counter() - t0)))
+                    out, _ = f.result(timeout=max(5.0, 8 * budget_cpu_s / threads - (time.perf_counter() - t0)))
                     done += len(out)
                 except cf.TimeoutError:
                     return None
         return done, time.perf_counter() - t0
 
-    def sized(fn):
+    def sized(fn, budget):
         t0 = time.perf_counter()
         fn(img, rays[:: max(1, len(rays) // 4000)])          # probe spread over the frame
         per_ray = (time.perf_counter() - t0) / len(rays[:: max(1, len(rays) // 4000)])
-        want = budget_cpu_s / per_ray                        # rays for the CPU-second budget
+        want = budget / per_ray                              # rays for the CPU-second budget
         if want >= len(rays):
             return rays, max(1, int(round(want / len(rays))))
         return rays[:: max(1, int(len(rays) / want))], 1
 
-    kind, res = "port", None
+    kind, res, fn = "port", None, po.trace_faithful
     if po.have_ref():
-        r, rep = sized(po.trace_ref)
-        res = run(po.trace_ref, r, rep)
-        kind = "reference" if res else "port"
+        r, rep = sized(po.trace_ref, budget_cpu_s)
+        res = run(po.trace_ref, r, rep, cores)
+        if res:
+            kind, fn = "reference", po.trace_ref
     if res is None:
-        r, rep = sized(po.trace_faithful)
-        res = run(po.trace_faithful, r, rep)
+        r, rep = sized(po.trace_faithful, budget_cpu_s)
+        res = run(po.trace_faithful, r, rep, cores)
     done, dt = res
-    return {"value": round(done / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": kind,
-            "sample": "%d primary camera rays of the %dx%d frame (closest hit, no shadow rays; %d x %d rays), %s, %d host threads, %.1f s wall"
-                      % (done, w, h, rep, len(r), "reference sim/simx/rt_traversal.cpp via oracle/_ref" if kind == "reference" else "oracle/rt_oracle.c restatement", cores, dt)}
+    what = "reference sim/simx/rt_traversal.cpp via oracle/_ref" if kind == "reference" else "oracle/rt_oracle.c restatement"
+    out = {"value": round(done / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": kind,
+           "sample": "B2-N: %d primary camera rays of the %dx%d frame (closest hit, no shadow rays; %d x %d rays), %s, %d host threads, %.1f s wall"
+                     % (done, w, h, rep, len(r), what, cores, dt)}
+    # B2-1: one thread, 3 CPU-seconds
+    r1, rep1 = sized(fn, 3.0)
+    res1 = run(fn, r1, rep1, 1)
+    if res1:
+        out["b2_single_thread"] = {"value": round(res1[0] / res1[1] / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                                   "sample": "%d rays (every %d-th camera ray of the frame), %.1f s wall" % (res1[0], max(1, len(rays) // max(1, len(r1))), res1[1])}
+    # B1: the reference's raycast render loop on the same geometry as BVH2, rows spread over the frame, one thread
+    if po.have_ref_rc():
+        try:
+            rc = vrt.scene.rc_procedural("atrium", int(round(np.log2(scene.n_tris) / 2 - 2)), 0, 3)
+            cam = vrt.scene.rc_camera_like_rtu(w, h)
+            light12 = tuple(light) + (1.0, 1.0, 1.0, 0.4, 0.4, 0.4, 0.4, 0.35, 0.25)
+            t0 = time.perf_counter()
+            n = 0
+            stride, off = max(1, h // 64), 0
+            while time.perf_counter() - t0 < 3.0 and off < stride:   # one full row at a time, each pass spread over the whole frame
+                for y in range(off, h, stride):
+                    _, k = po.ref_rc_render_buffers(rc, w, h, y, y + 1, cam, light12)
+                    n += k
+                    if time.perf_counter() - t0 >= 3.0:
+                        break
+                off += 1
+            dt1 = time.perf_counter() - t0
+            out["b1_raycast_render_loop"] = {"value": round(n / dt1 / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                                             "sample": "%d primary rays (+ shade) of %d rows spread over the %dx%d frame, reference raycast render.h via oracle/_ref on the BVH2 of the same %d triangles, %.1f s wall"
+                                                       % (n, n // w, w, h, rc["tri"].size // 36, dt1)}
+        except Exception as e:   # the baseline leg must not take the bench line down
+            out["b1_raycast_render_loop"] = {"error": repr(e)[:200]}
+    out["note"] = "no POCL path exists to time: the reference has no OpenCL ray tracer and POCL is not installed (SURVEY s0.5)"
+    return out
+
+
+def load_profile_constants():
+    """Per-frame counters of the timed kernel that a bench run cannot read itself (rocprofv3 --pmc needs its own passes):
+    profiles/valu_profile.json, written by tools/roofline_from_pmc.py from the round's PMC summary.  Labelled as profile
+    constants wherever they are used."""
+    p = os.path.join(ROOT, "profiles", "valu_profile.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except Exception:
+            return None
+    return None
 
 
 def main():
@@ -138,12 +190,10 @@ def main():
     ds = vrt.tracer.DeviceScene(scene, dev)
     shadow = 0 if a.no_shadow else 1
     params = rtapi.default_shade_params()
-    params.light_pos[:] = (300.0, 480.0, 60.0)   # inside the hall, so shadow rays are real work
+    LIGHT = (300.0, 480.0, 60.0)
+    params.light_pos[:] = LIGHT   # inside the hall, so shadow rays are real work
 
-    if a.shard == "rows" and world > 1:
-        y0, y1 = sharding.row_bands(H, world)[rank]
-    else:
-        y0, y1 = 0, H
+    y0, y1 = sharding.row_bands(H, world)[rank] if (a.shard == "rows" and world > 1) else (0, H)
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
     nfl = max(1, min(8, a.frames_in_flight))
@@ -154,16 +204,21 @@ def main():
     counters = torch.zeros(8, dtype=torch.int64, device=dev)
 
     def launch(buf, count_ptr=None, st=None):
-        rtapi.render(ds.accel, W, H, y0, y1, params, buf.data_ptr(), shadow, None, None, count_ptr, (st or stream).cuda_stream)
+        sp = (st or stream).cuda_stream
+        if world > 1 and a.shard == "tilerows":
+            rtapi.render_interleaved(ds.accel, W, H, rank, world, params, buf.data_ptr(), shadow, None, None, count_ptr, sp)
+        else:
+            rtapi.render(ds.accel, W, H, y0, y1, params, buf.data_ptr(), shadow, None, None, count_ptr, sp)
 
     # rays per step on this rank (primary + shadow), counted once by the kernel itself
     launch(frames[0], counters.data_ptr())
     torch.cuda.synchronize()
     assert rtapi.status(sptr) == 0, "kernel status (traversal stack overflow)"
     rays_rank = int(counters[0].item())
-    algo = None
-    if hasattr(rtapi, "render_stats"):
-        algo = rtapi.render_stats(ds.accel, W, H, y0, y1, params, frames[0].data_ptr(), shadow, sptr)
+    algo = algo_timed = None
+    if world == 1:
+        algo = rtapi.render_stats(ds.accel, W, H, 0, H, params, frames[0].data_ptr(), shadow, sptr)                  # reference-order counts
+        algo_timed = rtapi.render_stats(ds.accel, W, H, 0, H, params, frames[0].data_ptr(), shadow, sptr, timed=True)  # the traversal that is timed
 
     rtapi.accel_frames_in_flight(ds.accel, nfl)
     gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
@@ -184,12 +239,12 @@ def main():
             # image assembly overlaps the next step's traversal: the gather runs on its own stream
             gather_stream.wait_stream(st)
             with torch.cuda.stream(gather_stream):
-                src = buf if cdev != "cpu" else buf.cpu()
-                if a.shard == "rows":
-                    sharding.gather_frame(src[y0:y1], H, W, rank, world)
+                if a.shard == "tilerows":
+                    share = sharding.extract_interleaved(buf, H, rank, world)
+                    sharding.gather_interleaved(share if cdev != "cpu" else share.cpu(), H, W, rank, world)
                 else:
-                    out = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
-                    dist.gather(src, out, dst=0)
+                    band = buf[y0:y1]
+                    sharding.gather_frame(band if cdev != "cpu" else band.cpu(), H, W, rank, world)
                 gdone[b] = torch.cuda.Event()
                 gdone[b].record(gather_stream)
 
@@ -224,14 +279,13 @@ def main():
         elapsed = float(t.item())
         r = torch.tensor([rays_rank], dtype=torch.int64, device=cdev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays_all = int(r.item())
+        rays_all = int(r.item())        # the rays of ONE frame: every rank traces a disjoint part of it
     else:
         rays_all = rays_rank
     assert rtapi.status(sptr) == 0
-    # HIP events on the launch streams.  With frames in flight the launches of consecutive steps overlap, so
-    # the per-launch duration that prices the roofline is the span of the timed region's events divided by
-    # the launches in it (their union, not their sum); the overlapped and the isolated per-launch
-    # durations are reported next to it.
+    # HIP events on the launch streams.  With frames in flight the launches of consecutive steps overlap, so the per-launch
+    # duration that prices the roofline is the span of the timed region's events divided by the launches in it (their union,
+    # not their sum); the overlapped and the isolated per-launch durations are reported next to it.
     ovl_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps
     span_ms = max(evs[0][0].elapsed_time(e1) for _, e1 in evs)
     kern_ms = span_ms / a.steps
@@ -274,16 +328,23 @@ def main():
         mr = n * world * reps / rt / 1e6
         extras["random_rays_mrays_s"] = round(mr, 1)
         extras["random_rays_n"] = n * world
+        extras["random_rays_scaling"] = "weak (N rays per GPU)"
         if rstats:
             gbs = mr * 1e6 * rstats["bytes_per_ray"] / 1e9
             extras["random_rays"] = {"rays_per_gpu": n, "mrays_s": round(mr, 1), "ms_per_launch": round(rt / reps * 1e3, 3),
-                                     "bytes_per_ray": round(rstats["bytes_per_ray"], 1), "achieved_GBs": round(gbs, 1),
-                                     "frac_of_hbm_peak": round(gbs / (HBM_PEAK_GBS * world), 4),
+                                     "bytes_per_ray": round(rstats["bytes_per_ray"], 1), "algorithmic_GBs": round(gbs, 1),
+                                     "frac_of_hbm_peak": round(gbs / (HBM_PEAK_GBS * world), 4), "frac_of_l2_peak": round(gbs / (L2_PEAK_GBS * world), 4),
                                      "node_fetches_per_ray": round(rstats["node_fetches"] / n, 2),
                                      "tri_fetches_per_ray": round(rstats["tri_fetches"] / n, 2)}
         del rays, hits
 
     if rank == 0:
+        if world == 1:
+            par = "1 GPU: whole frame"
+        elif a.shard == "tilerows":
+            par = "one frame split by interleaved 8-row tile rows (rank r: rows r, r+%d, ... of %d tile rows) x%d GPUs, RCCL gather of the shares to rank 0" % (world, (H + 7) // 8, world)
+        else:
+            par = "one frame split into %d contiguous tile-aligned row bands, RCCL gather to rank 0" % world
         out = {
             "metric": "Mrays/s (primary+shadow) at %dx%d, 1M-tri BVH" % (W, H),
             "value": round(rays_all * a.steps / elapsed / 1e6, 2),
@@ -291,42 +352,50 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong" if (a.shard == "rows" and world > 1) else "weak",
+            "scaling": "strong",   # the frame -- the total work -- is fixed as N grows
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (procedural 'Sponza-class' atrium, seed 3; no Sponza/bunny asset exists offline)",
             "config": {"workload": "configs[2]: Sponza-class %d tris, %dx%d, primary + 1 shadow ray per hit%s" % (scene.n_tris, W, H, "" if shadow else " (shadow disabled)"),
-                       "rays_per_step_per_gpu": rays_rank, "frames_in_flight": nfl,
-                       "parallelism": ("spp-sharded x%d: one sample (full frame) per GPU, RCCL gather of frames to rank 0" % world) if a.shard == "samples"
-                                      else ("row bands x%d of one frame, RCCL gather to rank 0" % world),
+                       "rays_per_step": rays_all, "rays_per_step_rank0": rays_rank, "frames_in_flight": nfl, "parallelism": par,
                        "bvh_nodes": scene.n_bvh_nodes, "bvh_depth": scene.info.get("max_depth")},
         }
-        bytes_launch = None
-        if algo is not None:
-            bytes_launch = algo["bytes"]
-        # one step = the launches of vxrt_render: persistent traversal kernel (dominant, > 93 % of the step), the
-        # EXACT launches for the rays with NaN-capable slabs, and the shading pass; priced together
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+        prof = load_profile_constants()
+        # one step = the launches of vxrt_render: persistent traversal kernel (dominant, > 93 % of the step), the EXACT launches
+        # for the rays with NaN-capable slabs, and the shading pass; priced together
+        roof = {"bound": "valu", "achieved": None, "peak": round(SIMDS * CLOCK_GHZ, 1), "unit": "Gcycle/s (VALU issue cycles summed over the 1024 SIMDs)", "frac": None, "traffic": None,
                 "kernel": "rt_persistent_kernel<JOB_RENDER%s> (+ EXACT launches + rt_shade_kernel)" % ("_SHADOW" if shadow else ""),
                 "kernel_ms": round(kern_ms, 4), "kernel_ms_overlapped": round(ovl_ms, 4), "kernel_ms_isolated": round(iso_ms, 4),
                 "frames_in_flight": nfl,
-                "note": "algorithmic bytes are SURVEY s8d's per-ray formula (52 B per node, 36 B per triangle the reference would fetch); the scene is "
-                        "cache-resident (traffic = measured HBM bytes per step), so achieved can exceed the HBM peak; the kernel's own limit is VALU issue "
-                        "(88 % for an isolated launch, 69 % active lanes: profiles/r01_k_pmc.txt, DESIGN.md s4)"}
-        if bytes_launch:
-            ach = bytes_launch / (kern_ms * 1e-3) / 1e9
-            roof.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "frac_isolated": round(bytes_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": bytes_launch,
-                         "bytes_per_ray": round(bytes_launch / rays_rank, 1), "counts": algo})
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                roof["traffic"] = json.load(open(tf)).get("bytes_per_launch")
-            except Exception:
-                pass
+                "why_valu": "the scene is cache-resident (measured HBM traffic = a few % of the HBM peak) and every change to the memory path measured neutral "
+                            "(LDS-staged top of the tree serves 39 % of the node steps, +0 %); the kernel's time follows its VALU cycles: per-opcode SIMD cycles "
+                            "measured with tools/calibrate_valu.py (add/sub/mul/fma/mov/and/xor 2.2; cmp/cndmask/min/max/cvt_ubyte/lshl 4.1; rcp 8.1 per wave64 instruction)"}
+        if prof and world == 1 and W == 1920 and H == 1080 and a.level == 8 and shadow:
+            # profile constants of THIS workload (deterministic instruction counts per frame), source named in the file
+            cyc = prof["valu_simd_cycles_per_frame"]            # sum over instruction classes of count x measured cycles
+            ach = cyc / (kern_ms * 1e-3) / 1e9
+            roof.update({"achieved": round(ach, 1), "frac": round(ach / (SIMDS * CLOCK_GHZ), 4),
+                         "frac_isolated": round(cyc / (iso_ms * 1e-3) / 1e9 / (SIMDS * CLOCK_GHZ), 4),
+                         "valu_simd_cycles_per_frame": cyc, "valu_instr_per_frame": prof.get("valu_instr_per_frame"),
+                         "valu_source": prof.get("source"), "valu_pricing": prof.get("pricing")})
+            roof["traffic"] = prof.get("hbm_bytes_per_frame")
+            roof["traffic_source"] = prof.get("hbm_source")
+        if algo:
+            bytes_launch = algo["bytes"]
+            gbs = bytes_launch / (kern_ms * 1e-3) / 1e9
+            roof["bytes"] = {"algorithmic_bytes_per_launch": bytes_launch, "bytes_per_ray": round(bytes_launch / rays_rank, 1),
+                             "algorithmic_GBs": round(gbs, 1),
+                             "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "hbm_peak_GBs": HBM_PEAK_GBS,
+                             "frac_of_l2_peak": round(gbs / L2_PEAK_GBS, 4), "l2_peak_GBs": L2_PEAK_GBS,
+                             "note": "SURVEY s8d formula (52 B per node / instance record, 36 B per triangle the reference would fetch, + shading bytes); the scene is "
+                                     "cache-resident, so this figure prices bytes the L1/L2/Infinity Cache serve: it may exceed the HBM peak and is not the bound",
+                             "measured_hbm_GBs": round(roof["traffic"] / (kern_ms * 1e-3) / 1e9, 1) if roof.get("traffic") else None,
+                             "measured_hbm_frac_of_peak": round(roof["traffic"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if roof.get("traffic") else None}
+            roof["counts_reference_order"] = algo
+            roof["counts_timed_traversal"] = algo_timed
         out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, W, H, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(scene, vrt, W, H, LIGHT, a.cpu_seconds)
         if extras:
             out["extras"] = extras
         print(json.dumps(out), flush=True)

@@ -232,6 +232,13 @@ int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
                       const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                       unsigned long long* counters, void* stream);
 
+/* vxrt_render_stats for the traversal the TIMED kernel performs (same counters): a frame's occlusion rays visit children in
+ * slot order instead of near-to-far (the result is a boolean) and idle lanes test a leaf's second triangle, so its node /
+ * triangle fetch counts differ from the reference-order ones; bench.py reports both. */
+int vxrt_render_stats_timed(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                            const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
+                            unsigned long long* counters, void* stream);
+
 /* vxrt_trace with the fetch counters compiled in (slower; never a timed path).  counters: device u64[8], of which
  * [0..3] = rays, node fetches, instance fetches, triangle fetches as the reference accounts them (rt_traversal.cpp:
  * 54,116,148,158, without restart re-reads) -- the inputs of the algorithmic bytes per ray. */
@@ -283,11 +290,13 @@ typedef struct vxrc_params {     /* the fields of raycast/common.h:126-150 kerne
 int vxrc_render(const vxrc_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                 const vxrc_params_t* params, uint32_t* dst, float* colors, void* stream);
 
-/* Diagnostic variant of vxrt_render_stats: additionally logs 13 u64 per wavefront of the main traversal launch into
- * wave_log (device u64[13 * 4 * 8 * 256]): [0] first and [1] last 100 MHz clock, [2] rays started, [3] loop iterations,
+/* Diagnostic variant of vxrt_render_stats_timed: additionally logs 16 u64 per wavefront of the main traversal launch into
+ * wave_log (device u64[16 * 4 * 8 * 256]): [0] first and [1] last 100 MHz clock, [2] rays started, [3] loop iterations,
  * [4] runs of the node body and [5] lanes active in them, [6] runs of the leaf body and [7] lanes active in them,
- * [8..9] reserved, [10] shader clocks inside the node body, [11] inside the instance + leaf part, [12] of the whole
- * wavefront -- to study load balance and lane occupancy of the launch (tools/wave_balance.py). */
+ * [8] lane node steps served from the LDS top-of-tree image, [9] node-body runs in which every node lane was at the same
+ * node, [10] shader clocks inside the node body, [11] inside the instance + leaf part, [12] of the whole wavefront,
+ * [13] inside the fetch section (job queue, ray generation), [14] inside the finish section (records, occlusion-ray
+ * start), [15] reserved -- to study load balance and lane occupancy of the launch (tools/wave_balance.py). */
 int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                          unsigned long long* counters, unsigned long long* wave_log, void* stream);

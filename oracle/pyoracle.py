@@ -136,6 +136,23 @@ def ref_rc():
     return _ref_rc
 
 
+def ref_rc_render_buffers(scene, w, h, y0, y1, cam14, light12=None, x_step=1, spp=1, max_depth=1):
+    """The reference's own raycast render loop (render.h GenerateRay + Trace, compiled where it lies) over a raycast-format
+    scene given as a dict of uint8 arrays (tlas, blas, bvh, tri, triEx, triIdx, tex, tlas_root) -- rows [y0,y1), every
+    x_step-th column.  Returns (pixels [h, w] u32, primary rays traced).  BASELINE.md s2 baseline B1."""
+    L = ref_rc()
+    L.rcref_render_buffers.restype = C.c_uint64
+    L.rcref_render_buffers.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    keep = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("tri", "triEx", "triIdx", "bvh", "tlas", "blas", "tex")}
+    ptrs = (C.c_void_p * 7)(*[keep[k].ctypes.data if keep[k].size else None for k in ("tri", "triEx", "triIdx", "bvh", "tlas", "blas", "tex")])
+    cam = np.ascontiguousarray(cam14, np.float32)
+    lig = np.ascontiguousarray(light12 if light12 is not None else RC_DEFAULT_LIGHT, np.float32)
+    out = np.zeros((h, w), np.uint32)
+    n = L.rcref_render_buffers(ptrs, int(scene["tlas_root"]), w, h, y0, y1, x_step, spp, max_depth, _p(cam), _p(lig), _p(out))
+    return out, int(n)
+
+
 class RcArgs(C.Structure):   # rc_args_t (oracle/rc_oracle.h)
     _fields_ = [("dst_width", C.c_uint32), ("dst_height", C.c_uint32),
                 ("tri", C.c_void_p), ("triEx", C.c_void_p), ("triIdx", C.c_void_p), ("tex", C.c_void_p),

@@ -119,6 +119,45 @@ int rcref_render(void* h, uint32_t w, uint32_t hgt, uint32_t spp, uint32_t max_d
   return 0;
 }
 
+// The same loop (Tracer::render, tracer.cpp:249-263: GenerateRay + Trace of render.h) over caller-provided buffers in the
+// raycast formats, rows [y0,y1) only -- BASELINE.md s2's baseline B1 (the reference's software ray caster, single thread, render
+// loop only) on a scene too large for the reference's recursive builder to be part of a bench run.  ptrs: tri, triEx, triIdx,
+// bvh, tlas, blas, tex.  Returns the number of primary rays traced.
+uint64_t rcref_render_buffers(const void* const* ptrs, uint32_t tlas_root, uint32_t w, uint32_t hgt, uint32_t y0, uint32_t y1, uint32_t x_step,
+                              uint32_t spp, uint32_t max_depth, const float* cam14, const float* light12, uint32_t* out) {
+  kernel_arg_t a{};
+  a.dst_width = w; a.dst_height = hgt; a.dst_addr = (uint64_t)out;
+  a.tri_addr = (uint64_t)ptrs[0]; a.triEx_addr = (uint64_t)ptrs[1]; a.triIdx_addr = (uint64_t)ptrs[2];
+  a.bvh_addr = (uint64_t)ptrs[3]; a.tlas_addr = (uint64_t)ptrs[4]; a.blas_addr = (uint64_t)ptrs[5]; a.tex_addr = (uint64_t)ptrs[6];
+  a.tlas_root = tlas_root;
+  a.camera_pos = float3_t(cam14[0], cam14[1], cam14[2]);
+  a.camera_forward = float3_t(cam14[3], cam14[4], cam14[5]);
+  a.camera_right = float3_t(cam14[6], cam14[7], cam14[8]);
+  a.camera_up = float3_t(cam14[9], cam14[10], cam14[11]);
+  a.viewplane = {cam14[12], cam14[13]};
+  a.samples_per_pixel = spp; a.max_depth = max_depth;
+  a.light_pos = float3_t(light12[0], light12[1], light12[2]);
+  a.light_color = float3_t(light12[3], light12[4], light12[5]);
+  a.ambient_color = float3_t(light12[6], light12[7], light12[8]);
+  a.background_color = float3_t(light12[9], light12[10], light12[11]);
+  auto arg = &a;
+  uint64_t n = 0;
+  if (x_step == 0) x_step = 1;
+  for (uint32_t y = y0; y < y1 && y < arg->dst_height; ++y) {
+    for (uint32_t x = 0; x < arg->dst_width; x += x_step) {
+      uint32_t out_idx = y * arg->dst_width + x;
+      float3_t color = float3_t(0, 0, 0);
+      for (uint32_t s = 0; s < arg->samples_per_pixel; ++s) {
+        auto ray = GenerateRay(x, y, arg);
+        color += Trace(ray, arg);
+        ++n;
+      }
+      out[out_idx] = RGB32FtoRGB8(color);
+    }
+  }
+  return n;
+}
+
 // one ray through the reference's TLASIntersect (hit record) -- for traversal-only fixtures
 void rcref_trace(void* h, const float* ray6, float* out_dist, float* out_bc3, uint32_t* out_blas, uint32_t* out_tri) {
   auto sc = ((rcref_scene_t*)h)->scene;

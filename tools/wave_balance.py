@@ -14,7 +14,7 @@ L.vxrt_render_wave_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint3
 for shadow in (1,):
     for it in range(3):   # the third frame runs with the tile order learned from the second
         cnt = torch.zeros(8, dtype=torch.int64, device="cuda:0")
-        log = torch.zeros((4 * 8 * 256, 13), dtype=torch.int64, device="cuda:0")
+        log = torch.zeros((4 * 8 * 256, 16), dtype=torch.int64, device="cuda:0")
         assert L.vxrt_render_wave_log(ds.accel, W, H, 0, H, C.byref(p), shadow, px.data_ptr(), cnt.data_ptr(), log.data_ptr(), None) == 0
         torch.cuda.synchronize()
     lg = log.cpu().numpy().astype(np.float64)
@@ -35,4 +35,5 @@ for shadow in (1,):
     print("shader clocks: node body %.3f, instance+leaf part %.3f, rest (fetch, finish, loop control) %.3f of the wave lifetime" % (tn / tt, tl / tt, 1 - (tn + tl) / tt))
     print("node steps served from the LDS top-of-tree image: %.3f of lane node steps; node-body runs with every node lane at the SAME node: %.3f"
           % (lg[:, 8].sum() / max(nl, 1), lg[:, 9].sum() / max(nx, 1)))
+    print("shader clocks: fetch section %.3f, finish section %.3f of the wave lifetime" % (lg[:, 13].sum() / tt, lg[:, 14].sum() / tt))
     print("shader clocks per node-body run %.0f, per instance+leaf run %.0f, per iteration %.0f" % (tn / max(nx, 1), tl / max(lx, 1), tt / max(it, 1)))

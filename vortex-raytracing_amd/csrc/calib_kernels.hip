@@ -1,0 +1,159 @@
+// Calibration loops for the VALU roofline (tools/calibrate_valu.py): streams of INDEPENDENT vector instructions
+// of a known count, launched at a chosen number of wavefronts per SIMD.  Every wavefront stamps the shader clock (s_memtime)
+// and the 100 MHz wall clock (s_memrealtime) around its loop, so the cycles one wave64 instruction occupies its SIMD follow
+// from counts and clocks alone -- no assumption about the frequency the chip holds under this load.  Run under the same
+// rocprofv3 --pmc pass as the traversal kernel, it also shows what SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES read
+// for a VALU pipe whose utilisation is known.  No reference counterpart; measurement infrastructure of the product library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CAL_CHAINS 16   // independent accumulators per lane: no instruction waits for the one before it
+#define CAL_UNROLL 8    // loop body = CAL_UNROLL * CAL_CHAINS instructions, so loop control is < 3 % of the stream
+
+enum { OP_FMA = 0, OP_PK_FMA = 1, OP_ADD = 2, OP_CNDMASK = 3, OP_CVT_UBYTE = 4, OP_MAX3 = 5, OP_RCP = 6, OP_CNDMASK_SGPR = 7, OP_MOV = 8,
+       OP_CMP_VCC = 9, OP_CMP_SGPR = 10, OP_MUL = 11, OP_MAX = 12, OP_AND = 13, OP_CNDMASK_CONST = 14, OP_MIN = 15, OP_XOR = 16, OP_BFI = 17, OP_SUB = 18,
+       OP_LSHL = 19, OP_ADD_U32 = 20, OP_MED3 = 21, OP_FMAC = 22, OP_MUL_LO = 23, OP_PERM = 24, OP_CNDMASK_VCC_SET = 25, OP_ASHR = 26, OP_MIN_U32 = 27,
+       OP_LSHL_OR = 28, OP_AND_OR = 29, OP_PK_MUL = 30, OP_PK_ADD = 31, OP_CNDMASK_E64_VCC = 32, OP_CNDMASK_VCC_ALT_ADD = 33, OP_CNDMASK_VCC_DISTINCT = 34,
+       OP_CNDMASK_VCC_1OF8 = 35, OP_COUNT = 36 };
+
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+template <int OP>
+__global__ __launch_bounds__(256) void vxcal_kernel(float* __restrict__ out, unsigned long long* __restrict__ clocks, uint32_t n_iter, float m, float c) {
+  float a[CAL_CHAINS], b[CAL_CHAINS];
+#pragma unroll
+  for (int k = 0; k < CAL_CHAINS; ++k) { a[k] = (float)(threadIdx.x + k) * 1e-3f + 1.0f; b[k] = 0.f; }
+  unsigned long long mask = __ballot(a[0] > 1.03f), mask2 = 0;
+  if (OP == OP_CNDMASK_VCC_SET) asm volatile("s_mov_b64 vcc, %0" : : "s"(mask) : "vcc");
+  const unsigned long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  for (uint32_t i = 0; i < n_iter; ++i) {
+#pragma unroll
+    for (int u = 0; u < CAL_UNROLL; ++u) {
+#pragma unroll
+      for (int k = 0; k < CAL_CHAINS; ++k) {
+        if (OP == OP_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c));
+        if (OP == OP_ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+        if (OP == OP_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(c) : );
+        if (OP == OP_CVT_UBYTE) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(a[k]));
+        if (OP == OP_MAX3) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c));
+        if (OP == OP_RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[k]));
+        if (OP == OP_CNDMASK_SGPR) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[k]) : "v"(c), "s"(mask));
+        if (OP == OP_MOV) asm volatile("v_mov_b32 %0, %1" : "+v"(a[k]) : "v"(c));
+        if (OP == OP_CMP_VCC) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[k]), "v"(c) : "vcc");
+        if (OP == OP_CMP_SGPR) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(mask2) : "v"(a[k]), "v"(c));
+        if (OP == OP_MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k]) : "v"(m));
+        if (OP == OP_MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[k]) : "v"(m));
+        if (OP == OP_AND) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[k]) : "v"(m));
+        if (OP == OP_MIN) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[k]) : "v"(m));
+        if (OP == OP_XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[k]) : "v"(m));
+        if (OP == OP_BFI) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[k]) : "v"(m), "v"(c));
+        if (OP == OP_SUB) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+        if (OP == OP_LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[k]));
+        if (OP == OP_ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+        if (OP == OP_MED3) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c));
+        if (OP == OP_FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c));
+        if (OP == OP_MUL_LO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(m));
+        if (OP == OP_PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c));
+        if (OP == OP_CNDMASK_VCC_SET) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(c));
+        if (OP == OP_ASHR) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a[k]));
+        if (OP == OP_MIN_U32) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[k]) : "v"(m));
+        if (OP == OP_LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a[k]) : "v"(m));
+        if (OP == OP_AND_OR) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c));
+        if (OP == OP_CNDMASK_E64_VCC) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(c));
+        if (OP == OP_CNDMASK_VCC_ALT_ADD) { if (k & 1) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(c)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c)); }
+        if (OP == OP_CNDMASK_VCC_DISTINCT) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(b[k]) : "v"(a[k]), "v"(c));
+        if (OP == OP_CNDMASK_VCC_1OF8) { if ((k & 7) == 0) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(c)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c)); }
+        if (OP == OP_CNDMASK_CONST) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[k]) : "v"(c), "s"(0x5555555555555555ull));
+      }
+      if (OP == OP_PK_MUL || OP == OP_PK_ADD) {
+#pragma unroll
+        for (int rep2 = 0; rep2 < 2; ++rep2) {
+#pragma unroll
+          for (int k = 0; k < CAL_CHAINS; k += 2) {
+            float2_t v = {a[k], a[k + 1]};
+            const float2_t mm = {m, m};
+            if (OP == OP_PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(v) : "v"(mm));
+            else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v) : "v"(mm));
+            a[k] = v.x; a[k + 1] = v.y;
+          }
+        }
+      }
+      if (OP == OP_PK_FMA) {
+#pragma unroll
+        for (int k = 0; k < CAL_CHAINS; k += 2) {   // half as many instructions for the same number of lane operations ...
+          float2_t v = {a[k], a[k + 1]};
+          const float2_t mm = {m, m}, cc = {c, c};
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v) : "v"(mm), "v"(cc));
+          a[k] = v.x; a[k + 1] = v.y;
+        }
+#pragma unroll
+        for (int k = 0; k < CAL_CHAINS; k += 2) {   // ... issued twice, so every OP executes CAL_CHAINS instructions per unroll step
+          float2_t v = {a[k], a[k + 1]};
+          const float2_t mm = {m, m}, cc = {c, c};
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v) : "v"(mm), "v"(cc));
+          a[k] = v.x; a[k + 1] = v.y;
+        }
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  float s = (float)(mask2 & 1ull);
+#pragma unroll
+  for (int k = 0; k < CAL_CHAINS; ++k) s += a[k] + b[k];
+  out[(size_t)blockIdx.x * 256u + threadIdx.x] = s;
+  if ((threadIdx.x & 63u) == 0u) {
+    unsigned long long* w = clocks + 2ull * ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6));
+    w[0] = t1 - t0; w[1] = r1 - r0;
+  }
+}
+
+extern "C" {
+// blocks of 256 threads (4 wavefronts, one per SIMD of a CU); vector instructions per wavefront = CAL_CHAINS * CAL_UNROLL * n_iter.
+// clocks: device u64[2 * 4 * blocks] = per wavefront {shader cycles, 100 MHz ticks} around the loop.
+int vxcal_valu_loop(int op, uint32_t blocks, uint32_t n_iter, float* out, unsigned long long* clocks, void* stream) {
+  if (!blocks || !out || !clocks) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const float m = 1.0000001f, c = 0.25f;
+  switch (op) {
+    case 0: hipLaunchKernelGGL(vxcal_kernel<0>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 1: hipLaunchKernelGGL(vxcal_kernel<1>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 2: hipLaunchKernelGGL(vxcal_kernel<2>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 3: hipLaunchKernelGGL(vxcal_kernel<3>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 4: hipLaunchKernelGGL(vxcal_kernel<4>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 5: hipLaunchKernelGGL(vxcal_kernel<5>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 6: hipLaunchKernelGGL(vxcal_kernel<6>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 7: hipLaunchKernelGGL(vxcal_kernel<7>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 8: hipLaunchKernelGGL(vxcal_kernel<8>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 9: hipLaunchKernelGGL(vxcal_kernel<9>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 10: hipLaunchKernelGGL(vxcal_kernel<10>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 11: hipLaunchKernelGGL(vxcal_kernel<11>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 12: hipLaunchKernelGGL(vxcal_kernel<12>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 13: hipLaunchKernelGGL(vxcal_kernel<13>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 14: hipLaunchKernelGGL(vxcal_kernel<14>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 15: hipLaunchKernelGGL(vxcal_kernel<15>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 16: hipLaunchKernelGGL(vxcal_kernel<16>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 17: hipLaunchKernelGGL(vxcal_kernel<17>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 18: hipLaunchKernelGGL(vxcal_kernel<18>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 19: hipLaunchKernelGGL(vxcal_kernel<19>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 20: hipLaunchKernelGGL(vxcal_kernel<20>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 21: hipLaunchKernelGGL(vxcal_kernel<21>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 22: hipLaunchKernelGGL(vxcal_kernel<22>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 23: hipLaunchKernelGGL(vxcal_kernel<23>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 24: hipLaunchKernelGGL(vxcal_kernel<24>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 25: hipLaunchKernelGGL(vxcal_kernel<25>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 26: hipLaunchKernelGGL(vxcal_kernel<26>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 27: hipLaunchKernelGGL(vxcal_kernel<27>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 28: hipLaunchKernelGGL(vxcal_kernel<28>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 29: hipLaunchKernelGGL(vxcal_kernel<29>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 30: hipLaunchKernelGGL(vxcal_kernel<30>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 31: hipLaunchKernelGGL(vxcal_kernel<31>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 32: hipLaunchKernelGGL(vxcal_kernel<32>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 33: hipLaunchKernelGGL(vxcal_kernel<33>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 34: hipLaunchKernelGGL(vxcal_kernel<34>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 35: hipLaunchKernelGGL(vxcal_kernel<35>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    default: return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+uint32_t vxcal_instr_per_iter(void) { return CAL_CHAINS * CAL_UNROLL; }
+}

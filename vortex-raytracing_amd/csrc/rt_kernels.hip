@@ -448,6 +448,14 @@ static_assert(RT_TOP_NODES <= RT_TOP_MAX, "top-of-tree image");
 
 enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2 };
 
+// -DRT_ISA_MARKS: comment-only markers in the listing (hipcc -S) that delimit the regions of the traversal loop for
+// tools/isa_regions.py; never set for a build that is run
+#ifdef RT_ISA_MARKS
+#define RT_MARK(name) asm volatile("; RTMARK " name)
+#else
+#define RT_MARK(name)
+#endif
+
 // Hit records of a frame window are kept TILE-MAJOR between the traversal and the shading pass: record of pixel (x, y) =
 // tile * 64 + lane of the 8x8 tile grid that starts at row y0, i.e. the job id of the traversal kernel.  A wavefront
 // therefore writes the 64 records of its tile as one contiguous, 128-byte aligned 1,536-byte block, once (the occlusion
@@ -481,7 +489,7 @@ struct PersistArgs {
   // render jobs, optional: longest-processing-time-first order learned from the previous frame of this context
   // (tile_order[queue position] = tile, sorted by cost within each shard's band) and where this frame's cost goes
   const uint32_t* tile_order; uint32_t* tile_cost;
-  unsigned long long* wave_log;   // STATS only, optional: 13 u64 per wavefront (see vxrt_render_wave_log in the header)
+  unsigned long long* wave_log;   // STATS only, optional: 16 u64 per wavefront (see vxrt_render_wave_log in the header)
 };
 
 __device__ __forceinline__ bool is_node_desc(uint32_t d) { return d < 0x80000000u; }
@@ -503,7 +511,9 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 // direction (triangle tests only), barycentrics / indices of the best hit and blasIdx live in LDS
 // next to the stack; the world ray is not stored at all - it is re-derived from the job (ray buffer,
 // camera tables, or the pixel's primary hit record) on the rare TLAS-level steps.
-template <int JOB, bool STATS, bool LDEXP, bool EXACT>
+// STATS: 0 = the timed kernel; 1 = counting build in the reference's order (ordered occlusion, no leaf helpers: its fetch counts equal
+// the canonical restatement's); 2 = counting build of the traversal the timed kernel actually performs (unordered occlusion, helpers)
+template <int JOB, int STATS, bool LDEXP, bool EXACT>
 __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
   constexpr int WG_WAVES = EXACT ? 4 : RT_WG_WAVES;
   constexpr bool USE_TOP = RT_TOP_NODES > 0 && !EXACT && !LDEXP;   // (the ldexp decode reads exponents from the reference node by index)
@@ -555,7 +565,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   unsigned long long t_first = 0;
   unsigned long long wl_tn = 0, wl_tl = 0, wl_t0 = 0;   // wave_log: shader clocks inside the node body / the leaf body
   unsigned wl_no23 = 0, wl_no3 = 0, wl_iter = 0, wl_node_x = 0, wl_node_l = 0, wl_leaf_x = 0, wl_leaf_l = 0;   // wave_log: lane occupancy of the two bodies
-  unsigned long long wl_tstart = 0;
+  unsigned long long wl_tstart = 0, wl_tf = 0, wl_tfin = 0, wl_tmark = 0;   // wave_log: shader clocks in the fetch / finish sections
   if (STATS && A.wave_log) { t_first = wall_clock64(); wl_tstart = __builtin_readcyclecounter(); }
 
   auto pixel_of = [&](uint32_t r, uint32_t& x, uint32_t& y) {
@@ -670,6 +680,8 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   };
 
   for (;;) {
+    RT_MARK("fetch");
+    if (STATS && A.wave_log) wl_tmark = __builtin_readcyclecounter();
     // ================= fetch: hand new jobs to idle lanes =================
     // Jobs are reserved per wavefront in chunks from one of the queue shards (one global atomic per
     // RT_CHUNK jobs); lanes then draw from the wavefront's private range.
@@ -735,12 +747,15 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
             A.tile_cost[lpt_tile] = (uint32_t)min(wall_clock64() - lpt_t0, 0xFFFFFFFFull);
           break;
         }
+        if (STATS && A.wave_log) wl_tf += __builtin_readcyclecounter() - wl_tmark;
         continue;
       }
     }
+    if (STATS && A.wave_log) wl_tf += __builtin_readcyclecounter() - wl_tmark;
 
     // ================= traverse: one step of whatever each lane holds, per iteration =================
     for (;;) {
+      RT_MARK("loop_top");
       if (STATS && A.wave_log) {
         const unsigned long long nm = __ballot(is_node_desc(cur));
         ++wl_iter;
@@ -751,6 +766,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
         }
       }
       if (STATS && A.wave_log) wl_t0 = __builtin_readcyclecounter();
+      RT_MARK("node");
       if (is_node_desc(cur)) {
         // ---- internal node: 4 box tests, order, push the far ones, continue with the nearest ----
         const bool top = (cur >> 30) == DK_TLAS;
@@ -781,7 +797,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
         if (STATS) fx.node++;
         Cand c[4];
         eval_children<EXACT, LDEXP>(q0, q1, q2, q3, ref_node, arx, ary, arz, aix, aiy, aiz, hitd, c);
-        if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && !STATS && __all((flags & F_ANYHIT) != 0u)) {   // STATS keeps the reference's order, hence its fetch counts
+        if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && STATS != 1 && __all((flags & F_ANYHIT) != 0u)) {   // STATS keeps the reference's order, hence its fetch counts
           // occlusion rays of a frame only feed a boolean (is anything hit before the light?): the set
           // of triangles an any-hit traversal can reach does not depend on the visiting order, so the
           // ordering network and the path_m bookkeeping are skipped (vxrt_trace's MODE_ANY, which
@@ -816,6 +832,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
         }
       }
       if (STATS && A.wave_log) { const unsigned long long t1 = __builtin_readcyclecounter(); wl_tn += t1 - wl_t0; wl_t0 = t1; }
+      RT_MARK("inst");
       if (__any(is_inst_desc(cur))) {
         if (is_inst_desc(cur)) {
           float ox, oy, oz, dx, dy, dz, tm;
@@ -825,11 +842,12 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
       }
       // leaves are postponed until RT_LEAF_MIN lanes hold one (or no lane has a node left): the leaf
       // body then runs for many lanes at once instead of once per iteration for a few
+      RT_MARK("leaf");
       const unsigned long long leafm = __ballot(is_leaf_desc(cur));
       if (leafm != 0ull && ((uint32_t)__popcll(leafm) >= (JOB == JOB_TRACE ? RT_TRACE_LEAF_MIN : RT_LEAF_MIN) || __ballot(is_node_desc(cur) || is_inst_desc(cur)) == 0ull)) {
         // ---- BLAS leaf (:123-161): triangles in index order, strict '<' ----
         if (STATS && A.wave_log) { ++wl_leaf_x; wl_leaf_l += (unsigned)__popcll(leafm); }
-        constexpr bool HELP = RT_LEAF_HELPERS && !STATS && (JOB != JOB_TRACE || RT_LEAF_HELPERS > 1);   // (the counting build keeps the reference's triangle-test count)
+        constexpr bool HELP = RT_LEAF_HELPERS && STATS != 1 && (JOB != JOB_TRACE || RT_LEAF_HELPERS > 1);   // (the counting build keeps the reference's triangle-test count)
         if (!HELP) {
           if (is_leaf_desc(cur)) {
             if (STATS) fx.node++;
@@ -881,6 +899,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
           const bool owner = is_leaf_desc(cur);
           uint32_t leftFirst = 0u, triCount = 0u;
           if (owner) {
+            if (STATS) fx.node++;
             leftFirst = cur & LEAF_FIRST_MASK; triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
             if (triCount == 0u) {   // leaf with more than 15 triangles: range kept in the reference node
               const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS;
@@ -906,6 +925,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
             const float4* tp = sc.tri_w + (size_t)(tfirst + (helper ? 1u : 0u)) * 3;
             const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
             p_d = ray_tri(tox, toy, toz, cdx, cdy, cdz, t0, t1, t2, p_bx, p_by, p_bz);
+            if (STATS) fx.tri++;   // (a helper's test counts even when the owner stops before using it)
           }
           const int hl = served ? (int)pair_h[wr] : (int)lane;
           const float h_d = __shfl(p_d, hl), h_bx = __shfl(p_bx, hl), h_by = __shfl(p_by, hl), h_bz = __shfl(p_bz, hl);
@@ -921,6 +941,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
                 const float4* tp = sc.tri_w + (size_t)triIdx * 3;
                 const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                 d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
+                if (STATS) fx.tri++;
               }
               if (d < hitd) {
                 hitd = d;
@@ -937,6 +958,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
         }
       }
       if (STATS && A.wave_log) { const unsigned long long t1 = __builtin_readcyclecounter(); wl_tl += t1 - wl_t0; }
+      RT_MARK("loop_exit");
       // leave when nothing traverses any more, or when enough lanes are dead weight AND leaving can
       // revive them (finished rays to retire, or idle lanes while jobs remain)
       const unsigned long long work = __ballot(is_work_desc(cur));
@@ -948,6 +970,8 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
     }
 
     // ================= finish: rays whose traversal ended =================
+    RT_MARK("finish");
+    if (STATS && A.wave_log) wl_tmark = __builtin_readcyclecounter();
     if (cur == DESC_DONE) {
       const bool found = (flags & F_FOUND) != 0u;
       HitRec h; h.dist = RT_LARGE_FLOAT; h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0;
@@ -990,6 +1014,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
         cur = DESC_IDLE;
       }
     }
+    if (STATS && A.wave_log) wl_tfin += __builtin_readcyclecounter() - wl_tmark;
   }
 #undef CTX
 
@@ -998,7 +1023,8 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     for (int o = 32; o > 0; o >>= 1) wl_no23 += __shfl_down(wl_no23, o);   // node steps served from the LDS image, all lanes
     if (lane == 0) {
-      unsigned long long* w = A.wave_log + 13ull * (blockIdx.x * (uint32_t)WG_WAVES + (threadIdx.x >> 6));
+      unsigned long long* w = A.wave_log + 16ull * (blockIdx.x * (uint32_t)WG_WAVES + (threadIdx.x >> 6));
+      w[13] = wl_tf; w[14] = wl_tfin; w[15] = 0;
       w[0] = t_first; w[1] = wall_clock64(); w[2] = s; w[8] = wl_no23; w[9] = wl_no3; w[10] = wl_tn; w[11] = wl_tl; w[12] = __builtin_readcyclecounter() - wl_tstart;
       w[3] = wl_iter; w[4] = wl_node_x; w[5] = wl_node_l; w[6] = wl_leaf_x; w[7] = wl_leaf_l;
     }
@@ -1867,8 +1893,8 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
 #define LAUNCH_T(ST, LD) do { \
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, false>, n)), dim3(RT_WG_THREADS), 0, s, a->dev, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X); } while (0)
-  if (stats_counters) { if (a->dev.exact_decode) LAUNCH_T(true, true); else LAUNCH_T(true, false); }
-  else                { if (a->dev.exact_decode) LAUNCH_T(false, true); else LAUNCH_T(false, false); }
+  if (stats_counters) { if (a->dev.exact_decode) LAUNCH_T(1, true); else LAUNCH_T(1, false); }
+  else                { if (a->dev.exact_decode) LAUNCH_T(0, true); else LAUNCH_T(0, false); }
 #undef LAUNCH_T
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -2009,7 +2035,7 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
 
 static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits, float* colors,
-                         unsigned long long* counters, bool stats, void* stream, unsigned long long* wave_log = nullptr,
+                         unsigned long long* counters, int stats, void* stream, unsigned long long* wave_log = nullptr,
                          const vxrt_ao_params_t* ao = nullptr, uint32_t* unoccluded = nullptr, uint32_t stride = 1) {
   if (!a || !params || !dst) return -1;
   if (ao && (stats || shadow)) return -1;
@@ -2127,8 +2153,9 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<J, ST, LD, false>, A.total)), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, s, sc, p, X); } while (0)
 #define LAUNCH_PD(J, ST) do { if (sc.exact_decode) LAUNCH_P(J, ST, true); else LAUNCH_P(J, ST, false); } while (0)
-  if (stats) { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, true); else LAUNCH_PD(JOB_RENDER, true); }
-  else       { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, false); else LAUNCH_PD(JOB_RENDER, false); }
+  if (stats == 2)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 2); else LAUNCH_PD(JOB_RENDER, 2); }
+  else if (stats)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 1); else LAUNCH_PD(JOB_RENDER, 1); }
+  else             { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 0); else LAUNCH_PD(JOB_RENDER, 0); }
 #undef LAUNCH_PD
 #undef LAUNCH_P
   if (lpt) {
@@ -2183,13 +2210,22 @@ int vxrt_render_stats(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint
   return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream);
 }
 
+// vxrt_render_stats for the traversal the TIMED kernel performs: occlusion rays of a frame visit children in slot order (the
+// result is a boolean, the order cannot change it) and idle lanes test a leaf's second triangle, so node / triangle fetch
+// counts differ from the reference-order counts of vxrt_render_stats; both are reported next to each other (bench.py)
+int vxrt_render_stats_timed(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                            const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
+                            unsigned long long* counters, void* stream) {
+  return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, 2, stream);
+}
+
 // diagnostic: vxrt_render_stats that also logs, per wavefront of the main traversal launch, the first
 // and last 100 MHz clock and the number of rays it started (wave_log: device u64[13 * waves], waves =
 // 4 * blocks of the launch; 13 * 4 * 8 * 256 entries are always enough)
 int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst,
                          unsigned long long* counters, unsigned long long* wave_log, void* stream) {
-  return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, true, stream, wave_log);
+  return render_common(accel, width, height, y0, y1, params, shadow, dst, nullptr, nullptr, counters, 2, stream, wave_log);   // the timed traversal
 }
 
 int vxrt_render_diffuse_bounce(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,

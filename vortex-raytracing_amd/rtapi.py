@@ -183,12 +183,16 @@ def algorithmic_bytes(c):
             + (64 + 88) * c["shaded_hits"] + 4 * c["textured_hits"] + 4 * c["pixels"])
 
 
-def render_stats(accel, width, height, y0, y1, params, dst_ptr, shadow=0, stream=None):
-    """Runs the counting build of the render kernels once; returns the counters + algorithmic bytes."""
+def render_stats(accel, width, height, y0, y1, params, dst_ptr, shadow=0, stream=None, timed=False):
+    """Runs the counting build of the render kernels once; returns the counters + algorithmic bytes.  timed=True counts the
+    traversal the timed kernel performs (unordered occlusion rays, leaf helpers) instead of the reference-order one."""
     import torch
     cnt = torch.zeros(8, dtype=torch.int64, device="cuda:%d" % torch.cuda.current_device())
-    check(_lib().vxrt_render_stats(accel, width, height, y0, y1, C.byref(params), int(shadow), dst_ptr,
-                                   cnt.data_ptr(), stream), "vxrt_render_stats")
+    L = _lib()
+    fn = L.vxrt_render_stats_timed if timed else L.vxrt_render_stats
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    check(fn(accel, width, height, y0, y1, C.byref(params), int(shadow), dst_ptr, cnt.data_ptr(), stream), "vxrt_render_stats")
     torch.cuda.synchronize()
     c = dict(zip(STAT_KEYS, [int(v) for v in cnt[:7].tolist()]))
     c["bytes"] = algorithmic_bytes(c)
