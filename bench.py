@@ -367,9 +367,10 @@ def main():
                 "kernel": "rt_persistent_kernel<JOB_RENDER%s> (+ EXACT launches + rt_shade_kernel)" % ("_SHADOW" if shadow else ""),
                 "kernel_ms": round(kern_ms, 4), "kernel_ms_overlapped": round(ovl_ms, 4), "kernel_ms_isolated": round(iso_ms, 4),
                 "frames_in_flight": nfl,
-                "why_valu": "the scene is cache-resident (measured HBM traffic = a few % of the HBM peak) and every change to the memory path measured neutral "
-                            "(LDS-staged top of the tree serves 39 % of the node steps, +0 %); the kernel's time follows its VALU cycles: per-opcode SIMD cycles "
-                            "measured with tools/calibrate_valu.py (add/sub/mul/fma/mov/and/xor 2.2; cmp/cndmask/min/max/cvt_ubyte/lshl 4.1; rcp 8.1 per wave64 instruction)"}
+                "why_valu": "the scene is cache-resident (measured HBM traffic = a few % of the HBM peak) and relieving the memory path measured neutral (LDS-staged "
+                            "top of the tree: 39 % of node steps from LDS, -17 % vector-memory instructions, +0 %: profiles/r02_b_lds_top_counters.txt); what moves the time "
+                            "is the number of VALU instructions.  Roof: one wave64 VALU instruction per 2.2 SIMD cycles (measured, tools/calibrate_valu.py: 1,100 G/s "
+                            "over 1,024 SIMDs, for add/mul/fma/mov streams and for their 1:1 mixes with the cmp/cndmask/min/max/cvt class that alone sustains one per 4.1)"}
         if prof and world == 1 and W == 1920 and H == 1080 and a.level == 8 and shadow:
             # profile constants of THIS workload (deterministic instruction counts per frame), source named in the file
             cyc = prof["valu_simd_cycles_per_frame"]            # sum over instruction classes of count x measured cycles
@@ -377,6 +378,7 @@ def main():
             roof.update({"achieved": round(ach, 1), "frac": round(ach / (SIMDS * CLOCK_GHZ), 4),
                          "frac_isolated": round(cyc / (iso_ms * 1e-3) / 1e9 / (SIMDS * CLOCK_GHZ), 4),
                          "valu_simd_cycles_per_frame": cyc, "valu_instr_per_frame": prof.get("valu_instr_per_frame"),
+                         "valu_Ginstr_s": round(prof.get("valu_instr_per_frame", 0) / (kern_ms * 1e-3) / 1e9, 1), "valu_peak_Ginstr_s_measured": prof.get("valu_peak_Ginstr_s_measured"),
                          "valu_source": prof.get("source"), "valu_pricing": prof.get("pricing")})
             roof["traffic"] = prof.get("hbm_bytes_per_frame")
             roof["traffic_source"] = prof.get("hbm_source")

@@ -302,7 +302,8 @@ int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, u
                          unsigned long long* counters, unsigned long long* wave_log, void* stream);
 
 /* Trace n rays (6 floats each: origin, direction) read from HBM, write n hit records.
- * tmax: optional per-ray upper bound (NULL = 1e30). */
+ * tmax: optional per-ray upper bound (NULL = 1e30); a bound above 1e30 is taken as 1e30 (the reference's hit.dist never
+ * exceeds it: rt_traversal.h:7,44-52). */
 int vxrt_trace(vxrt_accel_t* accel, const float* rays, uint64_t n, const float* tmax,
                vxrt_hit_t* hits, int mode, void* stream);
 

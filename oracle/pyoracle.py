@@ -288,12 +288,22 @@ class Image:
             self.mem[o:o + b.size] = b
 
 
+def _tmax(tmax):
+    """Per-ray bounds as the C ABI defines them (include/vortex_hip.h, vxrt_trace): a bound above 1e30 is 1e30 -- the reference
+    reports a missed box as 1e30 (rt_traversal.cpp:338) and relies on `d < hit.dist` (<= 1e30) to drop it."""
+    if tmax is None:
+        return None
+    t = np.ascontiguousarray(tmax, np.float32).copy()
+    t[t > np.float32(1e30)] = np.float32(1e30)
+    return t
+
+
 def trace_faithful(scene, rays, tmax=None, any_hit=False):
     rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
     img = scene if isinstance(scene, Image) else Image(scene)
     out = np.zeros(len(rays), HIT_DTYPE)
     st = OrcStats()
-    tm = np.ascontiguousarray(tmax, np.float32) if tmax is not None else None
+    tm = _tmax(tmax)
     orc().orc_trace_faithful(_p(img.mem), img.mem.size, img.off["tlas"], img.off["blas"], img.off["bvh"], img.off["tri"],
                              _p(rays), len(rays), _p(tm), _p(out), C.byref(st), int(any_hit))
     return out, st.as_dict()
@@ -316,7 +326,7 @@ def trace_canonical(scene, rays, tmax=None, any_hit=False):
     rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
     out = np.zeros(len(rays), HIT_DTYPE)
     st = OrcStats()
-    tm = np.ascontiguousarray(tmax, np.float32) if tmax is not None else None
+    tm = _tmax(tmax)
     b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("tlas", "blas", "bvh", "tri")}
     orc().orc_trace_canonical(_p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(rays), len(rays), _p(tm), _p(out),
                               C.byref(st), int(any_hit))

@@ -31,16 +31,24 @@ OPS = [(0, "v_fma_f32"), (1, "v_pk_fma_f32"), (2, "v_add_f32"), (3, "v_cndmask_b
        (22, "v_fmac_f32"), (23, "v_mul_lo_u32"), (24, "v_perm_b32"), (25, "v_cndmask_b32 (vcc set by s_mov before the loop)"), (26, "v_ashrrev_i32"),
        (27, "v_min_u32"), (28, "v_lshl_or_b32"), (29, "v_and_or_b32"), (30, "v_pk_mul_f32"), (31, "v_pk_add_f32"),
        (32, "v_cndmask_b32_e64 with vcc as the explicit mask"), (33, "v_cndmask_b32 (vcc) alternating with v_add_f32"),
-       (34, "v_cndmask_b32 (vcc), destination != sources"), (35, "1 v_cndmask_b32 (vcc) per 7 v_add_f32")]
+       (34, "v_cndmask_b32 (vcc), destination != sources"), (35, "1 v_cndmask_b32 (vcc) per 7 v_add_f32"),
+       (36, "v_cvt_f32_f16"), (37, "v_fma_mix_f32 (f16 source)"), (38, "v_cvt_f32_u32"), (39, "v_cvt_f32_ubyte0"), (40, "v_lshrrev_b32"), (41, "v_bfe_u32"),
+       (42, "v_add3_u32"), (43, "v_mad_u32_u24"), (44, "v_cvt_f32_u32_sdwa (byte select)"), (45, "v_cmp_lt_i32 -> vcc"), (46, "v_sub_u32"), (47, "v_min_i32"),
+       (48, "MIX 1:1 v_add_f32 / v_max_f32"), (49, "MIX 1:1 v_fma_f32 / v_cvt_f32_ubyte1"), (50, "MIX 1:1 v_add_f32 / v_cndmask_b32_e64"),
+       (51, "MIX 1:1 v_add_f32 / v_cmp_lt_f32_e64"), (52, "MIX 3:1 v_add_f32 / v_max_f32"), (53, "MIX 3:1 v_add_f32 / v_rcp_f32")]
 if "--only-new" in sys.argv:
     OPS = [o for o in OPS if o[0] in (2, 3, 32, 33, 34, 35)]
+if "--mix" in sys.argv:
+    OPS = [o for o in OPS if o[0] >= 48 or o[0] in (2, 12)]
+if "--set3" in sys.argv:
+    OPS = [o for o in OPS if o[0] >= 36]
 if quick:
     OPS = OPS[:2]
 out = torch.zeros(8 * CUS * 256, dtype=torch.float32, device="cuda:0")
 s = torch.cuda.current_stream().cuda_stream
 best = {}
 for op, name in OPS:
-    for wps in ((1, 2, 4, 6, 8) if op < 1 else (6,)):
+    for wps in ((1, 2, 4, 6, 8) if op < 1 else ((1, 2, 6) if op >= 48 else (6,))):
         blocks = CUS * wps
         clocks = torch.zeros(blocks * 4 * 2, dtype=torch.int64, device="cuda:0")
         for _ in range(2):

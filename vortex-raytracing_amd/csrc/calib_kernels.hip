@@ -14,7 +14,9 @@ enum { OP_FMA = 0, OP_PK_FMA = 1, OP_ADD = 2, OP_CNDMASK = 3, OP_CVT_UBYTE = 4, 
        OP_CMP_VCC = 9, OP_CMP_SGPR = 10, OP_MUL = 11, OP_MAX = 12, OP_AND = 13, OP_CNDMASK_CONST = 14, OP_MIN = 15, OP_XOR = 16, OP_BFI = 17, OP_SUB = 18,
        OP_LSHL = 19, OP_ADD_U32 = 20, OP_MED3 = 21, OP_FMAC = 22, OP_MUL_LO = 23, OP_PERM = 24, OP_CNDMASK_VCC_SET = 25, OP_ASHR = 26, OP_MIN_U32 = 27,
        OP_LSHL_OR = 28, OP_AND_OR = 29, OP_PK_MUL = 30, OP_PK_ADD = 31, OP_CNDMASK_E64_VCC = 32, OP_CNDMASK_VCC_ALT_ADD = 33, OP_CNDMASK_VCC_DISTINCT = 34,
-       OP_CNDMASK_VCC_1OF8 = 35, OP_COUNT = 36 };
+       OP_CNDMASK_VCC_1OF8 = 35, OP_CVT_F32_F16 = 36, OP_FMA_MIX = 37, OP_CVT_F32_U32 = 38, OP_CVT_UBYTE0 = 39,
+       OP_LSHR = 40, OP_BFE = 41, OP_ADD3 = 42, OP_MAD_U24 = 43, OP_CVT_SDWA = 44, OP_CMP_I32 = 45, OP_SUB_U32 = 46, OP_MIN_I32 = 47, OP_MIX_ADD_MAX = 48, OP_MIX_FMA_CVT = 49, OP_MIX_ADD_CND64 = 50,
+       OP_MIX_ADD_CMP = 51, OP_MIX_3ADD_1MAX = 52, OP_MIX_ADD_RCP = 53, OP_COUNT = 54 };
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
@@ -63,6 +65,24 @@ __global__ __launch_bounds__(256) void vxcal_kernel(float* __restrict__ out, uns
         if (OP == OP_CNDMASK_VCC_ALT_ADD) { if (k & 1) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(c)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c)); }
         if (OP == OP_CNDMASK_VCC_DISTINCT) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(b[k]) : "v"(a[k]), "v"(c));
         if (OP == OP_CNDMASK_VCC_1OF8) { if ((k & 7) == 0) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(c)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c)); }
+        if (OP == OP_CVT_F32_F16) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a[k]));
+        if (OP == OP_FMA_MIX) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(a[k]) : "v"(m), "v"(c));
+        if (OP == OP_CVT_F32_U32) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[k]));
+        if (OP == OP_CVT_UBYTE0) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(a[k]));
+        if (OP == OP_LSHR) asm volatile("v_lshrrev_b32 %0, 8, %0" : "+v"(a[k]));
+        if (OP == OP_BFE) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a[k]));
+        if (OP == OP_ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c));
+        if (OP == OP_MAD_U24) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c));
+        if (OP == OP_CVT_SDWA) asm volatile("v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "+v"(a[k]));
+        if (OP == OP_CMP_I32) asm volatile("v_cmp_lt_i32 vcc, %0, %1" : : "v"(a[k]), "v"(c) : "vcc");
+        if (OP == OP_SUB_U32) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+        if (OP == OP_MIN_I32) asm volatile("v_min_i32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+        if (OP == OP_MIX_ADD_MAX) { if (k & 1) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[k]) : "v"(m)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c)); }
+        if (OP == OP_MIX_FMA_CVT) { if (k & 1) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(a[k])); else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c)); }
+        if (OP == OP_MIX_ADD_CND64) { if (k & 1) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[k]) : "v"(c), "s"(mask)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c)); }
+        if (OP == OP_MIX_ADD_CMP) { if (k & 1) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(mask2) : "v"(a[k]), "v"(c)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c)); }
+        if (OP == OP_MIX_3ADD_1MAX) { if ((k & 3) == 3) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[k]) : "v"(m)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c)); }
+        if (OP == OP_MIX_ADD_RCP) { if ((k & 3) == 3) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[k])); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c)); }
         if (OP == OP_CNDMASK_CONST) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[k]) : "v"(c), "s"(0x5555555555555555ull));
       }
       if (OP == OP_PK_MUL || OP == OP_PK_ADD) {
@@ -151,6 +171,24 @@ int vxcal_valu_loop(int op, uint32_t blocks, uint32_t n_iter, float* out, unsign
     case 33: hipLaunchKernelGGL(vxcal_kernel<33>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
     case 34: hipLaunchKernelGGL(vxcal_kernel<34>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
     case 35: hipLaunchKernelGGL(vxcal_kernel<35>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 36: hipLaunchKernelGGL(vxcal_kernel<36>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 37: hipLaunchKernelGGL(vxcal_kernel<37>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 38: hipLaunchKernelGGL(vxcal_kernel<38>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 39: hipLaunchKernelGGL(vxcal_kernel<39>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 40: hipLaunchKernelGGL(vxcal_kernel<40>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 41: hipLaunchKernelGGL(vxcal_kernel<41>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 42: hipLaunchKernelGGL(vxcal_kernel<42>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 43: hipLaunchKernelGGL(vxcal_kernel<43>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 44: hipLaunchKernelGGL(vxcal_kernel<44>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 45: hipLaunchKernelGGL(vxcal_kernel<45>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 46: hipLaunchKernelGGL(vxcal_kernel<46>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 47: hipLaunchKernelGGL(vxcal_kernel<47>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 48: hipLaunchKernelGGL(vxcal_kernel<48>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 49: hipLaunchKernelGGL(vxcal_kernel<49>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 50: hipLaunchKernelGGL(vxcal_kernel<50>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 51: hipLaunchKernelGGL(vxcal_kernel<51>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 52: hipLaunchKernelGGL(vxcal_kernel<52>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
+    case 53: hipLaunchKernelGGL(vxcal_kernel<53>, dim3(blocks), dim3(256), 0, s, out, clocks, n_iter, m, c); break;
     default: return -1;
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;

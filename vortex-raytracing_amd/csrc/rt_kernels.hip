@@ -380,9 +380,6 @@ __device__ __forceinline__ void generate_ray(float u, float v,
   dx = vx * inv; dy = vy * inv; dz = vz * inv;
 }
 
-#ifndef RT_LEAF_HELPERS
-#define RT_LEAF_HELPERS 1   // 1: render jobs (+1.5 %), 2: ray-buffer jobs too (no gain there: they prefetch instead)
-#endif
 #ifndef RT_TRI_PREFETCH
 #define RT_TRI_PREFETCH 1
 #endif
@@ -436,6 +433,10 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #ifndef LDS_STACK
 #define LDS_STACK 8         // stack levels kept in LDS per lane (4 KiB per wavefront); deeper ones go to scratch
 #endif
+#ifndef RT_NODE_V2
+#define RT_NODE_V2 0        // 1: alternative node step (children ranked by float subtraction + sign shift and scattered to the LDS stack by
+#endif                      // rank instead of a compare/select sorting network + register-cached stack top).  Bit-equal results (all GPU
+                            // tests pass with it); measured 2.5 % SLOWER (profiles/r02_c_node_v2.txt), so off: DESIGN.md s5
 #ifndef RT_WG_WAVES
 #define RT_WG_WAVES 4       // wavefronts per workgroup of the persistent kernels (the staged top of the tree is shared by them)
 #endif
@@ -492,6 +493,37 @@ struct PersistArgs {
   unsigned long long* wave_log;   // STATS only, optional: 16 u64 per wavefront (see vxrt_render_wave_log in the header)
 };
 
+// Domain of the fast (non-EXACT) traversal: every component of 1/d finite, non-zero and at most 2^64 in magnitude, every origin
+// component at most 2^60.  The accel build holds node planes to 2^60 as well (else the scene runs the LDEXP instantiation), so
+// a slab value (plane - o) * (1/d) stays below 2^125: finite, never NaN.  Rays outside go to the EXACT launch, which evaluates
+// the reference's min/max chains literally.  (Comparisons with NaN are false, so NaN / inf components fail these tests.)
+#define RT_FAST_INV_MAX 0x1p+64f
+#define RT_FAST_POS_MAX 0x1p+60f
+__device__ __forceinline__ bool ray_in_fast_domain(float ox, float oy, float oz, float ix, float iy, float iz) {
+  return fabsf(ix) <= RT_FAST_INV_MAX && fabsf(iy) <= RT_FAST_INV_MAX && fabsf(iz) <= RT_FAST_INV_MAX && ix != 0.0f && iy != 0.0f && iz != 0.0f &&
+         fabsf(ox) <= RT_FAST_POS_MAX && fabsf(oy) <= RT_FAST_POS_MAX && fabsf(oz) <= RT_FAST_POS_MAX;
+}
+
+// V2 node step, slab test of child K on sign-selected plane words (nw = near x, y, z; fw = far x, y, z; one byte per child):
+// the arithmetic of child_box's fast form, returning both interval ends.
+template <int K>
+__device__ __forceinline__ void child_slab(const uint32_t* nw, const uint32_t* fw, float px, float py, float pz, float sx, float sy, float sz,
+                                           float rox, float roy, float roz, float rix, float riy, float riz, float& tmin, float& tmax) {
+  const float ax = __fmaf_rn(qbyte<K>(nw[0]), sx, px), ay = __fmaf_rn(qbyte<K>(nw[1]), sy, py), az = __fmaf_rn(qbyte<K>(nw[2]), sz, pz);
+  const float bx = __fmaf_rn(qbyte<K>(fw[0]), sx, px), by = __fmaf_rn(qbyte<K>(fw[1]), sy, py), bz = __fmaf_rn(qbyte<K>(fw[2]), sz, pz);
+  const float tx1 = (ax - rox) * rix, tx2 = (bx - rox) * rix;
+  const float ty1 = (ay - roy) * riy, ty2 = (by - roy) * riy;
+  const float tz1 = (az - roz) * riz, tz2 = (bz - roz) * riz;
+  tmin = fmaxf(fmaxf(tx1, ty1), tz1);
+  tmax = fminf(fminf(tx2, ty2), tz2);
+}
+// -1 if a < b else 0, for finite a, b (and a or b = +inf, not both): the sign of the float difference -- two full-rate VALU
+// instructions (v_sub_f32, v_ashrrev_i32) where a compare + select takes two half-rate ones (profiles/r02_valu_calibration.txt)
+__device__ __forceinline__ int lt_mask(float a, float b) { return __float_as_int(a - b) >> 31; }
+// max of two values neither of which is a NaN: one v_max_f32 (fmaxf adds a canonicalising v_max_f32 x, x for a signalling NaN the
+// compiler cannot rule out)
+__device__ __forceinline__ float vmax_nonan(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 __device__ __forceinline__ bool is_node_desc(uint32_t d) { return d < 0x80000000u; }
 __device__ __forceinline__ bool is_leaf_desc(uint32_t d) { return (d >> 30) == DK_LEAF; }
 __device__ __forceinline__ bool is_inst_desc(uint32_t d) { return d >= 0xC0000000u && d < DESC_IDLE; }
@@ -517,6 +549,10 @@ template <int JOB, int STATS, bool LDEXP, bool EXACT>
 __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
   constexpr int WG_WAVES = EXACT ? 4 : RT_WG_WAVES;
   constexpr bool USE_TOP = RT_TOP_NODES > 0 && !EXACT && !LDEXP;   // (the ldexp decode reads exponents from the reference node by index)
+  // V2 node step: only where every slab value is finite (bounded scene -- checked by the accel build, which selects the LDEXP
+  // instantiation otherwise -- and rays inside the bounds checked in start_ray / enter_instance), so that the sign of a float
+  // difference IS the comparison
+  constexpr bool V2 = RT_NODE_V2 && !EXACT && !LDEXP;
   constexpr uint32_t DEAD_MAX = JOB == JOB_TRACE ? RT_TRACE_DEAD_MAX : RT_DEAD_MAX;
   // render-with-shadow jobs: retire finished primary rays (their lanes continue with the occlusion ray
   // of the same pixel - same traversal code, so no phase mixing) before the whole tile is done
@@ -527,9 +563,6 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   const uint32_t per_shard = (EXACT || A.total_dev) ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
 
   __shared__ uint2 s_stk[WG_WAVES][LDS_STACK][64];   // stack levels below the register top, 8 B entries, conflict-free rows
-  __shared__ uint8_t s_pair[WG_WAVES][2][64];        // leaf helpers (RT_LEAF_HELPERS): owner lane by rank, helper lane by rank
-  uint8_t* const pair_o = &s_pair[threadIdx.x >> 6][0][0];
-  uint8_t* const pair_h = &s_pair[threadIdx.x >> 6][1][0];
   // 0-2 active dir, 3-4 hit bx/by (bz = 1 - bx - by is re-derived when the record is written), 5 distance of the pixel's
   // primary hit while its occlusion ray is traced, 6 hit blasIdx, 7 hit triIdx, 8 blasIdx
   __shared__ uint32_t s_ctx[WG_WAVES][9][64];
@@ -551,7 +584,11 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   float arx = 0, ary = 0, arz = 0, aix = 0, aiy = 0, aiz = 0;   // active ray: origin, 1/direction
   float hitd = 0, path_m = 0, tos_m = 0;
   uint32_t cur = DESC_IDLE, tos_d = DESC_DONE, job = 0, flags = 0;
-  int sp = 0;                     // entries below the register top (LDS, then scratch)
+  int sp = 0;                     // V2: entries on the stack; else: entries below the register top (LDS, then scratch)
+  // V2 keeps the stack as two planes in the same LDS block (descriptors, then path maxima): rank-addressed scatter writes need no
+  // register pairs, and there is no register-cached top to shuffle
+  uint32_t* const stk_d = (uint32_t*)&s_stk[threadIdx.x >> 6][0][0] + lane;
+  float* const stk_m = (float*)stk_d + LDS_STACK * 64;
   uint32_t ovf_d[RT_STACK_ENTRIES];
   float ovf_m[RT_STACK_ENTRIES];
   // wave-uniform job-queue state
@@ -624,8 +661,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
     const float cdy = m10 * dx + m11 * dy + m12 * dz;
     const float cdz = m20 * dx + m21 * dy + m22 * dz;
     aix = 1.0f / cdx; aiy = 1.0f / cdy; aiz = 1.0f / cdz;
-    const bool s2 = (aix - aix == 0.0f) && (aiy - aiy == 0.0f) && (aiz - aiz == 0.0f) && aix != 0.0f && aiy != 0.0f && aiz != 0.0f &&
-                    (arx - arx == 0.0f) && (ary - ary == 0.0f) && (arz - arz == 0.0f);
+    const bool s2 = ray_in_fast_domain(arx, ary, arz, aix, aiy, aiz);
     if (!EXACT && !s2) { defer(true); return; }   // object-space ray can produce NaN slabs: restart it in the EXACT launch
     flags &= ~F_WORLD;
     CTX(0) = __float_as_uint(cdx); CTX(1) = __float_as_uint(cdy); CTX(2) = __float_as_uint(cdz);
@@ -636,9 +672,8 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   auto start_ray = [&](float ox, float oy, float oz, float dx, float dy, float dz, float tmax_, bool any_) {
     arx = ox; ary = oy; arz = oz;
     aix = 1.0f / dx; aiy = 1.0f / dy; aiz = 1.0f / dz;
-    // the fast slab forms are exact only if no slab product can be NaN (finite non-zero 1/d, finite origin)
-    const bool safe = (aix - aix == 0.0f) && (aiy - aiy == 0.0f) && (aiz - aiz == 0.0f) && aix != 0.0f && aiy != 0.0f && aiz != 0.0f &&
-                      (ox - ox == 0.0f) && (oy - oy == 0.0f) && (oz - oz == 0.0f);
+    // the fast slab forms are exact only if no slab product can be NaN or overflow (see ray_in_fast_domain)
+    const bool safe = ray_in_fast_domain(ox, oy, oz, aix, aiy, aiz);
     flags = (flags & (F_SHADOW | F_RESUMED)) | F_WORLD | (any_ ? F_ANYHIT : 0u);
     if (!EXACT && !safe) {
       // camera rays with a zero direction component are known before the launch (u == 0 or v == 0): the
@@ -646,14 +681,23 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
       if (JOB != JOB_TRACE && !(flags & F_SHADOW)) cur = DESC_IDLE; else defer(false);
       return;
     }
-    hitd = tmax_; path_m = -__builtin_inff(); sp = 0; tos_d = DESC_DONE;
+    hitd = tmax_ > RT_LARGE_FLOAT ? RT_LARGE_FLOAT : tmax_;   // (a bound above 1e30 is 1e30: a missed box reports 1e30, rt_traversal.cpp:338, and must stay filtered by `d < hit.dist`)
+    path_m = -__builtin_inff(); sp = 0; tos_d = DESC_DONE;
     cur = root_desc;
     nrays++;
     // single-instance scenes (the reference's default): the TLAS root is the instance leaf, enter it
     // right away with the ray at hand instead of re-deriving it in the instance step
     if (is_inst_desc(root_desc)) enter_instance(root_desc & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz);
   };
+  // (the scratch part of the stack through volatile pointers: the compiler must not speculate its loads into the common path)
+  volatile uint32_t* const vovf_d = ovf_d;
+  volatile float* const vovf_m = ovf_m;
+  auto stk_write = [&](int slot, uint32_t d, float m) {   // V2, general form
+    if (slot < LDS_STACK) { stk_d[slot * 64] = d; stk_m[slot * 64] = m; }
+    else { vovf_d[slot - LDS_STACK] = d; vovf_m[slot - LDS_STACK] = m; }
+  };
   auto push = [&](uint32_t d, float m) {
+    if (V2) { stk_write(sp, d, m); ++sp; return; }
     if (tos_d != DESC_DONE) {
       if (sp < LDS_STACK) lstk[sp * 64] = make_uint2(tos_d, __float_as_uint(tos_m));
       else { ovf_d[sp - LDS_STACK] = tos_d; ovf_m[sp - LDS_STACK] = tos_m; }
@@ -665,6 +709,25 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   // or DESC_DONE when its stack is exhausted.  The refill of the register top from LDS is not waited for.
   auto pop_next = [&]() {
     cur = DESC_DONE;
+    if (V2) {
+      if (!__any(sp > LDS_STACK)) {   // wave-uniform: every entry any lane can pop is in LDS (the common case by far)
+        while (sp > 0) {
+          --sp;
+          const uint32_t d = stk_d[sp * 64];
+          const float m = stk_m[sp * 64];
+          if (m < hitd) { cur = d; path_m = m; break; }
+        }
+        return;
+      }
+      while (sp > 0) {
+        --sp;
+        uint32_t d; float m;
+        if (sp < LDS_STACK) { d = stk_d[sp * 64]; m = stk_m[sp * 64]; }
+        else { d = vovf_d[sp - LDS_STACK]; m = vovf_m[sp - LDS_STACK]; }
+        if (m < hitd) { cur = d; path_m = m; break; }
+      }
+      return;
+    }
     while (tos_d != DESC_DONE) {
       const uint32_t d = tos_d;
       const float m = tos_m;
@@ -795,6 +858,81 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
         const uint32_t* ref_node = nullptr;
         if (LDEXP) ref_node = top ? sc.ref_tlas + (size_t)ni * RT_NODE_DWORDS : sc.ref_bvh + (size_t)(ni - sc.n_tlas) * RT_NODE_DWORDS;
         if (STATS) fx.node++;
+        if (V2) {
+          // ---- V2 node step.  Same values as eval_children's fast form, then:
+          //  * D_k = entry distance of child k, +inf if it is not to be visited (rt_traversal.cpp:60,71 and :338)
+          //  * r_k = how many children are visited before child k: near to far, equal distance -> higher index first (the order
+          //    of the far-to-near std::sort of :76-78 read from the back).  From the sign of the six pairwise differences.
+          //  * all children to visit go to the stack at sp + (n - 1 - r_k), the nearest on top, and the top is popped.
+          const float px = __uint_as_float(q0.x), py = __uint_as_float(q0.y), pz = __uint_as_float(q0.z);
+          const float sx = __uint_as_float(q0.w), sy = __uint_as_float(q3.z), sz = __uint_as_float(q3.w);
+          // near / far plane words by the sign of 1/d: swap lo and hi where the mask is all ones (xor swap, full-rate VALU)
+          const uint32_t mx = (uint32_t)(__float_as_int(aix) >> 31), my = (uint32_t)(__float_as_int(aiy) >> 31), mz = (uint32_t)(__float_as_int(aiz) >> 31);
+          const uint32_t dxw = (q1.x ^ q1.w) & mx, dyw = (q1.y ^ q2.x) & my, dzw = (q1.z ^ q2.y) & mz;
+          const uint32_t nw[3] = {q1.x ^ dxw, q1.y ^ dyw, q1.z ^ dzw};
+          const uint32_t fw[3] = {q1.w ^ dxw, q2.x ^ dyw, q2.y ^ dzw};
+          const uint32_t desc[4] = {q2.z, q2.w, q3.x, q3.y};
+          float tn[4], tf[4];
+          child_slab<0>(nw, fw, px, py, pz, sx, sy, sz, arx, ary, arz, aix, aiy, aiz, tn[0], tf[0]);
+          child_slab<1>(nw, fw, px, py, pz, sx, sy, sz, arx, ary, arz, aix, aiy, aiz, tn[1], tf[1]);
+          child_slab<2>(nw, fw, px, py, pz, sx, sy, sz, arx, ary, arz, aix, aiy, aiz, tn[2], tf[2]);
+          child_slab<3>(nw, fw, px, py, pz, sx, sy, sz, arx, ary, arz, aix, aiy, aiz, tn[3], tf[3]);
+          bool ok[4];
+          float D[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            ok[k] = !(tf[k] < tn[k] || tf[k] <= 0) && tn[k] < hitd && desc[k] != DESC_NONE;   // :327-338, :71, :60
+            D[k] = ok[k] ? tn[k] : __builtin_inff();
+          }
+          const int n = (int)ok[0] + (int)ok[1] + (int)ok[2] + (int)ok[3];
+          int r0, r1, r2, r3;
+          if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && STATS != 1 && __all((flags & F_ANYHIT) != 0u)) {
+            // occlusion rays of a frame only feed a boolean: any order reaches the same set of triangles, so children are taken in
+            // slot order (vxrt_trace's MODE_ANY, which returns the reference's FIRST accepted candidate, keeps the distance order)
+            r0 = 0; r1 = (int)ok[0]; r2 = r1 + (int)ok[1]; r3 = r2 + (int)ok[2];
+          } else {
+            // m_ij = -1 if child i is visited before child j (D_i < D_j), else 0 (D_j <= D_i: j first), i < j
+            const int m01 = lt_mask(D[0], D[1]), m02 = lt_mask(D[0], D[2]), m03 = lt_mask(D[0], D[3]);
+            const int m12 = lt_mask(D[1], D[2]), m13 = lt_mask(D[1], D[3]), m23 = lt_mask(D[2], D[3]);
+            r0 = 3 + m01 + m02 + m03;
+            r1 = 2 - m01 + m12 + m13;
+            r2 = 1 - m02 - m12 + m23;
+            r3 = 0 - m03 - m13 - m23;
+          }
+          if (!__any(sp + 4 > LDS_STACK)) {
+            // common case, wave-uniform: four free LDS slots above every lane's stack.  ALL four children are written, without
+            // predication, to the distinct slots sp + ((n - 1 - r_k) & 3): a child to visit (r_k < n) lands at sp + (n - 1 - r_k), far
+            // ones first and the nearest on top; the others (r_k >= n) land above the new top, where nothing is live
+            const int tn = n - 1;
+            uint32_t* const wd = stk_d + sp * 64;
+            float* const wm = stk_m + sp * 64;
+            const int o0 = (tn - r0) & 3, o1 = (tn - r1) & 3, o2 = (tn - r2) & 3, o3 = (tn - r3) & 3;
+            wd[o0 * 64] = desc[0]; wm[o0 * 64] = vmax_nonan(path_m, D[0]);
+            wd[o1 * 64] = desc[1]; wm[o1 * 64] = vmax_nonan(path_m, D[1]);
+            wd[o2 * 64] = desc[2]; wm[o2 * 64] = vmax_nonan(path_m, D[2]);
+            wd[o3 * 64] = desc[3]; wm[o3 * 64] = vmax_nonan(path_m, D[3]);
+            if (n != 0) {
+              // the top is the nearest child, its m = max(path_m, D) < hit.dist by construction: continue with it
+              cur = wd[tn * 64]; path_m = wm[tn * 64];
+              sp += tn;
+            } else {
+              pop_next();
+            }
+          } else {
+            if (n != 0) {
+              if (sp + n > LDS_STACK + RT_STACK_ENTRIES) atomicOr(A.status, STATUS_STACK_OVERFLOW);
+              else {
+                const int t = sp + n - 1;
+                if (ok[0]) stk_write(t - r0, desc[0], fmaxf(path_m, D[0]));
+                if (ok[1]) stk_write(t - r1, desc[1], fmaxf(path_m, D[1]));
+                if (ok[2]) stk_write(t - r2, desc[2], fmaxf(path_m, D[2]));
+                if (ok[3]) stk_write(t - r3, desc[3], fmaxf(path_m, D[3]));
+                sp += n;
+              }
+            }
+            pop_next();
+          }
+        } else {
         Cand c[4];
         eval_children<EXACT, LDEXP>(q0, q1, q2, q3, ref_node, arx, ary, arz, aix, aiy, aiz, hitd, c);
         if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && STATS != 1 && __all((flags & F_ANYHIT) != 0u)) {   // STATS keeps the reference's order, hence its fetch counts
@@ -830,6 +968,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
             pop_next();
           }
         }
+        }   // !V2
       }
       if (STATS && A.wave_log) { const unsigned long long t1 = __builtin_readcyclecounter(); wl_tn += t1 - wl_t0; wl_t0 = t1; }
       RT_MARK("inst");
@@ -847,8 +986,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
       if (leafm != 0ull && ((uint32_t)__popcll(leafm) >= (JOB == JOB_TRACE ? RT_TRACE_LEAF_MIN : RT_LEAF_MIN) || __ballot(is_node_desc(cur) || is_inst_desc(cur)) == 0ull)) {
         // ---- BLAS leaf (:123-161): triangles in index order, strict '<' ----
         if (STATS && A.wave_log) { ++wl_leaf_x; wl_leaf_l += (unsigned)__popcll(leafm); }
-        constexpr bool HELP = RT_LEAF_HELPERS && STATS != 1 && (JOB != JOB_TRACE || RT_LEAF_HELPERS > 1);   // (the counting build keeps the reference's triangle-test count)
-        if (!HELP) {
+        {
           if (is_leaf_desc(cur)) {
             if (STATS) fx.node++;
             uint32_t leftFirst = cur & LEAF_FIRST_MASK, triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
@@ -885,71 +1023,6 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
                 // the reference re-descends from the root with the shrunken hit.dist; if any box on the
                 // current path no longer passes `d < hit.dist` it abandons this subtree
                 if (!(path_m < hitd)) break;
-              }
-            }
-            if (stop) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
-            else pop_next();
-          }
-        } else {
-          // Lanes without a leaf (they did their node step already, or hold no ray) test the SECOND triangle of a lane that
-          // has one, in the same pass in which the owners test their first: the leaf body runs at ~18 of 64 lanes and leaves
-          // hold two triangles on average, so one pass replaces two.  ray_tri does not depend on hit.dist, and the owner
-          // applies the two results in index order with the reference's accept / abandon rules, so nothing changes.
-          // Owner -> helper: origin and first triangle by ds_bpermute, direction from the owner's LDS slots.
-          const bool owner = is_leaf_desc(cur);
-          uint32_t leftFirst = 0u, triCount = 0u;
-          if (owner) {
-            if (STATS) fx.node++;
-            leftFirst = cur & LEAF_FIRST_MASK; triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
-            if (triCount == 0u) {   // leaf with more than 15 triangles: range kept in the reference node
-              const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS;
-              leftFirst = rn[4]; triCount = rn[5];
-            }
-          }
-          const bool want = owner && triCount >= 2u;
-          const unsigned long long wantm = __ballot(want), freem = ~leafm;
-          const unsigned long long lt = (1ull << lane) - 1ull;
-          const uint32_t nw = (uint32_t)__popcll(wantm), nf = (uint32_t)__popcll(freem);
-          const uint32_t wr = (uint32_t)__popcll(wantm & lt), fr = (uint32_t)__popcll(freem & lt);
-          const bool served = want && wr < nf;
-          const bool helper = !owner && fr < nw;
-          if (served) pair_o[wr] = (uint8_t)lane;
-          if (helper) pair_h[fr] = (uint8_t)lane;
-          const int own = helper ? (int)pair_o[fr] : (int)lane;
-          const float tox = __shfl(arx, own), toy = __shfl(ary, own), toz = __shfl(arz, own);   // (all lanes take part)
-          const uint32_t tfirst = __shfl(leftFirst, own);
-          float p_d = RT_LARGE_FLOAT, p_bx = 0.f, p_by = 0.f, p_bz = 0.f;   // this lane's triangle of the common pass
-          if (owner || helper) {
-            const uint32_t* octx = &s_ctx[threadIdx.x >> 6][0][own];
-            const float cdx = __uint_as_float(octx[0]), cdy = __uint_as_float(octx[64]), cdz = __uint_as_float(octx[128]);
-            const float4* tp = sc.tri_w + (size_t)(tfirst + (helper ? 1u : 0u)) * 3;
-            const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-            p_d = ray_tri(tox, toy, toz, cdx, cdy, cdz, t0, t1, t2, p_bx, p_by, p_bz);
-            if (STATS) fx.tri++;   // (a helper's test counts even when the owner stops before using it)
-          }
-          const int hl = served ? (int)pair_h[wr] : (int)lane;
-          const float h_d = __shfl(p_d, hl), h_bx = __shfl(p_bx, hl), h_by = __shfl(p_by, hl), h_bz = __shfl(p_bz, hl);
-          if (owner) {
-            const float cdx = __uint_as_float(CTX(0)), cdy = __uint_as_float(CTX(1)), cdz = __uint_as_float(CTX(2));
-            bool stop = false;
-            for (uint32_t i = 0; i < triCount; ++i) {
-              const uint32_t triIdx = leftFirst + i;
-              float d, bx, by, bz;
-              if (i == 0u) { d = p_d; bx = p_bx; by = p_by; bz = p_bz; }
-              else if (i == 1u && served) { d = h_d; bx = h_bx; by = h_by; bz = h_bz; }
-              else {
-                const float4* tp = sc.tri_w + (size_t)triIdx * 3;
-                const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-                d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
-                if (STATS) fx.tri++;
-              }
-              if (d < hitd) {
-                hitd = d;
-                flags |= F_FOUND;
-                // (a frame's occlusion ray only feeds a boolean; slots 3-7 keep the pixel's primary hit meanwhile)
-                if (!(JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW))) { CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(6) = CTX(8); CTX(7) = triIdx; }
-                if (flags & F_ANYHIT) { stop = true; break; }
-                if (!(path_m < hitd)) break;   // abandon rule, as above
               }
             }
             if (stop) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
