@@ -1113,6 +1113,47 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   }
 }
 
+// Tile order for the next frame of a context: within each queue shard's band of tiles (a contiguous part of the
+// frame, whose tiles share BVH nodes in the L2 of the XCD that works on it), most expensive first; cost = 100 MHz
+// clocks the tile occupied its wavefront in the frame just traced.  A launch ends when its last tile ends, and a
+// wavefront only gets about five tiles of a 1080p frame: starting the expensive ones first leaves the cheap ones for
+// the tail.  One workgroup of 256 threads per shard, counting sort over 2048 monotone cost classes (5-bit exponent, 6-bit
+// mantissa) with a parallel scan.  Runs as the FIRST workgroups of the shading launch (rt_shade_kernel): as a launch of its
+// own between the traversal and the shading pass it sat on the critical path of a serial frame for 21 us, most of it one
+// thread scanning the 2048 counters (profiles/r02_d_exact_timeline.txt).
+// Measured and rejected: one global order dealt round robin to the shards (-4 %: loses the band -> XCD locality) and
+// bands cut at equal cost instead of equal size (-7 %: the measured cost of a tile includes the contention on its SIMD).
+__device__ void lpt_order_block(uint32_t shard, const uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
+                                uint32_t n_tiles, uint32_t tiles_per_shard, uint32_t* hist /* LDS, 2048 + 8 words */) {
+  const uint32_t lo = shard * tiles_per_shard;
+  const uint32_t hi = min(lo + tiles_per_shard, n_tiles);
+  if (lo >= hi) return;   // (block-uniform)
+  for (uint32_t i = threadIdx.x; i < 2048u; i += 256u) hist[i] = 0u;
+  __syncthreads();
+  auto cls = [](uint32_t c) -> uint32_t {
+    if (c < 64u) return c;                                  // exponents 0..5 collapse onto the small values
+    const uint32_t e = 31u - (uint32_t)__clz((int)c);       // 6..31
+    return ((e - 5u) << 6) | ((c >> (e - 6u)) & 63u);       // 64 .. 1727
+  };
+  for (uint32_t t = lo + threadIdx.x; t < hi; t += 256u) atomicAdd(&hist[2047u - cls(cost[t])], 1u);   // descending
+  __syncthreads();
+  // exclusive scan of the 2048 counters: 8 consecutive counters per thread, wavefront scan, then the four wavefront totals
+  uint32_t v[8], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { v[k] = hist[threadIdx.x * 8u + k]; sum += v[k]; }
+  uint32_t inc = sum;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += y; }
+  if (lane == 63u) hist[2048u + wave] = inc;
+  __syncthreads();
+  uint32_t base = inc - sum;
+  for (uint32_t w = 0; w < wave; ++w) base += hist[2048u + w];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { hist[threadIdx.x * 8u + k] = base; base += v[k]; }
+  __syncthreads();
+  for (uint32_t t = lo + threadIdx.x; t < hi; t += 256u) order[lo + atomicAdd(&hist[2047u - cls(cost[t])], 1u)] = t;
+}
+
 // Deferred shading pass: one thread per pixel of rows [y0,y1), x fastest, so hit records are read
 // and pixels written fully coalesced.
 template <bool STATS>
@@ -1120,12 +1161,18 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
                                                       uint32_t n_rows, const float* __restrict__ utab, const float* __restrict__ vtab,
                                                       const HitRec* __restrict__ hb, uint32_t* __restrict__ dst,
                                                       HitRec* __restrict__ hits, float* __restrict__ colors,
-                                                      unsigned long long* counters, uint32_t* __restrict__ ctl_reset) {
+                                                      unsigned long long* counters, uint32_t* __restrict__ ctl_reset,
+                                                      uint32_t lpt_blocks, const uint32_t* __restrict__ lpt_cost, uint32_t* __restrict__ lpt_order,
+                                                      uint32_t lpt_tiles, uint32_t lpt_per_shard) {
+  // the first lpt_blocks workgroups sort the frame's tiles by cost for the context's next frame (see lpt_order_block)
+  __shared__ uint32_t s_hist[2048 + 8];
+  if (blockIdx.x < lpt_blocks) { lpt_order_block(blockIdx.x, lpt_cost, lpt_order, lpt_tiles, lpt_per_shard, s_hist); return; }
+  const uint32_t blk = blockIdx.x - lpt_blocks;
   // last kernel of a frame: every user of the frame's control block (queue counters, deferral count)
   // has finished, so zero it here for the context's next frame instead of paying fill launches per frame
-  if (ctl_reset && blockIdx.x == 0)
+  if (ctl_reset && blk == 0)
     for (uint32_t i = threadIdx.x; i < CTL_DWORDS; i += 256u) ctl_reset[i] = 0u;
-  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  const uint64_t t = (uint64_t)blk * 256u + threadIdx.x;
   const uint64_t n = (uint64_t)W * n_rows;   // local rows of the window (its tile rows x 8; rows past y1 are skipped)
   unsigned ntex = 0, npix = 0;
   const uint32_t x = (uint32_t)(t % W), lr = (uint32_t)(t / W), y = frame_row(lr, y0, row_step);
@@ -1404,36 +1451,6 @@ __global__ __launch_bounds__(256) void rt_ao_final_kernel(uint64_t n, uint32_t W
   }
   const unsigned long long m = __ballot(hit);
   if (rays_traced && (threadIdx.x & 63u) == 0u && m) atomicAdd(rays_traced, (unsigned long long)__popcll(m) * spp);
-}
-
-// Tile order for the next frame of a context: within each queue shard's band of tiles (a contiguous part of the
-// frame, whose tiles share BVH nodes in the L2 of the XCD that works on it), most expensive first; cost = 100 MHz
-// clocks the tile occupied its wavefront in the frame just traced.  A launch ends when its last tile ends, and a
-// wavefront only gets about five tiles of a 1080p frame: starting the expensive ones first leaves the cheap ones for
-// the tail.  One workgroup per shard, counting sort over 2048 monotone cost classes (5-bit exponent, 6-bit mantissa).
-// Measured and rejected: one global order dealt round robin to the shards (-4 %: loses the band -> XCD locality) and
-// bands cut at equal cost instead of equal size (-7 %: the measured cost of a tile includes the contention on its SIMD).
-__global__ __launch_bounds__(1024) void lpt_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
-                                                       uint32_t n_tiles, uint32_t tiles_per_shard) {
-  __shared__ uint32_t hist[2048];
-  const uint32_t lo = blockIdx.x * tiles_per_shard;
-  const uint32_t hi = min(lo + tiles_per_shard, n_tiles);
-  if (lo >= hi) return;
-  for (uint32_t i = threadIdx.x; i < 2048u; i += 1024u) hist[i] = 0u;
-  __syncthreads();
-  auto cls = [](uint32_t c) -> uint32_t {
-    if (c < 64u) return c;                                  // exponents 0..5 collapse onto the small values
-    const uint32_t e = 31u - (uint32_t)__clz((int)c);       // 6..31
-    return ((e - 5u) << 6) | ((c >> (e - 6u)) & 63u);       // 64 .. 1727
-  };
-  for (uint32_t t = lo + threadIdx.x; t < hi; t += 1024u) atomicAdd(&hist[2047u - cls(cost[t])], 1u);   // descending
-  __syncthreads();
-  if (threadIdx.x == 0) {   // exclusive scan of 2048 counters: a few microseconds, once per frame and shard
-    uint32_t run = 0;
-    for (uint32_t i = 0; i < 2048u; ++i) { const uint32_t v = hist[i]; hist[i] = run; run += v; }
-  }
-  __syncthreads();
-  for (uint32_t t = lo + threadIdx.x; t < hi; t += 1024u) order[lo + atomicAdd(&hist[2047u - cls(cost[t])], 1u)] = t;
 }
 
 // One diffuse bounce (extension for BASELINE config 3; recipe in oracle/rt_oracle.c:orc_render_gi): the bounce rays are
@@ -1741,6 +1758,7 @@ struct FrameCtx {
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr;
   bool busy = false, inited = false;
+  hipStream_t last_stream = nullptr;
 };
 
 struct vxrt_accel {
@@ -1798,7 +1816,7 @@ static FrameCtx* acquire_ctx(vxrt_accel* a, hipStream_t s) {
     if (hipMemset(c.ctl, 0, CTL_DWORDS * sizeof(uint32_t)) != hipSuccess) return nullptr;
     c.inited = true;
   }
-  if (c.busy && hipStreamWaitEvent(s, c.ev_done, 0) != hipSuccess) return nullptr;
+  if (c.busy && c.last_stream != s && hipStreamWaitEvent(s, c.ev_done, 0) != hipSuccess) return nullptr;   // (same stream: already ordered)
   if (c.ctl_dirty) {
     if (hipMemsetAsync(c.ctl, 0, CTL_DWORDS * sizeof(uint32_t), s) != hipSuccess) return nullptr;
     c.ctl_dirty = false;
@@ -1808,7 +1826,7 @@ static FrameCtx* acquire_ctx(vxrt_accel* a, hipStream_t s) {
 
 static int release_ctx(FrameCtx* c, hipStream_t s) {
   if (hipEventRecord(c->ev_done, s) != hipSuccess) return -1;
-  c->busy = true;
+  c->busy = true; c->last_stream = s;
   return 0;
 }
 
@@ -2215,6 +2233,10 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
   c->ctl_dirty = true;   // until the shading pass that zeroes the block again is enqueued
   const bool side_launch = a->ap_count != 0;
+  // the a-priori EXACT launch needs a few workgroups (3,000 rays of a 1080p frame = 12); the main launch leaves that many slots
+  // free: a persistent grid that fills every CU (LDS) would otherwise keep them waiting until its first workgroups retire, and
+  // the frame would end on them (measured: 33 us after the main launch, profiles/r02_d_exact_timeline.txt)
+  const uint32_t side_wgs = side_launch ? std::min<uint32_t>(EXACT_GRID, (a->ap_count + 255u) / 256u) : 0u;
   hipStream_t side = c->side;
   if (side_launch) {
     if (hipEventRecord(c->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, c->ev_in, 0) != hipSuccess) return -1;
@@ -2222,8 +2244,8 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = a->ap_count;
   }
 #define LAUNCH_P(J, ST, LD) do { \
-    if (side_launch) hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(std::min<uint32_t>(EXACT_GRID, (a->ap_count + 255u) / 256u)), block, 0, side, sc, p, X0); \
-    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<J, ST, LD, false>, A.total)), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
+    if (side_launch) hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(side_wgs), block, 0, side, sc, p, X0); \
+    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false>), dim3(std::max<uint32_t>(1u, persistent_grid(rt_persistent_kernel<J, ST, LD, false>, A.total + (uint64_t)side_wgs * RT_WG_THREADS) - side_wgs)), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, s, sc, p, X); } while (0)
 #define LAUNCH_PD(J, ST) do { if (sc.exact_decode) LAUNCH_P(J, ST, true); else LAUNCH_P(J, ST, false); } while (0)
   if (stats == 2)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 2); else LAUNCH_PD(JOB_RENDER, 2); }
@@ -2231,10 +2253,9 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   else             { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 0); else LAUNCH_PD(JOB_RENDER, 0); }
 #undef LAUNCH_PD
 #undef LAUNCH_P
-  if (lpt) {
-    hipLaunchKernelGGL(lpt_order_kernel, dim3(QUEUE_SHARDS), dim3(1024), 0, s, (const uint32_t*)c->tile_cost, c->tile_order, n_tiles, A.per_shard >> 6);
-    c->lpt_valid = true;
-  }
+  // (the tile sort for the next frame rides in the shading launch; the AO / bounce tails have no such launch and skip it)
+  const bool lpt_sort = lpt && !ao && !(p.max_depth > 1 && a->max_reflectivity > 0.0f);
+  if (lpt && !lpt_sort) c->lpt_valid = false;
   if (side_launch) {
     if (hipEventRecord(c->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, c->ev_side, 0) != hipSuccess) return -1;
   }
@@ -2249,10 +2270,14 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     return release_ctx(c, s);
   }
   const uint64_t npx = (uint64_t)width * tiles_y * 8u;
-  dim3 sgrid((uint32_t)((npx + 255) / 256));
-  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl);
-  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl);
+  const uint32_t lpt_blocks = lpt_sort ? QUEUE_SHARDS : 0u;
+  dim3 sgrid((uint32_t)((npx + 255) / 256) + lpt_blocks);
+  if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl,
+                                lpt_blocks, (const uint32_t*)c->tile_cost, c->tile_order, n_tiles, A.per_shard >> 6);
+  else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl,
+                                lpt_blocks, (const uint32_t*)c->tile_cost, c->tile_order, n_tiles, A.per_shard >> 6);
   if (hipGetLastError() != hipSuccess) return -1;
+  if (lpt_sort) c->lpt_valid = true;
   c->ctl_dirty = false;
   return release_ctx(c, s);
 }
