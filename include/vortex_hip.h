@@ -307,6 +307,12 @@ int vxrt_render_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, u
 int vxrt_trace(vxrt_accel_t* accel, const float* rays, uint64_t n, const float* tmax,
                vxrt_hit_t* hits, int mode, void* stream);
 
+/* Closest-hit / miss shader over n (ray, hit record) pairs -- the hit records vxrt_trace wrote for those rays: f32 colour (3 per
+ * ray, optional) and packed RGB8 (optional) as closest.cpp:57-127 (no secondary ray) / miss.cpp:9-14 / common.h:149-154 compute
+ * them.  The records must come from this accel (their blasIdx / triIdx are followed unchecked). */
+int vxrt_shade_rays(vxrt_accel_t* accel, const float* rays, const vxrt_hit_t* hits, uint64_t n, const vxrt_shade_params_t* params,
+                    float* colors, uint32_t* rgb8, void* stream);
+
 /* Status word of the launches on this device since the last call: 0 = ok, bit0 = traversal stack overflow
  * (tree deeper than the 32 levels the reference's own trail supports; the twin: deeper than BVH_STACK_SIZE),
  * bit1 = iteration limit, bit2 = the twin's kernel met an index outside its buffers.  Synchronises `stream`;

@@ -35,6 +35,28 @@ def wrap(name):
     return p
 
 
+def wrap_textured(name, png, uv_scale, uv_shift, tag):
+    """The asset with an MTL whose diffuse map is one of the reference's own PNGs, and its texture coordinates stretched and
+    shifted so that they leave [0,1] on both sides (negative and > 1): texSample's `uint32_t(uv * w) % w` (rtx_shading.h:5-18)
+    and RGB8toRGB32F (common.h:156-162) are then exercised as the reference's object code evaluates them."""
+    import shutil
+    os.makedirs(TMP, exist_ok=True)
+    shutil.copy(ASSETS + png, os.path.join(TMP, png))
+    mtl = "m_%s.mtl" % tag
+    with open(os.path.join(TMP, mtl), "w") as f:
+        f.write("newmtl mt_%s\nKd 0.9 0.8 0.7\nKa 0.1 0.1 0.1\nmap_Kd %s\n" % (tag, png))
+    out = []
+    for line in open(ASSETS + name):
+        if line.startswith("vt "):
+            u, v = [float(x) for x in line.split()[1:3]]
+            line = "vt %.6f %.6f\n" % (u * uv_scale + uv_shift, v * uv_scale - uv_shift * 0.5)
+        out.append(line)
+    p = os.path.join(TMP, tag + "_" + name)
+    with open(p, "w") as f:
+        f.write("mtllib %s\nusemtl mt_%s\n" % (mtl, tag) + "".join(out))
+    return p
+
+
 def rays_at(scene, n, seed):
     tri = scene["tri"].view(np.float32).reshape(-1, 3)
     blas = scene["blas"].view(np.float32).reshape(-1, 40)
@@ -112,6 +134,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "cube":
         make("cube", [wrap("cube.obj")], 32, 16, edges=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "textured":
+        make_textured()
+        return
     camera_fixture()
     make("teapot", [wrap("teapot.obj")], 4096, 11)
     make("torus", [wrap("torus.obj")], 2048, 12)
@@ -121,6 +146,14 @@ def main():
     make("cube", [wrap("cube.obj")], 32, 16, edges=True)
     make("cone", [wrap("cone.obj")], 96, 14)
     make("cylinder", [wrap("cylinder.obj")], 96, 15)
+    make_textured()
+
+
+def make_textured():
+    # textured materials (two PNGs of different, non-power-of-two sizes) next to an untextured one, uv outside [0,1]:
+    # pins texSample / RGB8toRGB32F and the texId rebasing of scene.cpp through the reference's own code
+    make("tex_mix", [wrap_textured("torus.obj", "flower.png", 3.7, -1.3, "a"), wrap("sphere.obj"),
+                     wrap_textured("teapot.obj", "red.png", 2.2, -0.6, "b")], 3072, 21)
 
 
 # ---------------------------------------------------------------------------------------------

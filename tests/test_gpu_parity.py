@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 COLOR_RTOL = 1e-5
-FIXTURES = ["teapot", "torus", "sphere", "cone", "cylinder", "cube", "teapot_x3", "sphere_x6"]
+FIXTURES = ["teapot", "torus", "sphere", "cone", "cylinder", "cube", "teapot_x3", "sphere_x6", "tex_mix"]
 
 
 def _bits(a):
@@ -74,6 +74,33 @@ def test_any_hit_matches_reference_fixture(vrt, po, golden, gpu_device, name):
     got = gpu_trace(vrt, ds, g["rays"], mode=vrt.rtapi.MODE_ANY)
     ok = ~po.stale_base_mask(g, g["rays"]) if name == "sphere_x6" else np.ones(len(got), bool)
     assert np.array_equal(_bits(got[ok]), _bits(g["anyhits"][ok]))
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_shading_matches_reference_fixture(vrt, po, golden, gpu_device, name):
+    """Closest-hit / miss shading of the fixture's rays on the GPU == what the reference's own helpers (texSample, diffuseLighting,
+    RGB32FtoRGB8, via oracle/_ref) returned: f32 colour within the north-star tolerance (in practice bit-equal), RGB8 equal.
+    tex_mix has textured materials with uv below 0 and above 1."""
+    import torch
+    g = golden(name)
+    ds = vrt.tracer.DeviceScene(g, gpu_device)
+    n = len(g["rays"])
+    r = torch.from_numpy(np.ascontiguousarray(g["rays"], np.float32)).to(gpu_device)
+    h = torch.from_numpy(np.ascontiguousarray(g["hits"]).view(np.uint8).copy()).to(gpu_device)   # the reference traverser's hit records
+    col = torch.zeros(n * 3, dtype=torch.float32, device=gpu_device)
+    px = torch.zeros(n, dtype=torch.int32, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.shade_rays(ds.accel, r.data_ptr(), h.data_ptr(), n, vrt.rtapi.default_shade_params(), col.data_ptr(), px.data_ptr(), s)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(col.cpu().numpy().reshape(n, 3), g["colors"], rtol=COLOR_RTOL, atol=0)
+    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), g["rgb8"])
+    if name == "tex_mix":
+        te = g["triEx"].view(np.float32).reshape(-1, 16)
+        assert te[:, 9:15].min() < -1.0 and te[:, 9:15].max() > 2.0
+        hit = g["hits"]["dist"] < 1e29
+        mats = g["mat"].view(np.int32).reshape(-1, 22)[:, 16]
+        tex_hit = mats[te[g["hits"]["triIdx"][hit], 15].view(np.int32)] >= 0
+        assert tex_hit.any() and (~tex_hit).any()      # textured and untextured hits both present
 
 
 @pytest.mark.parametrize("scene_args,w,h", [(("cornell", 0, 0, 1), 256, 256), (("blob", 4, 0, 1), 160, 120),
@@ -199,6 +226,49 @@ def test_malformed_trees_are_rejected_at_build_time(vrt, golden, gpu_device):
     for mut in (child_out_of_range, child_before_parent, leaf_past_triangles, wrong_kind, bad_instance, bad_bvh_offset):
         with pytest.raises(vrt.runtime.VxError):
             try_build(mut)
+    torch.cuda.synchronize()
+
+
+def test_malformed_shading_inputs_are_rejected_at_build_time(vrt, golden, gpu_device):
+    """closest.cpp:52-77 dereferences mat[texId] and the texels of a textured material unchecked; the accel build validates
+    them, so a scene whose shading would read outside its buffers fails on the host (-1) instead of faulting the GPU."""
+    import torch
+    g = golden("tex_mix")
+    mat_dt = np.dtype([("f", "<f4", 16), ("tex_id", "<i4"), ("illum", "<i4"), ("tw", "<u4"), ("th", "<u4"), ("off", "<u8")])
+    assert mat_dt.itemsize == 88
+
+    def try_build(mut, drop_tex=False):
+        sc = {k: v.copy() for k, v in g.items() if k in ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")}
+        mut(sc)
+        if drop_tex:
+            sc["tex"] = np.zeros(0, np.uint8)
+        return vrt.tracer.DeviceScene(sc, gpu_device)
+
+    try_build(lambda sc: None).close()
+    n_mats = len(g["mat"]) // 88
+    textured = int(np.nonzero(g["mat"].view(mat_dt)["tex_id"] >= 0)[0][0])
+
+    def tex_id_out_of_range(sc):
+        sc["triEx"].view(np.uint32).reshape(-1, 16)[7, 15] = n_mats
+
+    def zero_width(sc):
+        sc["mat"].view(mat_dt)["tw"][textured] = 0
+
+    def zero_height(sc):
+        sc["mat"].view(mat_dt)["th"][textured] = 0
+
+    def offset_past_buffer(sc):
+        sc["mat"].view(mat_dt)["off"][textured] = len(sc["tex"]) - 16
+
+    def huge_dimensions(sc):
+        sc["mat"].view(mat_dt)["tw"][textured] = 0x10000
+        sc["mat"].view(mat_dt)["th"][textured] = 0x10000
+
+    for mut in (tex_id_out_of_range, zero_width, zero_height, offset_past_buffer, huge_dimensions):
+        with pytest.raises(vrt.runtime.VxError):
+            try_build(mut)
+    with pytest.raises(vrt.runtime.VxError):          # textured material, no texture buffer at all
+        try_build(lambda sc: None, drop_tex=True)
     torch.cuda.synchronize()
 
 

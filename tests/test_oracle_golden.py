@@ -3,7 +3,8 @@ code (oracle/gen_golden.py).  This is what pins the oracle when /root/reference 
 import numpy as np
 import pytest
 
-SCENES = ["teapot", "torus", "sphere", "cone", "cylinder", "cube", "teapot_x3", "sphere_x6"]
+# tex_mix: textured materials (uv outside [0,1], two non-power-of-two PNGs of the reference) next to an untextured one
+SCENES = ["teapot", "torus", "sphere", "cone", "cylinder", "cube", "teapot_x3", "sphere_x6", "tex_mix"]
 # TLAS deeper than one level: the reference traverser addresses the children of a TLAS internal node
 # popped from its short stack relative to the last BLAS's base (rt_traversal.cpp:91-92 vs :119-120),
 # reads unrelated nodes and loses real hits.  The faithful restatement reproduces that bit for bit;

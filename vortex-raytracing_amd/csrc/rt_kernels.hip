@@ -1204,6 +1204,21 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
   }
 }
 
+// closest-hit / miss shader of arbitrary (ray, hit record) pairs: what the RTU test's shaders compute for the ray a payload belongs
+// to (closest.cpp:57-127 without a secondary ray, miss.cpp:9-14), e.g. for the hit records vxrt_trace returns
+__global__ __launch_bounds__(256) void rt_shade_rays_kernel(SceneDev sc, ShadeParams p, uint64_t n, const float* __restrict__ rays,
+                                                           const HitRec* __restrict__ hits, float* __restrict__ colors, uint32_t* __restrict__ rgb8) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const float* rp = rays + i * 6;
+  HitRec h = hits[i];
+  h.blasIdx &= 0x7fffffffu;
+  float r, g, b;
+  shade_eval<false>(sc, p, rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], h, h.dist != RT_LARGE_FLOAT, false, r, g, b);
+  if (colors) { colors[3 * i] = r; colors[3 * i + 1] = g; colors[3 * i + 2] = b; }
+  if (rgb8) rgb8[i] = pack_rgb8(r, g, b);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Mirror bounce (closest.cpp:95-121) as a wavefront over depth levels.  The reference recurses inside
 // the closest-hit shader: C(ray) = term + (reflectivity > 0 && bounce + 1 < max_depth ? C(mirror ray)
@@ -2367,6 +2382,23 @@ int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax
   if (!c) return -1;
   if (trace_on_ctx(a, c, rays, n, tmax, (HitRec*)hits, mode, s) != 0) return -1;
   return release_ctx(c, s);
+}
+
+int vxrt_shade_rays(vxrt_accel_t* a, const float* rays, const vxrt_hit_t* hits, uint64_t n, const vxrt_shade_params_t* params,
+                    float* colors, uint32_t* rgb8, void* stream) {
+  if (!a || !params || (n && (!rays || !hits)) || (!colors && !rgb8)) return -1;
+  if (!a->ref.triEx || !a->ref.mat || a->ref.n_mats == 0) return -1;
+  if (n == 0) return 0;
+  if (n > 0x7fffffffull) return -1;
+  // a hit record names a triangle and an instance: both must exist (records a caller made up are not trusted)
+  ShadeParams p;
+  for (int i = 0; i < 3; ++i) {
+    p.amb[i] = params->ambient[i]; p.lcol[i] = params->light_color[i];
+    p.lpos[i] = params->light_pos[i]; p.bg[i] = params->background[i];
+  }
+  p.max_depth = 1;
+  hipLaunchKernelGGL(rt_shade_rays_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->dev, p, n, rays, (const HitRec*)hits, colors, rgb8);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int vxrt_status(void* stream, uint32_t* status) {

@@ -203,6 +203,14 @@ def trace(accel, rays_ptr, n, hits_ptr, mode=MODE_CLOSEST, tmax_ptr=None, stream
     check(_lib().vxrt_trace(accel, rays_ptr, n, tmax_ptr, hits_ptr, mode, stream), "vxrt_trace")
 
 
+def shade_rays(accel, rays_ptr, hits_ptr, n, params, colors_ptr=None, rgb8_ptr=None, stream=None):
+    """vxrt_shade_rays: closest-hit / miss shader over (ray, hit record) pairs."""
+    L = _lib()
+    L.vxrt_shade_rays.restype = C.c_int
+    L.vxrt_shade_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(ShadeParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    check(L.vxrt_shade_rays(accel, rays_ptr, hits_ptr, n, C.byref(params), colors_ptr, rgb8_ptr, stream), "vxrt_shade_rays")
+
+
 def status(stream=None):
     st = C.c_uint32()
     check(_lib().vxrt_status(stream, C.byref(st)), "vxrt_status")
