@@ -478,6 +478,7 @@ struct PersistArgs {
   const uint32_t* total_dev;      // optional: the job count lives in device memory (produced by an earlier kernel of the stream)
   HitRec* hits;                   // render: W*H hit records (occlusion in bit 31 of blasIdx); trace: n records
   const float* rays; const float* tmax; int any_hit;   // trace inputs
+  const uint32_t* order;          // trace, optional: queue position -> ray id (rays binned by origin cell and direction octant)
   unsigned long long* counters;   // [0] rays (+ STATS: [1..4])
   uint32_t* status;
   uint32_t* queue;                // QUEUE_SHARDS counters (QUEUE_STRIDE dwords apart), zeroed by the host before the launch
@@ -783,6 +784,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
           if (rank < avail) {
             job = loc_next + rank + loc_off;
             flags = 0;
+            if (!EXACT && JOB == JOB_TRACE && A.order) job = A.order[job];
             if (EXACT) {
               const uint32_t wd = A.defer_list[job];
               job = wd & 0x7fffffffu;
@@ -1468,6 +1470,49 @@ __global__ __launch_bounds__(256) void rt_ao_final_kernel(uint64_t n, uint32_t W
   if (rays_traced && (threadIdx.x & 63u) == 0u && m) atomicAdd(rays_traced, (unsigned long long)__popcll(m) * spp);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Secondary rays re-sorted before they are traced (north_star: "ray packets re-sorted ... to tame divergence").
+// The rays of a bounce / AO pass leave the compaction in pixel order with directions spread over a hemisphere: a wavefront of
+// 64 consecutive rays shares origins but not directions.  Counting sort by key = direction octant x origin cell (the 16x16-pixel
+// cell of the ray's pixel: hit points of neighbouring pixels are neighbours in space), so that 64 consecutive queue positions
+// hold rays that start in one small region AND point into the same octant.  Only the ORDER in which rays are traced changes:
+// the kernel reads ray order[q] and writes hit record order[q], so every result is bit-identical (tests compare them all).
+// ---------------------------------------------------------------------------------------------
+#define BIN_CELL_SHIFT 4u   // 16 x 16 pixels
+__global__ __launch_bounds__(256) void rt_bin_count_kernel(uint64_t cap, const uint32_t* __restrict__ hdr, const float* __restrict__ rays,
+    const uint32_t* __restrict__ list, uint32_t ns, uint32_t W, uint32_t cells_x, uint32_t n_cells, uint32_t* __restrict__ hist, uint32_t* __restrict__ keys) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= hdr[1] || i >= cap) return;
+  const uint32_t t = list[i / ns];
+  const uint32_t cell = ((t / W) >> BIN_CELL_SHIFT) * cells_x + ((t % W) >> BIN_CELL_SHIFT);
+  const float* r = rays + i * 6;
+  const uint32_t oct = (__float_as_uint(r[3]) >> 31) | ((__float_as_uint(r[4]) >> 31) << 1) | ((__float_as_uint(r[5]) >> 31) << 2);
+  const uint32_t key = oct * n_cells + cell;
+  keys[i] = key;
+  atomicAdd(&hist[key], 1u);
+}
+// exclusive scan of hist[0..n) in place, one workgroup of 1024 threads, `per` consecutive counters per thread
+__global__ __launch_bounds__(1024) void rt_bin_scan_kernel(uint32_t* __restrict__ hist, uint32_t n, uint32_t per) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n);
+  uint32_t sum = 0;
+  for (uint32_t k = lo; k < hi; ++k) sum += hist[k];
+  uint32_t inc = sum;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += y; }
+  if (lane == 63u) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = inc - sum;
+  for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
+  for (uint32_t k = lo; k < hi; ++k) { const uint32_t v = hist[k]; hist[k] = base; base += v; }
+}
+__global__ __launch_bounds__(256) void rt_bin_scatter_kernel(uint64_t cap, const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ order) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= hdr[1] || i >= cap) return;
+  order[atomicAdd(&hist[keys[i]], 1u)] = (uint32_t)i;
+}
+
 // One diffuse bounce (extension for BASELINE config 3; recipe in oracle/rt_oracle.c:orc_render_gi): the bounce rays are
 // the AO rays of sample 0 with spp = 1 and no tmax, traced for their closest hit.  Listed pixel i: colour += albedo *
 // (Lambert colour of the bounce hit | background).
@@ -1770,6 +1815,7 @@ struct FrameCtx {
   float4* ao_geo = nullptr; float4* ao_nrm = nullptr; float4* ao_col = nullptr; float4* ao_alb = nullptr; uint32_t* ao_cnt = nullptr;
   uint32_t* ao_list = nullptr; uint32_t* ao_hdr = nullptr;   // pixels with a hit; [0] their number, [1] rays of the current batch
   float* ao_rays = nullptr; float* ao_tmax = nullptr; HitRec* ao_hits = nullptr; uint64_t ao_cap = 0, ao_ray_cap = 0;
+  uint32_t* bin_hist = nullptr; uint32_t* bin_keys = nullptr; uint32_t* bin_order = nullptr; uint64_t bin_cap = 0, bin_ray_cap = 0;   // secondary-ray binning
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr;
   bool busy = false, inited = false;
@@ -1803,6 +1849,7 @@ static void accel_free(vxrt_accel* a) {
   for (FrameCtx& c : a->ctx) {
     (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount); (void)hipFree(c.tile_cost); (void)hipFree(c.tile_order);
     (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_alb); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits); (void)hipFree(c.ao_list); (void)hipFree(c.ao_hdr);
+    (void)hipFree(c.bin_hist); (void)hipFree(c.bin_keys); (void)hipFree(c.bin_order);
     for (FrameCtx::Level& l : c.lv) {
       (void)hipFree(l.rays); (void)hipFree(l.hits); (void)hipFree(l.parent); (void)hipFree(l.term); (void)hipFree(l.col);
       (void)hipFree(l.srays); (void)hipFree(l.stmax); (void)hipFree(l.shits);
@@ -1974,12 +2021,13 @@ static int ensure_defer(FrameCtx* c, uint64_t jobs, hipStream_t s) {
 // ray buffer -> hit records on frame context c (the body of vxrt_trace; also the bounce levels of vxrt_render)
 static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_t n, const float* tmax,
                         HitRec* hits, int mode, hipStream_t s, const uint32_t* n_dev = nullptr,
-                        unsigned long long* stats_counters = nullptr) {
+                        unsigned long long* stats_counters = nullptr, const uint32_t* order = nullptr) {
   uint32_t* st = status_word();
   if (!st) return -1;
   PersistArgs A{};
   A.total = (uint32_t)n; A.hits = hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
   A.total_dev = n_dev;
+  A.order = order;
   A.counters = stats_counters;
   A.status = st;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
@@ -1995,6 +2043,7 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   PersistArgs X = A;
   X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
   X.total_dev = nullptr;   // the EXACT launch takes its count from the deferral list
+  X.order = nullptr;
   ShadeParams p{};
 #define LAUNCH_T(ST, LD) do { \
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, false>, n)), dim3(RT_WG_THREADS), 0, s, a->dev, p, A); \
@@ -2112,6 +2161,29 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
     c->ao_cap = std::max(have, n); c->ao_ray_cap = std::max(rhave, ray_cap);
   }
   const dim3 block(256), grid((uint32_t)((n + 255) / 256)), rgrid((uint32_t)((ray_cap + 255) / 256));
+  // VXRT_SORT_SECONDARY=1: trace the secondary rays in (direction octant, origin cell) order instead of generation order.  OFF by
+  // default: measured SLOWER on both passes that use it (diffuse bounce 1.53 -> 1.95 ms, 10M-triangle hairball AO 9.2 -> 16.6 ms,
+  // profiles/r02_f_secondary_sort.txt).  The traversal is bound by per-lane VALU work, which coherence does not reduce, and the
+  // generation order already puts the 16 samples of one pixel (AO) / 64 neighbouring pixels (bounce) side by side.
+  static const bool sort_on = [] { const char* e = getenv("VXRT_SORT_SECONDARY"); return e && e[0] == '1'; }();
+  const uint32_t cells_x = (width + (1u << BIN_CELL_SHIFT) - 1) >> BIN_CELL_SHIFT, cells_y = (y1 - y0 + (1u << BIN_CELL_SHIFT) - 1) >> BIN_CELL_SHIFT;
+  const uint32_t n_cells = cells_x * cells_y, n_bins = 8u * n_cells;
+  if (sort_on && (c->bin_cap < n_bins || c->bin_ray_cap < ray_cap)) {
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    bool ok = grow_buf((void**)&c->bin_hist, c->bin_cap, n_bins, 4) && grow_buf((void**)&c->bin_keys, c->bin_ray_cap, ray_cap, 4) &&
+              grow_buf((void**)&c->bin_order, c->bin_ray_cap, ray_cap, 4);
+    if (!ok) return -1;
+    c->bin_cap = std::max<uint64_t>(c->bin_cap, n_bins); c->bin_ray_cap = std::max(c->bin_ray_cap, ray_cap);
+  }
+  auto bin_rays = [&](uint32_t ns_batch) -> const uint32_t* {   // ao_rays of the current batch -> bin_order
+    if (!sort_on) return nullptr;
+    if (hipMemsetAsync(c->bin_hist, 0, (size_t)n_bins * 4, s) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(rt_bin_count_kernel, rgrid, block, 0, s, ray_cap, (const uint32_t*)c->ao_hdr, (const float*)c->ao_rays, (const uint32_t*)c->ao_list, ns_batch,
+                       width, cells_x, n_cells, c->bin_hist, c->bin_keys);
+    hipLaunchKernelGGL(rt_bin_scan_kernel, dim3(1), dim3(1024), 0, s, c->bin_hist, n_bins, (n_bins + 1023u) / 1024u);
+    hipLaunchKernelGGL(rt_bin_scatter_kernel, rgrid, block, 0, s, ray_cap, (const uint32_t*)c->ao_hdr, (const uint32_t*)c->bin_keys, c->bin_hist, c->bin_order);
+    return c->bin_order;
+  };
   if (hipMemsetAsync(c->ao_hdr, 0, 8, s) != hipSuccess) return -1;
   hipLaunchKernelGGL(rt_ao_prepare_kernel, grid, block, 0, s, sc, p, n, width, y0, utab, vtab, (const HitRec*)c->hitbuf,
                      c->ao_geo, c->ao_nrm, c->ao_col, c->ao_cnt, c->ao_list, c->ao_hdr, c->ctl, gi ? c->ao_alb : (float4*)nullptr);
@@ -2120,7 +2192,7 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
   if (gi) {
     hipLaunchKernelGGL(rt_ao_rays_kernel, rgrid, block, 0, s, ray_cap, width, y0, utab, vtab, (const float4*)c->ao_geo, (const float4*)c->ao_nrm,
                        (const uint32_t*)c->ao_list, c->ao_hdr, 1u, 0u, 1u, ao->seed, RT_LARGE_FLOAT, c->ao_rays, c->ao_tmax);
-    if (trace_on_ctx(a, c, c->ao_rays, n, nullptr, c->ao_hits, VXRT_MODE_CLOSEST, s, c->ao_hdr + 1) != 0) return -1;
+    if (trace_on_ctx(a, c, c->ao_rays, n, nullptr, c->ao_hits, VXRT_MODE_CLOSEST, s, c->ao_hdr + 1, nullptr, bin_rays(1u)) != 0) return -1;
     hipLaunchKernelGGL(rt_gi_accumulate_kernel, rgrid, block, 0, s, sc, p, ray_cap, (const uint32_t*)c->ao_list, (const uint32_t*)c->ao_hdr,
                        (const float*)c->ao_rays, (const HitRec*)c->ao_hits, (const float4*)c->ao_alb, c->ao_col);
     hipLaunchKernelGGL(rt_gi_final_kernel, grid, block, 0, s, n, width, y0, (const float4*)c->ao_geo, (const float4*)c->ao_col, dst, colors, rays_traced);
@@ -2130,7 +2202,7 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
     const uint32_t k = std::min(ns, ao->spp - s0);
     hipLaunchKernelGGL(rt_ao_rays_kernel, rgrid, block, 0, s, ray_cap, width, y0, utab, vtab, (const float4*)c->ao_geo, (const float4*)c->ao_nrm,
                        (const uint32_t*)c->ao_list, c->ao_hdr, ao->spp, s0, k, ao->seed, ao->radius, c->ao_rays, c->ao_tmax);
-    if (trace_on_ctx(a, c, c->ao_rays, n * k, c->ao_tmax, c->ao_hits, VXRT_MODE_ANY, s, c->ao_hdr + 1) != 0) return -1;
+    if (trace_on_ctx(a, c, c->ao_rays, n * k, c->ao_tmax, c->ao_hits, VXRT_MODE_ANY, s, c->ao_hdr + 1, nullptr, bin_rays(k)) != 0) return -1;
     hipLaunchKernelGGL(rt_ao_accumulate_kernel, rgrid, block, 0, s, ray_cap, (const uint32_t*)c->ao_list, (const uint32_t*)c->ao_hdr, k,
                        (const HitRec*)c->ao_hits, c->ao_cnt);
   }
