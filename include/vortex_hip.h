@@ -283,10 +283,24 @@ typedef struct vxrc_params {     /* the fields of raycast/common.h:126-150 kerne
   uint32_t samples_per_pixel, max_depth;
   float light_pos[3], light_color[3], ambient_color[3], background_color[3];
 } vxrc_params_t;
-/* Rows [y0,y1) of the frame kernel.cpp:9-33 renders: GenerateRay (render.h:192-211) -> Trace (:213-275) summed
+/* Acceleration layout of a raycast scene, built once per scene (compact 64-byte BVH2 nodes holding both children's boxes and
+ * complete child descriptors; triangles in edge form in leaf order, the triIdx indirection resolved).  The build validates every
+ * index the BVH walk follows (children inside their instance's node range and after their parent, leaf ranges inside triIdx,
+ * triIdx entries inside tri, bvh_offset of every instance) and fails (-1) on a malformed tree; TLAS indices, instance indices
+ * and texture extents are checked where the kernel follows them (status bit 2).  The scene's buffers must stay alive and
+ * unchanged while the layout is in use. */
+typedef struct vxrc_accel vxrc_accel_t;
+int vxrc_accel_build(const vxrc_scene_t* scene, void* stream, vxrc_accel_t** out);
+int vxrc_accel_destroy(vxrc_accel_t* accel);
+/* vxrc_render on a prebuilt layout (asynchronous on `stream`; one frame in flight per layout). */
+int vxrc_render_accel(vxrc_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                      const vxrc_params_t* params, uint32_t* dst, float* colors, void* stream);
+
+/* One-shot form: builds the layout, renders, frees it (synchronises the device).
+ * Rows [y0,y1) of the frame kernel.cpp:9-33 renders: GenerateRay (render.h:192-211) -> Trace (:213-275) summed
  * over the samples -> RGB32FtoRGB8 -> dst[x + y*W].  colors (optional): f32 rgb per pixel before packing.
- * Every index the traversal follows is bounds-checked in the kernel; a violation, a stack deeper than the
- * reference's BVH_STACK_SIZE (64, undefined behaviour there) or a runaway loop sets vxrt_status bits 4/1/2. */
+ * A malformed BVH fails the call (-1); a TLAS / instance index or texture extent outside its buffer, a stack deeper than the
+ * reference's BVH_STACK_SIZE (64, undefined behaviour there) or a runaway TLAS walk sets vxrt_status bits 2 / 0 / 1. */
 int vxrc_render(const vxrc_scene_t* scene, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                 const vxrc_params_t* params, uint32_t* dst, float* colors, void* stream);
 

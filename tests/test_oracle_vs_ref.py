@@ -37,3 +37,36 @@ def test_restatement_equals_reference_object_code(po, golden, name, n):
     ref_any, _ = po.trace_ref(g, rays, any_hit=True)
     got_any, _ = po.trace_faithful(g, rays, any_hit=True)
     assert np.array_equal(got_any.view(np.uint8), ref_any.view(np.uint8))
+
+
+def test_obj_ingest_equals_the_reference_mesh_loader(vrt, po, tmp_path):
+    """the package's own OBJ / MTL / PNG readers against the reference's Mesh loader (tinyobj + stb_image, compiled
+    where they lie in oracle/_ref) on the same files: the same triangles with the same normals / uvs / material ids (as a
+    multiset -- each builder reorders triangles for its own tree), the same materials (the fields the reference initialises:
+    it leaves `illum`, and `tex_offset` of an untextured material, uninitialised), the same texels."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref/libvxref.so not built")
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_reference_host import _write_obj
+    d = str(tmp_path)
+    _write_obj(vrt, d, "scene.obj")        # textured blob (uv outside [0,1]) + plain floor, v/vn/vt per corner, two materials
+    ours = vrt.scene.load_obj(os.path.join(d, "scene.obj"))
+    ref = po.ref_scene([os.path.join(d, "scene.obj")])
+
+    def canon(sc):
+        tri = np.ascontiguousarray(sc["tri"]).view(np.uint8).reshape(-1, 36)
+        ex = np.ascontiguousarray(sc["triEx"]).view(np.uint8).reshape(-1, 64)
+        rec = np.concatenate([tri, ex], 1)
+        return rec[np.lexsort(rec.T[::-1])]
+    a, b = canon(ours), canon(ref)
+    assert a.shape == b.shape and len(a) > 1000
+    assert np.array_equal(a, b)
+    assert np.array_equal(np.asarray(ours["tex"]), np.asarray(ref["tex"])) and len(ref["tex"]) == 23 * 37 * 4
+    mat_dt = np.dtype([("f", "<f4", 16), ("tex_id", "<i4"), ("illum", "<i4"), ("tw", "<u4"), ("th", "<u4"), ("off", "<u8")])
+    ma, mb = np.ascontiguousarray(ours["mat"]).view(mat_dt), np.ascontiguousarray(ref["mat"]).view(mat_dt)
+    assert len(ma) == len(mb) == 2
+    for k in ("f", "tex_id", "tw", "th"):
+        assert np.array_equal(ma[k], mb[k]), k
+    textured = mb["tex_id"] >= 0
+    assert textured.any() and np.array_equal(ma["off"][textured], mb["off"][textured])

@@ -189,3 +189,57 @@ def test_hip_twin_on_package_built_scene(vrt, po, gpu_device):
     np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), opx)
     np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3), ocol, rtol=1e-5)
     assert (opx != opx[0, 0]).mean() > 0.05
+
+
+@pytest.mark.gpu
+def test_twin_accel_is_reusable_and_rejects_malformed_scenes(vrt, po, golden, gpu_device):
+    """vxrc_accel_build once, several frames on it (different samples / depth / row windows) equal the restatement; a scene whose
+    BVH walk would leave its buffers fails at build time (-1) instead of reaching a kernel."""
+    import torch
+    g = golden("rc_teapot_x3")
+    sc = {k: g[k] for k in po.RC_BUFFERS}
+    sc["tlas_root"] = int(g["tlas_root"])
+    w, h = int(g["width"]), int(g["height"])
+    ds = vrt.tracer.RcDeviceScene(sc, gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    for spp, depth in ((1, 1), (int(g["spp"]), int(g["max_depth"])), (3, 5)):
+        prm = vrt.rtapi.rc_params(g["cam14"], g["light12"], spp, depth)
+        px = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
+        vrt.rtapi.rc_render_accel(ds.accel, w, h, 0, h, prm, px.data_ptr(), None, s)
+        assert vrt.rtapi.status(s) == 0
+        want, _ = po.rc_render(po.rc_args(sc, w, h, g["cam14"], g["light12"], spp, depth))
+        np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), want)
+    ds.close()
+
+    def bad_scene(mut):
+        b = {k: v.copy() for k, v in sc.items() if k != "tlas_root"}
+        b["tlas_root"] = sc["tlas_root"]
+        mut(b)
+        d2 = vrt.tracer.RcDeviceScene(b, gpu_device)
+        with pytest.raises(vrt.runtime.VxError):
+            d2.accel
+        d2.close()
+
+    nodes = sc["bvh"].view(np.uint32).reshape(-1, 8)
+    inner = int(np.nonzero(nodes[:, 7] == 0)[0][0])
+    inner2 = int(np.nonzero((nodes[:, 7] == 0) & (np.arange(len(nodes)) > 6))[0][0])
+    leaf = int(np.nonzero(nodes[:, 7] != 0)[0][0])
+
+    def child_out_of_range(b):
+        b["bvh"].view(np.uint32).reshape(-1, 8)[inner, 3] = 0x7FFFFFF0
+
+    def child_before_parent(b):       # would be a cycle
+        b["bvh"].view(np.uint32).reshape(-1, 8)[inner2, 3] = 0
+
+    def leaf_past_tri_idx(b):
+        b["bvh"].view(np.uint32).reshape(-1, 8)[leaf, 3] = len(b["triIdx"]) // 4
+
+    def tri_idx_past_tris(b):
+        b["triIdx"].view(np.uint32)[5] = 0x00FFFFFF
+
+    def bad_bvh_offset(b):
+        b["blas"].view(np.uint32).reshape(-1, 40)[0, 32] = 0x7FFFFFFF
+
+    for mut in (child_out_of_range, child_before_parent, leaf_past_tri_idx, tri_idx_past_tris, bad_bvh_offset):
+        bad_scene(mut)
+    torch.cuda.synchronize()

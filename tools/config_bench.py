@@ -100,7 +100,7 @@ def main():
         prm = rtapi.rc_params(vrt.scene.rc_camera_like_rtu(W, H), (300.0, 480.0, 60.0, 1, 1, 1, 0.4, 0.4, 0.4, 0.4, 0.35, 0.25), 1, 1)
         px = torch.zeros((H, W), dtype=torch.int32, device=dev)
         s = torch.cuda.current_stream().cuda_stream
-        ms = timed(lambda: rtapi.rc_render(ds.c, W, H, 0, H, prm, px.data_ptr(), None, s), 20)
+        ms = timed(lambda: rtapi.rc_render_accel(ds.accel, W, H, 0, H, prm, px.data_ptr(), None, s), 20)
         assert rtapi.status(s) == 0
         out.append({"config": "software twin (raycast): Sponza-class BVH2, 1920x1080, primary rays, 1 spp", "tris": sc["tri"].size // 36,
                     "bvh2_nodes": sc["bvh"].size // 32, "bvh2_depth": sc["max_depth"], "host_build_s": round(build_s, 1),

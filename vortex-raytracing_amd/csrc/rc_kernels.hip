@@ -1,41 +1,73 @@
-// HIP kernel of the reference's SOFTWARE ray caster (tests/regression/raycast, the "software twin" of the RTU
-// test: SURVEY.md s8f-4) for gfx950.  Same boundary as the RTU path: the reference host program uploads its
-// BVH2 / TLAS / instance / triangle / texture buffers and a 192-byte kernel_arg_t through vx_*, the backend
-// resolves the addresses and calls vxrc_render.
+// HIP kernels of the reference's SOFTWARE ray caster (tests/regression/raycast, the "software twin" of the RTU
+// test: SURVEY.md s8f-4) for gfx950, built on the machinery of the RTU path (rt_kernels.hip) instead of a lane-per-pixel
+// copy of the CPU loop:
+//   * an acceleration layout derived once per scene from the reference-format buffers: compact 64-byte BVH2 nodes that hold
+//     BOTH children's boxes and complete child descriptors (one aligned fetch per node step tests two boxes; a leaf never costs
+//     a node fetch: its triangle range is in the descriptor), and triangles in edge form laid out in leaf order, so the triIdx
+//     indirection of the reference (render.h:95) is resolved at build time (the original index rides in the record);
+//   * persistent wavefronts pulling 8x8 pixel tiles from a sharded queue; whole tiles traverse together;
+//   * per-lane traversal stack of 4-byte descriptors in LDS (the reference re-tests nothing at pop time, so an entry is just
+//     the node), hit attributes / world ray in LDS next to it, the active object-space ray in registers;
+//   * an if-if loop (node step, leaf step, TLAS step), shading once the tile's rays have finished, mirror bounces and
+//     samples as further rays of the same lane.
+// Same boundary as the RTU path: the reference host program uploads its BVH2 / TLAS / instance / triangle / texture buffers and
+// a 192-byte kernel_arg_t through vx_*, the backend resolves the addresses, caches the layout and calls vxrc_render_accel.
 //
 // Semantics restated from the reference (paths relative to tests/regression/raycast):
-//   kernel loop      kernel.cpp:9-33 (16x4 pixel blocks, samples summed, RGB32FtoRGB8)
+//   kernel loop      kernel.cpp:9-33 (samples summed, RGB32FtoRGB8)
 //   ray generation   render.h:192-211
 //   Trace            render.h:213-275 (iterative mirror bounce, per-instance texture)
 //   traversal        render.h:75-190 (explicit stacks of BVH_STACK_SIZE = 64; note :110 pushes the NEARER BVH
-//                    child first, i.e. visits the farther one first -- reproduced, it decides distance ties)
-//   box / triangle   geometry.h:1442-1465 / :1416-1440 (1/dir recomputed per box test, libstdc++ min/max)
-// One 16x4 block = one wavefront, one lane per pixel, stacks in scratch.  Built -ffp-contract=off.
+//                    child first, i.e. visits the farther one first -- reproduced, it decides distance ties; the TLAS loop at
+//                    :176 has it the right way round; a pushed child is visited even if hit.dist has shrunk since)
+//   box / triangle   geometry.h:1442-1465 / :1416-1440 (libstdc++ min/max chains kept literally: NaN slabs of rays with a zero
+//                    direction component resolve as on the host)
+// Built -ffp-contract=off.  Pixel-exact against the reference's own -c output (tests/test_rc_twin.py, tests/golden/rc_*.npz).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
+#include <new>
+#include <vector>
 #include "../../include/vortex_hip.h"
 
 #define RC_LARGE_FLOAT 1e30f
 #define RC_EPSILON 1e-6f
-#define RC_STACK 64
+#define RC_STACK 64             // BVH_STACK_SIZE of the reference (deeper = undefined behaviour there, status bit here)
+#define RC_LDS_STACK 16         // stack entries kept in LDS per lane; deeper ones in scratch
 #define RC_STATUS_STACK 1u      // same bits as the RTU path's status word
 #define RC_STATUS_ITER 2u
 #define RC_STATUS_BAD_SCENE 4u
-#define RC_ITER_LIMIT (1u << 24)
+#define RC_TLAS_ITER_LIMIT (1u << 20)   // the TLAS is taken as uploaded (not re-laid out), so its walk is bounded
+#define RC_QUEUE_SHARDS 8u
+#define RC_QUEUE_STRIDE 32u
+#define RC_CTL_DWORDS (RC_QUEUE_SHARDS * RC_QUEUE_STRIDE)
 
 extern "C" uint32_t* vxrt_status_word_device(void);   // rt_kernels.hip
 
 namespace {
 
+// child / work descriptor: bit 31 clear = internal node (compact index); bit 31 set = leaf: bit 30 clear -> inline,
+// (count - 1) in [29:25], first wide triangle in [24:0]; bit 30 set -> by reference (index of the reference leaf node)
+#define RCD_LEAF 0x80000000u
+#define RCD_LEAF_REF 0x40000000u
+#define RCD_FIRST_MASK 0x01FFFFFFu
+#define RC_CUR_TLAS 0xFFFFFFF0u    // BVH stack exhausted: next step is a TLAS pop
+#define RC_CUR_SHADE 0xFFFFFFF1u   // ray finished: shade
+#define RC_CUR_IDLE 0xFFFFFFF2u
+__device__ __forceinline__ bool rc_is_node(uint32_t d) { return d < RCD_LEAF; }
+__device__ __forceinline__ bool rc_is_leaf(uint32_t d) { return d >= RCD_LEAF && d < RC_CUR_TLAS; }
+
 struct RcDev {
-  const uint32_t* tlas; uint32_t n_tlas;   // 8 dwords per node: aabbMin, leftRight, aabbMax, blasIdx
+  const uint32_t* tlas; uint32_t n_tlas;   // reference format, 8 dwords per node: aabbMin, leftRight, aabbMax, blasIdx
   const uint32_t* blas; uint32_t n_blas;   // 40 dwords per record
-  const uint32_t* bvh; uint32_t n_bvh;     // 8 dwords per node: aabbMin, leftFirst, aabbMax, triCount
-  const float* tri; uint32_t n_tris;       // 9 floats
+  const uint32_t* bvh; uint32_t n_bvh;     // reference nodes (leaves by reference only)
   const float* triEx;                      // 15 floats
-  const uint32_t* triIdx; uint32_t n_triIdx;
   const uint8_t* tex; uint64_t tex_bytes;
   uint32_t tlas_root;
+  const uint4* nodes_c;                    // compact nodes, one per reference node slot (only internal ones are filled)
+  const float4* tri_w;                     // wide triangles in triIdx order: (v0, e1.x) (e1.yz, e2.xy) (e2.z, triIdx, -, -)
+  const uint32_t* blas_root;               // per instance record: descriptor of its BVH root
+  uint32_t n_tri_idx;
 };
 
 struct RcParams {
@@ -47,25 +79,25 @@ struct RcParams {
 __device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
 
-// geometry.h:1442-1465
-__device__ __forceinline__ float ray_box(float ox, float oy, float oz, float dx, float dy, float dz, const float* mn, const float* mx) {
-  const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-  const float tx1 = (mn[0] - ox) * ix, tx2 = (mx[0] - ox) * ix;
+// geometry.h:1442-1465 with 1/dir hoisted (it is recomputed per test there: same value)
+__device__ __forceinline__ float ray_box(float ox, float oy, float oz, float ix, float iy, float iz,
+                                         float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
+  const float tx1 = (mnx - ox) * ix, tx2 = (mxx - ox) * ix;
   float tmin = std_min(tx1, tx2), tmax = std_max(tx1, tx2);
-  const float ty1 = (mn[1] - oy) * iy, ty2 = (mx[1] - oy) * iy;
+  const float ty1 = (mny - oy) * iy, ty2 = (mxy - oy) * iy;
   tmin = std_max(tmin, std_min(ty1, ty2)); tmax = std_min(tmax, std_max(ty1, ty2));
-  const float tz1 = (mn[2] - oz) * iz, tz2 = (mx[2] - oz) * iz;
+  const float tz1 = (mnz - oz) * iz, tz2 = (mxz - oz) * iz;
   tmin = std_max(tmin, std_min(tz1, tz2)); tmax = std_min(tmax, std_max(tz1, tz2));
   if (tmax < tmin || tmax <= 0) return RC_LARGE_FLOAT;
   return tmin;
 }
 
-// geometry.h:1416-1440
-__device__ __forceinline__ bool ray_tri(float ox, float oy, float oz, float dx, float dy, float dz, const float* t,
+// geometry.h:1416-1440 on a wide triangle (v0, edge1, edge2: the subtractions of :1418-1419 done once at build time)
+__device__ __forceinline__ bool ray_tri(float ox, float oy, float oz, float dx, float dy, float dz, float4 t0, float4 t1, float4 t2,
                                         float& dist, float& bx, float& by, float& bz) {
-  const float v0x = t[0], v0y = t[1], v0z = t[2];
-  const float e1x = t[3] - v0x, e1y = t[4] - v0y, e1z = t[5] - v0z;
-  const float e2x = t[6] - v0x, e2y = t[7] - v0y, e2z = t[8] - v0z;
+  const float v0x = t0.x, v0y = t0.y, v0z = t0.z;
+  const float e1x = t0.w, e1y = t1.x, e1z = t1.y;
+  const float e2x = t1.z, e2y = t1.w, e2z = t2.x;
   const float hx = dy * e2z - dz * e2y, hy = dz * e2x - dx * e2z, hz = dx * e2y - dy * e2x;
   const float a = e1x * hx + e1y * hy + e1z * hz;
   if (fabsf(a) < RC_EPSILON) return false;
@@ -82,222 +114,438 @@ __device__ __forceinline__ bool ray_tri(float ox, float oy, float oz, float dx, 
   return true;
 }
 
-struct RcHit { float dist, bx, by, bz; uint32_t blasIdx, triIdx; };
+__device__ __forceinline__ uint32_t f2u_x86(float f) { return (uint32_t)(long long)f; }   // uint32_t(float) as x86-64 g++ lowers it
 
-// render.h:143-190 TLASIntersect with BLASIntersect (:126-141) and BVHIntersect (:75-124) inlined.
-// Returns status bits (0 = fine).  Indices are bounds-checked so that a malformed scene cannot fault.
-__device__ uint32_t rc_trace(const RcDev& sc, float ox, float oy, float oz, float dx, float dy, float dz, RcHit& hit) {
-  hit.dist = RC_LARGE_FLOAT; hit.bx = 0; hit.by = 0; hit.bz = 0; hit.blasIdx = 0; hit.triIdx = 0;
-  uint32_t tstack[RC_STACK], bstack[RC_STACK];
-  uint32_t tsp = 0, iters = 0;
-  tstack[tsp++] = sc.tlas_root;
-  while (tsp != 0) {
-    const uint32_t nodeIdx = tstack[--tsp];
-    if (nodeIdx >= sc.n_tlas) return RC_STATUS_BAD_SCENE;
-    const uint32_t* nd = sc.tlas + (size_t)nodeIdx * 8;
-    const uint32_t leftRight = nd[3];
-    if (leftRight == 0u) {
-      const uint32_t blasIdx = nd[7];
-      if (blasIdx >= sc.n_blas) return RC_STATUS_BAD_SCENE;
-      const uint32_t* bp = sc.blas + (size_t)blasIdx * 40;
-      const float* M = (const float*)bp + 16;   // invTransform
-      // ray_t::transform (geometry.h:1411-1414): float4(v, w) * M, direction (w = 0) first, then origin (w = 1)
-      const float bdx = M[0] * dx + M[1] * dy + M[2] * dz + M[3] * 0.0f;
-      const float bdy = M[4] * dx + M[5] * dy + M[6] * dz + M[7] * 0.0f;
-      const float bdz = M[8] * dx + M[9] * dy + M[10] * dz + M[11] * 0.0f;
-      const float box = M[0] * ox + M[1] * oy + M[2] * oz + M[3] * 1.0f;
-      const float boy = M[4] * ox + M[5] * oy + M[6] * oz + M[7] * 1.0f;
-      const float boz = M[8] * ox + M[9] * oy + M[10] * oz + M[11] * 1.0f;
-      const uint32_t base = bp[32];
-      if (base >= sc.n_bvh) return RC_STATUS_BAD_SCENE;
-      const uint32_t nb = sc.n_bvh - base;
-      const uint32_t* bvh = sc.bvh + (size_t)base * 8;
-      uint32_t bsp = 0;
-      bstack[bsp++] = 0;
-      while (bsp != 0) {
-        if (++iters > RC_ITER_LIMIT) return RC_STATUS_ITER;
-        const uint32_t ni = bstack[--bsp];
-        if (ni >= nb) return RC_STATUS_BAD_SCENE;
-        const uint32_t* bn = bvh + (size_t)ni * 8;
-        const uint32_t leftFirst = bn[3], triCount = bn[7];
-        if (triCount != 0u) {
-          if ((uint64_t)leftFirst + triCount > sc.n_triIdx) return RC_STATUS_BAD_SCENE;
-          for (uint32_t i = 0; i < triCount; ++i) {
-            const uint32_t ti = sc.triIdx[leftFirst + i];
-            if (ti >= sc.n_tris) return RC_STATUS_BAD_SCENE;
+// ---------------------------------------------------------------------------------------------
+// acceleration-layout build (validates every index the BVH walk follows; a malformed scene fails on the host)
+// ---------------------------------------------------------------------------------------------
+// an internal node is well formed if its two children (adjacent, render.h:103-104; indices relative to the instance) lie inside
+// the instance's node range and AFTER the node: both builders allocate children after their parent, and requiring it makes
+// every accepted tree acyclic
+__device__ __forceinline__ bool rc_node_ok(const uint32_t* ref, uint32_t i, uint32_t base, uint32_t end) {
+  const uint64_t l64 = (uint64_t)base + ref[(size_t)i * 8 + 3];
+  return l64 > i && l64 + 1 < end && l64 + 1 < 0x3FFFFFF0ull;
+}
+// descriptor of child / root node ci (reachable, so what it names must exist: violations raise the status)
+__device__ uint32_t rc_child_desc(const uint32_t* ref, uint32_t ci, uint32_t base, uint32_t end, uint32_t n_tri_idx, uint32_t* status) {
+  const uint32_t* cw = ref + (size_t)ci * 8;
+  const uint32_t lf = cw[3], tc = cw[7];
+  if (tc == 0u) {                                                // internal
+    if (!rc_node_ok(ref, ci, base, end)) atomicOr(status, RC_STATUS_BAD_SCENE);
+    return ci;
+  }
+  if ((uint64_t)lf + tc > n_tri_idx) { atomicOr(status, RC_STATUS_BAD_SCENE); return RCD_LEAF | RCD_LEAF_REF | ci; }
+  if (tc <= 32u && lf <= RCD_FIRST_MASK) return RCD_LEAF | ((tc - 1u) << 25) | lf;
+  return RCD_LEAF | RCD_LEAF_REF | ci;
+}
+
+// one thread per reference node; bases/ends: sorted node ranges of the instances
+__global__ void rc_accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t n_nodes, uint4* __restrict__ out,
+                                      const uint32_t* __restrict__ bases, const uint32_t* __restrict__ ends, uint32_t nb,
+                                      uint32_t n_tri_idx, uint32_t* status) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  uint32_t base = 0, end = 0;
+  bool in = false;
+  for (uint32_t j = 0; j < nb; ++j) if (i >= bases[j] && i < ends[j]) { base = bases[j]; end = ends[j]; in = true; }
+  if (!in) return;
+  const uint32_t* w = ref + (size_t)i * 8;
+  if (w[7] != 0u) return;                                        // leaf: described by its parent (or by the root descriptor)
+  // a slot that is not a well-formed internal node (the unused tail and slot 1 of the reference's 2N-node buffer are zero) is left
+  // alone: if it is reachable, its parent -- or the root check -- has raised the status
+  if (!rc_node_ok(ref, i, base, end)) return;
+  const uint32_t l = base + w[3], r = l + 1;
+  const uint32_t* lw = ref + (size_t)l * 8;
+  const uint32_t* rw = ref + (size_t)r * 8;
+  uint4* o = out + (size_t)i * 4;
+  o[0] = make_uint4(lw[0], lw[1], lw[2], lw[4]);                 // L.min.xyz, L.max.x
+  o[1] = make_uint4(lw[5], lw[6], rw[0], rw[1]);                 // L.max.yz, R.min.xy
+  o[2] = make_uint4(rw[2], rw[4], rw[5], rw[6]);                 // R.min.z, R.max.xyz
+  o[3] = make_uint4(rc_child_desc(ref, l, base, end, n_tri_idx, status), rc_child_desc(ref, r, base, end, n_tri_idx, status), 0u, 0u);
+}
+
+__global__ void rc_accel_tris_kernel(const float* __restrict__ tri, const uint32_t* __restrict__ triIdx, uint32_t n_idx, uint32_t n_tris,
+                                     float4* __restrict__ out, uint32_t* status) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_idx) return;
+  const uint32_t ti = triIdx[j];
+  if (ti >= n_tris) { atomicOr(status, RC_STATUS_BAD_SCENE); return; }
+  const float* t = tri + (size_t)ti * 9;
+  const float v0x = t[0], v0y = t[1], v0z = t[2];
+  out[(size_t)j * 3 + 0] = make_float4(v0x, v0y, v0z, t[3] - v0x);
+  out[(size_t)j * 3 + 1] = make_float4(t[4] - v0y, t[5] - v0z, t[6] - v0x, t[7] - v0y);
+  out[(size_t)j * 3 + 2] = make_float4(t[8] - v0z, __uint_as_float(ti), 0.f, 0.f);
+}
+
+__global__ void rc_accel_roots_kernel(const uint32_t* __restrict__ ref, const uint32_t* __restrict__ blas, uint32_t n_blas, uint32_t n_bvh,
+                                      const uint32_t* __restrict__ bases, const uint32_t* __restrict__ ends, uint32_t nb,
+                                      uint32_t n_tri_idx, uint32_t* __restrict__ roots, uint32_t* status) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_blas) return;
+  const uint32_t base = blas[(size_t)j * 40 + 32];
+  roots[j] = RC_CUR_IDLE;
+  if (base >= n_bvh || base >= 0x3FFFFFF0u) { atomicOr(status, RC_STATUS_BAD_SCENE); return; }
+  uint32_t end = n_bvh;
+  for (uint32_t k = 0; k < nb; ++k) if (bases[k] == base) end = ends[k];
+  roots[j] = rc_child_desc(ref, base, base, end, n_tri_idx, status);       // bstack[0] = node 0 of the instance (render.h:84)
+}
+
+// ---------------------------------------------------------------------------------------------
+// persistent render kernel
+// ---------------------------------------------------------------------------------------------
+struct RcArgs {
+  uint32_t W, H, y0, y1, tiles_x, n_tiles, per_shard;
+  uint32_t* dst; float* colors; uint32_t* status; uint32_t* queue;
+};
+
+__global__ __launch_bounds__(256, 5) void rc_persistent_kernel(RcDev sc, RcParams p, RcArgs A) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  __shared__ uint32_t s_stk[4][RC_LDS_STACK][64];
+  // 0-2 world origin, 3-5 world direction, 6-8 object direction, 9-11 hit bx/by/bz, 12 hit blasIdx, 13 hit triIdx
+  __shared__ uint32_t s_ctx[4][14][64];
+  uint32_t* const lstk = &s_stk[wave][0][lane];
+  uint32_t* const ctx = &s_ctx[wave][0][lane];
+#define CTX(i) ctx[(i) * 64]
+#define CTXF(i) __uint_as_float(ctx[(i) * 64])
+  uint32_t ovf[RC_STACK];            // stack entries past the LDS part
+  uint32_t tstack[RC_STACK];         // TLAS stack (scratch; an instance list is walked once per ray)
+  // active object-space ray and traversal state in registers
+  float rox = 0, roy = 0, roz = 0, rix = 0, riy = 0, riz = 0, hitd = 0;
+  uint32_t cur = RC_CUR_IDLE, cur_blas = 0, sp = 0, tsp = 0, titer = 0;
+  // pixel / path state
+  uint32_t px = 0, py = 0, smp = 0, bounce = 0;
+  float cr = 0, cg = 0, cb = 0, rr = 0, rg = 0, rb = 0, thr = 1.0f;
+  // queue
+  bool queue_empty = false;
+  uint32_t shard = blockIdx.x % RC_QUEUE_SHARDS, tries = 0;
+
+  auto push = [&](uint32_t d) {
+    if (sp >= RC_STACK) { atomicOr(A.status, RC_STATUS_STACK); return; }
+    if (sp < RC_LDS_STACK) lstk[sp * 64] = d; else ovf[sp] = d;
+    ++sp;
+  };
+  auto pop = [&]() {
+    if (sp == 0) { cur = RC_CUR_TLAS; return; }
+    --sp;
+    cur = sp < RC_LDS_STACK ? lstk[sp * 64] : ovf[sp];
+  };
+  // a new ray of this lane (render.h:143-150: hit reset, TLAS root on the stack)
+  auto start_ray = [&](float ox, float oy, float oz, float dx, float dy, float dz) {
+    CTX(0) = __float_as_uint(ox); CTX(1) = __float_as_uint(oy); CTX(2) = __float_as_uint(oz);
+    CTX(3) = __float_as_uint(dx); CTX(4) = __float_as_uint(dy); CTX(5) = __float_as_uint(dz);
+    hitd = RC_LARGE_FLOAT;
+    CTX(9) = 0; CTX(10) = 0; CTX(11) = 0; CTX(12) = 0; CTX(13) = 0;
+    tsp = 0; sp = 0; titer = 0;
+    tstack[tsp++] = sc.tlas_root;
+    cur = RC_CUR_TLAS;
+  };
+  // render.h:192-211 GenerateRay
+  auto primary_ray = [&]() {
+    const float x_ndc = (float)((double)(((float)px + 0.5f) / (float)A.W) - 0.5);
+    const float y_ndc = (float)((double)(((float)py + 0.5f) / (float)A.H) - 0.5);
+    const float x_vp = x_ndc * p.viewplane[0], y_vp = y_ndc * p.viewplane[1];
+    const float cx = x_vp * p.cright[0] + y_vp * p.cup[0] + p.cfwd[0];
+    const float cy = x_vp * p.cright[1] + y_vp * p.cup[1] + p.cfwd[1];
+    const float cz = x_vp * p.cright[2] + y_vp * p.cup[2] + p.cfwd[2];
+    const float wx = cx + p.cpos[0], wy = cy + p.cpos[1], wz = cz + p.cpos[2];
+    const float vx = wx - p.cpos[0], vy = wy - p.cpos[1], vz = wz - p.cpos[2];
+    const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+    rr = 0.f; rg = 0.f; rb = 0.f; thr = 1.0f; bounce = 0;
+    start_ray(p.cpos[0], p.cpos[1], p.cpos[2], vx * inv, vy * inv, vz * inv);
+  };
+
+  for (;;) {
+    // ================= fetch: one 8x8 tile per wavefront once every lane is idle =================
+    if (__ballot(cur != RC_CUR_IDLE) == 0ull) {
+      uint32_t tile = 0xFFFFFFFFu;
+      while (!queue_empty && tries < RC_QUEUE_SHARDS) {
+        const uint32_t s_lo = shard * A.per_shard;
+        const uint32_t s_n = s_lo < A.n_tiles ? min(A.per_shard, A.n_tiles - s_lo) : 0u;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(A.queue + shard * RC_QUEUE_STRIDE, 1u);
+        base = __shfl(base, 0);
+        if (base < s_n) { tile = s_lo + base; break; }
+        shard = (shard + 1u) % RC_QUEUE_SHARDS;
+        ++tries;
+      }
+      if (tile == 0xFFFFFFFFu) { queue_empty = true; break; }
+      px = (tile % A.tiles_x) * 8u + (lane & 7u);
+      py = A.y0 + (tile / A.tiles_x) * 8u + (lane >> 3);
+      if (px < A.W && py < A.y1) {
+        smp = 0; cr = 0.f; cg = 0.f; cb = 0.f;
+        primary_ray();
+      }
+    }
+
+    // ================= traverse: one step of whatever each lane holds, per iteration =================
+    for (;;) {
+      if (rc_is_node(cur)) {
+        // ---- BVH internal node (render.h:99-121): both children's boxes in one 64-byte record ----
+        const uint4* np = sc.nodes_c + (size_t)cur * 4;
+        const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+        const float dLeft = ray_box(rox, roy, roz, rix, riy, riz, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z),
+                                    __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+        const float dRight = ray_box(rox, roy, roz, rix, riy, riz, __uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x),
+                                     __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w));
+        uint32_t left = q3.x, right = q3.y;
+        const bool hitLeft = (dLeft != RC_LARGE_FLOAT) && (dLeft < hitd);
+        const bool hitRight = (dRight != RC_LARGE_FLOAT) && (dRight < hitd);
+        if (hitLeft && hitRight) {
+          if (dLeft < dRight) { const uint32_t t = left; left = right; right = t; }   // :110 as written: the farther child is visited first
+          push(right);
+          cur = left;
+        } else if (hitLeft) cur = left;
+        else if (hitRight) cur = right;
+        else pop();
+      }
+      if (__ballot(rc_is_leaf(cur)) != 0ull) {
+        if (rc_is_leaf(cur)) {
+          // ---- BVH leaf (render.h:88-98): triangles in triIdx order, strict '<' ----
+          uint32_t first, count;
+          if (cur & RCD_LEAF_REF) { const uint32_t* rn = sc.bvh + (size_t)(cur & 0x3FFFFFFFu) * 8; first = rn[3]; count = rn[7]; }
+          else { first = cur & RCD_FIRST_MASK; count = ((cur >> 25) & 31u) + 1u; }
+          const float cdx = CTXF(6), cdy = CTXF(7), cdz = CTXF(8);
+          for (uint32_t i = 0; i < count; ++i) {
+            const float4* tp = sc.tri_w + (size_t)(first + i) * 3;
+            const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
             float d, b0, b1, b2;
-            if (ray_tri(box, boy, boz, bdx, bdy, bdz, sc.tri + (size_t)ti * 9, d, b0, b1, b2) && d < hit.dist) {
-              hit.dist = d; hit.bx = b0; hit.by = b1; hit.bz = b2; hit.blasIdx = blasIdx; hit.triIdx = ti;
+            if (ray_tri(rox, roy, roz, cdx, cdy, cdz, t0, t1, t2, d, b0, b1, b2) && d < hitd) {
+              hitd = d;
+              CTX(9) = __float_as_uint(b0); CTX(10) = __float_as_uint(b1); CTX(11) = __float_as_uint(b2);
+              CTX(12) = cur_blas; CTX(13) = __float_as_uint(t2.y);
             }
           }
-        } else {
-          uint32_t left = leftFirst, right = left + 1;
-          if (right >= nb || right < left) return RC_STATUS_BAD_SCENE;
-          const float* ln = (const float*)(bvh + (size_t)left * 8);
-          const float* rn = (const float*)(bvh + (size_t)right * 8);
-          const float dLeft = ray_box(box, boy, boz, bdx, bdy, bdz, ln, ln + 4);
-          const float dRight = ray_box(box, boy, boz, bdx, bdy, bdz, rn, rn + 4);
-          const bool hitLeft = (dLeft != RC_LARGE_FLOAT) && (dLeft < hit.dist);
-          const bool hitRight = (dRight != RC_LARGE_FLOAT) && (dRight < hit.dist);
-          if (hitLeft && hitRight) {
-            if (dLeft < dRight) { const uint32_t t = left; left = right; right = t; }   // :110 as written
-            if (bsp + 2 > RC_STACK) return RC_STATUS_STACK;
-            bstack[bsp++] = right;
-            bstack[bsp++] = left;
-          } else if (hitLeft) {
-            if (bsp + 1 > RC_STACK) return RC_STATUS_STACK;
-            bstack[bsp++] = left;
-          } else if (hitRight) {
-            if (bsp + 1 > RC_STACK) return RC_STATUS_STACK;
-            bstack[bsp++] = right;
+          pop();
+        }
+      }
+      if (__ballot(cur == RC_CUR_TLAS) != 0ull) {
+        if (cur == RC_CUR_TLAS) {
+          // ---- TLAS step (render.h:152-187), on the buffers as uploaded ----
+          if (tsp == 0) cur = RC_CUR_SHADE;
+          else if (++titer > RC_TLAS_ITER_LIMIT) { atomicOr(A.status, RC_STATUS_ITER); cur = RC_CUR_SHADE; }
+          else {
+            const uint32_t nodeIdx = tstack[--tsp];
+            if (nodeIdx >= sc.n_tlas) { atomicOr(A.status, RC_STATUS_BAD_SCENE); cur = RC_CUR_SHADE; }
+            else {
+              const uint32_t* nd = sc.tlas + (size_t)nodeIdx * 8;
+              const uint32_t leftRight = nd[3];
+              const float ox = CTXF(0), oy = CTXF(1), oz = CTXF(2), dx = CTXF(3), dy = CTXF(4), dz = CTXF(5);
+              if (leftRight == 0u) {
+                const uint32_t blasIdx = nd[7];
+                if (blasIdx >= sc.n_blas) { atomicOr(A.status, RC_STATUS_BAD_SCENE); cur = RC_CUR_SHADE; }
+                else {
+                  const uint32_t* bp = sc.blas + (size_t)blasIdx * 40;
+                  const float* M = (const float*)bp + 16;   // invTransform
+                  // ray_t::transform (geometry.h:1411-1414): float4(v, w) * M, direction (w = 0) first, then origin (w = 1)
+                  const float bdx = M[0] * dx + M[1] * dy + M[2] * dz + M[3] * 0.0f;
+                  const float bdy = M[4] * dx + M[5] * dy + M[6] * dz + M[7] * 0.0f;
+                  const float bdz = M[8] * dx + M[9] * dy + M[10] * dz + M[11] * 0.0f;
+                  rox = M[0] * ox + M[1] * oy + M[2] * oz + M[3] * 1.0f;
+                  roy = M[4] * ox + M[5] * oy + M[6] * oz + M[7] * 1.0f;
+                  roz = M[8] * ox + M[9] * oy + M[10] * oz + M[11] * 1.0f;
+                  rix = 1.0f / bdx; riy = 1.0f / bdy; riz = 1.0f / bdz;
+                  CTX(6) = __float_as_uint(bdx); CTX(7) = __float_as_uint(bdy); CTX(8) = __float_as_uint(bdz);
+                  cur_blas = blasIdx;
+                  sp = 0;
+                  cur = sc.blas_root[blasIdx];
+                  if (cur == RC_CUR_IDLE) { atomicOr(A.status, RC_STATUS_BAD_SCENE); cur = RC_CUR_TLAS; }
+                }
+              } else {
+                uint32_t left = leftRight & 0xFFFFu, right = leftRight >> 16;
+                if (left >= sc.n_tlas || right >= sc.n_tlas) { atomicOr(A.status, RC_STATUS_BAD_SCENE); cur = RC_CUR_SHADE; }
+                else {
+                  const float* ln = (const float*)(sc.tlas + (size_t)left * 8);
+                  const float* rn = (const float*)(sc.tlas + (size_t)right * 8);
+                  const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+                  const float dLeft = ray_box(ox, oy, oz, ix, iy, iz, ln[0], ln[1], ln[2], ln[4], ln[5], ln[6]);
+                  const float dRight = ray_box(ox, oy, oz, ix, iy, iz, rn[0], rn[1], rn[2], rn[4], rn[5], rn[6]);
+                  const bool hitLeft = (dLeft != RC_LARGE_FLOAT) && (dLeft < hitd);
+                  const bool hitRight = (dRight != RC_LARGE_FLOAT) && (dRight < hitd);
+                  if (hitLeft && hitRight) {
+                    if (dLeft > dRight) { const uint32_t t = left; left = right; right = t; }   // :176
+                    if (tsp + 2 > RC_STACK) atomicOr(A.status, RC_STATUS_STACK);
+                    else { tstack[tsp++] = right; tstack[tsp++] = left; }
+                  } else if (hitLeft) {
+                    if (tsp + 1 > RC_STACK) atomicOr(A.status, RC_STATUS_STACK); else tstack[tsp++] = left;
+                  } else if (hitRight) {
+                    if (tsp + 1 > RC_STACK) atomicOr(A.status, RC_STATUS_STACK); else tstack[tsp++] = right;
+                  }
+                }
+              }
+            }
           }
         }
       }
-    } else {
-      if (++iters > RC_ITER_LIMIT) return RC_STATUS_ITER;
-      uint32_t left = leftRight & 0xFFFFu, right = leftRight >> 16;
-      if (left >= sc.n_tlas || right >= sc.n_tlas) return RC_STATUS_BAD_SCENE;
-      const float* ln = (const float*)(sc.tlas + (size_t)left * 8);
-      const float* rn = (const float*)(sc.tlas + (size_t)right * 8);
-      const float dLeft = ray_box(ox, oy, oz, dx, dy, dz, ln, ln + 4);
-      const float dRight = ray_box(ox, oy, oz, dx, dy, dz, rn, rn + 4);
-      const bool hitLeft = (dLeft != RC_LARGE_FLOAT) && (dLeft < hit.dist);
-      const bool hitRight = (dRight != RC_LARGE_FLOAT) && (dRight < hit.dist);
-      if (hitLeft && hitRight) {
-        if (dLeft > dRight) { const uint32_t t = left; left = right; right = t; }   // :176
-        if (tsp + 2 > RC_STACK) return RC_STATUS_STACK;
-        tstack[tsp++] = right;
-        tstack[tsp++] = left;
-      } else if (hitLeft) {
-        if (tsp + 1 > RC_STACK) return RC_STATUS_STACK;
-        tstack[tsp++] = left;
-      } else if (hitRight) {
-        if (tsp + 1 > RC_STACK) return RC_STATUS_STACK;
-        tstack[tsp++] = right;
+      if (__ballot(cur < RC_CUR_SHADE) == 0ull) break;   // no lane has traversal work left: shade the tile's finished rays
+    }
+
+    // ================= shade: render.h:213-275 Trace, one bounce per pass =================
+    if (cur == RC_CUR_SHADE) {
+      const float ox = CTXF(0), oy = CTXF(1), oz = CTXF(2), dx = CTXF(3), dy = CTXF(4), dz = CTXF(5);
+      bool next_ray = false;
+      if (hitd == RC_LARGE_FLOAT) {
+        rr = rr + p.bg[0] * thr; rg = rg + p.bg[1] * thr; rb = rb + p.bg[2] * thr;   // :230
+      } else {
+        const float hbx = CTXF(9), hby = CTXF(10), hbz = CTXF(11);
+        const uint32_t hblas = CTX(12), htri = CTX(13);
+        const uint32_t* bp = sc.blas + (size_t)hblas * 40;
+        const float* te = sc.triEx + (size_t)htri * 15;   // N0 N1 N2 uv0 uv1 uv2
+        const float Ix = ox + dx * hitd, Iy = oy + dy * hitd, Iz = oz + dz * hitd;   // :239
+        float Nx = te[3] * hbx + te[6] * hby + te[0] * hbz;                             // :242 N1*bx + N2*by + N0*bz
+        float Ny = te[4] * hbx + te[7] * hby + te[1] * hbz;
+        float Nz = te[5] * hbx + te[8] * hby + te[2] * hbz;
+        const float* m = (const float*)bp + 16;
+        const float z0 = 0.0f * 0.0f;
+        const float Tx = m[0] * Nx + m[4] * Ny + m[8] * Nz + z0;     // float4(N,0) * transposed 3x3 (geometry.h:1141-1147)
+        const float Ty = m[1] * Nx + m[5] * Ny + m[9] * Nz + z0;
+        const float Tz = m[2] * Nx + m[6] * Ny + m[10] * Nz + z0;
+        const float inv = 1.0f / sqrtf(Tx * Tx + Ty * Ty + Tz * Tz);
+        Nx = Tx * inv; Ny = Ty * inv; Nz = Tz * inv;
+        const float u = te[11] * hbx + te[13] * hby + te[9] * hbz;    // :247 uv1*bx + uv2*by + uv0*bz
+        const float v = te[12] * hbx + te[14] * hby + te[10] * hbz;
+        const unsigned long long tex_offset = (unsigned long long)bp[34] | ((unsigned long long)bp[35] << 32);
+        const uint32_t tw = bp[36], th = bp[37];
+        float cr_ = 0.f, cg_ = 0.f, cb_ = 0.f;
+        if (tw == 0u || th == 0u || tex_offset > sc.tex_bytes || (unsigned long long)tw * th > (sc.tex_bytes - tex_offset) / 4ull) {
+          atomicOr(A.status, RC_STATUS_BAD_SCENE);
+        } else {
+          uint32_t iu = f2u_x86(u * (float)tw), iv = f2u_x86(v * (float)th);
+          iu %= tw; iv %= th;
+          const uint32_t texel = ((const uint32_t*)(sc.tex + tex_offset))[iu + iv * tw];
+          const float s256 = 1 / 256.0f;
+          cr_ = (float)(int)((texel >> 16) & 255) * s256; cg_ = (float)(int)((texel >> 8) & 255) * s256; cb_ = (float)(int)(texel & 255) * s256;
+        }
+        // diffuseLighting :59-71
+        float Lx = p.lpos[0] - Ix, Ly = p.lpos[1] - Iy, Lz = p.lpos[2] - Iz;
+        const float dist = sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
+        const float il = 1.0f / dist;
+        Lx *= il; Ly *= il; Lz *= il;
+        const float att = 1.0f / (1.0f + dist * 0.1f);
+        const float NdotL = std_max(0.0f, Nx * Lx + Ny * Ly + Nz * Lz);
+        const float dr = cr_ * (p.amb[0] + att * p.lcol[0] * NdotL);
+        const float dg = cg_ * (p.amb[1] + att * p.lcol[1] * NdotL);
+        const float db = cb_ * (p.amb[2] + att * p.lcol[2] * NdotL);
+        const float refl = __uint_as_float(bp[38]);
+        rr = rr + thr * dr * (1 - refl); rg = rg + thr * dg * (1 - refl); rb = rb + thr * db * (1 - refl);   // :257
+        thr *= refl;                                                                                           // :260
+        if (refl > 0.0f && bounce + 1 < p.max_depth) {                                                          // :263-268
+          const float nd = Nx * dx + Ny * dy + Nz * dz;
+          const float vx = dx - (2.0f * Nx) * nd, vy = dy - (2.0f * Ny) * nd, vz = dz - (2.0f * Nz) * nd;
+          const float rinv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+          const float Rx = vx * rinv, Ry = vy * rinv, Rz = vz * rinv;
+          ++bounce;
+          start_ray(Ix + Rx * 0.001f, Iy + Ry * 0.001f, Iz + Rz * 0.001f, Rx, Ry, Rz);
+          next_ray = true;
+        } else {
+          rr = rr + thr * p.bg[0]; rg = rg + thr * p.bg[1]; rb = rb + thr * p.bg[2];                           // :271
+        }
+      }
+      if (!next_ray) {
+        // (a sample whose loop ran out of depth ends here too: `for bounce < max_depth` leaves with the radiance so far)
+        cr = cr + rr; cg = cg + rg; cb = cb + rb;          // kernel.cpp:24
+        if (++smp < p.spp) primary_ray();
+        else {
+          const size_t idx = (size_t)px + (size_t)py * A.W;
+          const int ir = (int)(std_min(cr, 1.f) * 255), ig = (int)(std_min(cg, 1.f) * 255), ib = (int)(std_min(cb, 1.f) * 255);   // common.h:107-112
+          A.dst[idx] = (uint32_t)((ir << 16) + (ig << 8) + ib);
+          if (A.colors) { A.colors[3 * idx] = cr; A.colors[3 * idx + 1] = cg; A.colors[3 * idx + 2] = cb; }
+          cur = RC_CUR_IDLE;
+        }
       }
     }
   }
-  return 0u;
-}
-
-__device__ __forceinline__ uint32_t f2u_x86(float f) { return (uint32_t)(long long)f; }   // uint32_t(float) as x86-64 g++ lowers it
-
-// render.h:213-275 Trace
-__device__ uint32_t rc_radiance(const RcDev& sc, const RcParams& p, float ox, float oy, float oz, float dx, float dy, float dz,
-                                float& R_, float& G_, float& B_) {
-  float rr = 0.f, rg = 0.f, rb = 0.f, thr = 1.0f;
-  for (uint32_t bounce = 0; bounce < p.max_depth; ++bounce) {
-    RcHit hit;
-    const uint32_t st = rc_trace(sc, ox, oy, oz, dx, dy, dz, hit);
-    if (st) return st;
-    if (hit.dist == RC_LARGE_FLOAT) {
-      rr = rr + p.bg[0] * thr; rg = rg + p.bg[1] * thr; rb = rb + p.bg[2] * thr;   // :230
-      break;
-    }
-    const uint32_t* bp = sc.blas + (size_t)hit.blasIdx * 40;
-    const float* te = sc.triEx + (size_t)hit.triIdx * 15;   // N0 N1 N2 uv0 uv1 uv2
-    const float Ix = ox + dx * hit.dist, Iy = oy + dy * hit.dist, Iz = oz + dz * hit.dist;   // :239
-    float Nx = te[3] * hit.bx + te[6] * hit.by + te[0] * hit.bz;                             // :242 N1*bx + N2*by + N0*bz
-    float Ny = te[4] * hit.bx + te[7] * hit.by + te[1] * hit.bz;
-    float Nz = te[5] * hit.bx + te[8] * hit.by + te[2] * hit.bz;
-    const float* m = (const float*)bp + 16;
-    const float z0 = 0.0f * 0.0f;
-    const float Tx = m[0] * Nx + m[4] * Ny + m[8] * Nz + z0;     // float4(N,0) * transposed 3x3 (geometry.h:1141-1147)
-    const float Ty = m[1] * Nx + m[5] * Ny + m[9] * Nz + z0;
-    const float Tz = m[2] * Nx + m[6] * Ny + m[10] * Nz + z0;
-    const float inv = 1.0f / sqrtf(Tx * Tx + Ty * Ty + Tz * Tz);
-    Nx = Tx * inv; Ny = Ty * inv; Nz = Tz * inv;
-    const float u = te[11] * hit.bx + te[13] * hit.by + te[9] * hit.bz;    // :247 uv1*bx + uv2*by + uv0*bz
-    const float v = te[12] * hit.bx + te[14] * hit.by + te[10] * hit.bz;
-    const unsigned long long tex_offset = (unsigned long long)bp[34] | ((unsigned long long)bp[35] << 32);
-    const uint32_t tw = bp[36], th = bp[37];
-    if (tw == 0u || th == 0u || tex_offset + (unsigned long long)tw * th * 4ull > sc.tex_bytes) return RC_STATUS_BAD_SCENE;
-    uint32_t iu = f2u_x86(u * (float)tw), iv = f2u_x86(v * (float)th);
-    iu %= tw; iv %= th;
-    const uint32_t texel = ((const uint32_t*)(sc.tex + tex_offset))[iu + iv * tw];
-    const float s256 = 1 / 256.0f;
-    const float cr = (float)(int)((texel >> 16) & 255) * s256, cg = (float)(int)((texel >> 8) & 255) * s256, cb = (float)(int)(texel & 255) * s256;
-    // diffuseLighting :59-71
-    float Lx = p.lpos[0] - Ix, Ly = p.lpos[1] - Iy, Lz = p.lpos[2] - Iz;
-    const float dist = sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
-    const float il = 1.0f / dist;
-    Lx *= il; Ly *= il; Lz *= il;
-    const float att = 1.0f / (1.0f + dist * 0.1f);
-    const float NdotL = std_max(0.0f, Nx * Lx + Ny * Ly + Nz * Lz);
-    const float dr = cr * (p.amb[0] + att * p.lcol[0] * NdotL);
-    const float dg = cg * (p.amb[1] + att * p.lcol[1] * NdotL);
-    const float db = cb * (p.amb[2] + att * p.lcol[2] * NdotL);
-    const float refl = __uint_as_float(bp[38]);
-    rr = rr + thr * dr * (1 - refl); rg = rg + thr * dg * (1 - refl); rb = rb + thr * db * (1 - refl);   // :257
-    thr *= refl;                                                                                           // :260
-    if (refl > 0.0f && bounce + 1 < p.max_depth) {                                                          // :263-268
-      const float nd = Nx * dx + Ny * dy + Nz * dz;
-      const float vx = dx - (2.0f * Nx) * nd, vy = dy - (2.0f * Ny) * nd, vz = dz - (2.0f * Nz) * nd;
-      const float rinv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
-      const float Rx = vx * rinv, Ry = vy * rinv, Rz = vz * rinv;
-      ox = Ix + Rx * 0.001f; oy = Iy + Ry * 0.001f; oz = Iz + Rz * 0.001f;
-      dx = Rx; dy = Ry; dz = Rz;
-      continue;
-    }
-    rr = rr + thr * p.bg[0]; rg = rg + thr * p.bg[1]; rb = rb + thr * p.bg[2];                               // :271
-    break;
-  }
-  R_ = rr; G_ = rg; B_ = rb;
-  return 0u;
-}
-
-// kernel.cpp:9-33: 16x4 pixel blocks, lane = pixel
-__global__ __launch_bounds__(64) void rc_render_kernel(RcDev sc, RcParams p, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
-                                                      uint32_t* __restrict__ dst, float* __restrict__ colors, uint32_t* status) {
-  const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u);
-  const uint32_t y = y0 + blockIdx.y * 4u + (threadIdx.x >> 4);
-  if (x >= W || y >= y1) return;
-  // render.h:192-211 GenerateRay
-  const float x_ndc = (float)((double)(((float)x + 0.5f) / (float)W) - 0.5);
-  const float y_ndc = (float)((double)(((float)y + 0.5f) / (float)H) - 0.5);
-  const float x_vp = x_ndc * p.viewplane[0], y_vp = y_ndc * p.viewplane[1];
-  const float cx = x_vp * p.cright[0] + y_vp * p.cup[0] + p.cfwd[0];
-  const float cy = x_vp * p.cright[1] + y_vp * p.cup[1] + p.cfwd[1];
-  const float cz = x_vp * p.cright[2] + y_vp * p.cup[2] + p.cfwd[2];
-  const float wx = cx + p.cpos[0], wy = cy + p.cpos[1], wz = cz + p.cpos[2];
-  const float vx = wx - p.cpos[0], vy = wy - p.cpos[1], vz = wz - p.cpos[2];
-  const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
-  const float dx = vx * inv, dy = vy * inv, dz = vz * inv;
-  float cr = 0.f, cg = 0.f, cb = 0.f;
-  for (uint32_t s = 0; s < p.spp; ++s) {
-    float r = 0.f, g = 0.f, b = 0.f;
-    const uint32_t st = rc_radiance(sc, p, p.cpos[0], p.cpos[1], p.cpos[2], dx, dy, dz, r, g, b);
-    if (st) { atomicOr(status, st); break; }
-    cr = cr + r; cg = cg + g; cb = cb + b;
-  }
-  const size_t idx = (size_t)x + (size_t)y * W;
-  const int ir = (int)(std_min(cr, 1.f) * 255), ig = (int)(std_min(cg, 1.f) * 255), ib = (int)(std_min(cb, 1.f) * 255);   // common.h:107-112
-  dst[idx] = (uint32_t)((ir << 16) + (ig << 8) + ib);
-  if (colors) { colors[3 * idx] = cr; colors[3 * idx + 1] = cg; colors[3 * idx + 2] = cb; }
+#undef CTX
+#undef CTXF
 }
 
 }  // namespace
 
-extern "C" int vxrc_render(const vxrc_scene_t* s, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
-                           const vxrc_params_t* prm, uint32_t* dst, float* colors, void* stream) {
-  if (!s || !prm || !dst) return -1;
+// ---------------------------------------------------------------------------------------------
+// host entry points
+// ---------------------------------------------------------------------------------------------
+struct vxrc_accel {
+  vxrc_scene_t ref{};
+  void* nodes_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr; uint32_t* ctl = nullptr;
+};
+
+extern "C" int vxrc_accel_destroy(vxrc_accel_t* a) {
+  if (!a) return 0;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(a->nodes_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root); (void)hipFree(a->ctl);
+  delete a;
+  return 0;
+}
+
+extern "C" int vxrc_accel_build(const vxrc_scene_t* s, void* stream, vxrc_accel_t** out) {
+  if (!s || !out) return -1;
   if (!s->tlas || !s->blas || !s->bvh || !s->tri || !s->triEx || !s->triIdx || !s->tex) return -1;
   if (s->n_tlas_nodes == 0 || s->n_blas == 0 || s->n_bvh_nodes == 0 || s->n_tris == 0 || s->n_tri_idx == 0) return -1;
   if (s->tlas_root >= s->n_tlas_nodes) return -1;
+  if (s->n_bvh_nodes >= 0x3FFFFFF0u) return -1;   // node indices share the descriptor space with the state markers
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<uint32_t> recs((size_t)s->n_blas * 40);
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;
+  if (hipMemcpy(recs.data(), s->blas, recs.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  std::vector<uint32_t> bases;
+  for (uint32_t j = 0; j < s->n_blas; ++j) {
+    const uint32_t off = recs[(size_t)j * 40 + 32];
+    if (off >= s->n_bvh_nodes) return -1;
+    bases.push_back(off);
+  }
+  std::sort(bases.begin(), bases.end());
+  bases.erase(std::unique(bases.begin(), bases.end()), bases.end());
+  std::vector<uint32_t> ends(bases.size());
+  for (size_t j = 0; j < bases.size(); ++j) ends[j] = j + 1 < bases.size() ? bases[j + 1] : s->n_bvh_nodes;
+  auto a = new (std::nothrow) vxrc_accel();
+  if (!a) return -1;
+  a->ref = *s;
+  uint32_t* d_ranges = nullptr; uint32_t* d_status = nullptr;
+  bool ok = hipMalloc(&a->nodes_c, (size_t)s->n_bvh_nodes * 64) == hipSuccess &&
+            hipMalloc(&a->tri_w, (size_t)s->n_tri_idx * 48) == hipSuccess &&
+            hipMalloc(&a->blas_root, (size_t)s->n_blas * 4) == hipSuccess &&
+            hipMalloc((void**)&a->ctl, RC_CTL_DWORDS * 4) == hipSuccess &&
+            hipMalloc((void**)&d_ranges, bases.size() * 8) == hipSuccess && hipMalloc((void**)&d_status, 4) == hipSuccess;
+  uint32_t hstatus = 0;
+  if (ok) {
+    ok = hipMemcpy(d_ranges, bases.data(), bases.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_ranges + bases.size(), ends.data(), ends.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(d_status, 0, 4) == hipSuccess && hipMemsetAsync(a->tri_w, 0, (size_t)s->n_tri_idx * 48, st) == hipSuccess;
+  }
+  if (ok) {
+    const uint32_t nb = (uint32_t)bases.size();
+    hipLaunchKernelGGL(rc_accel_nodes_kernel, dim3((s->n_bvh_nodes + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->bvh, s->n_bvh_nodes, (uint4*)a->nodes_c,
+                       d_ranges, d_ranges + nb, nb, s->n_tri_idx, d_status);
+    hipLaunchKernelGGL(rc_accel_tris_kernel, dim3((s->n_tri_idx + 255) / 256), dim3(256), 0, st, (const float*)s->tri, (const uint32_t*)s->triIdx, s->n_tri_idx,
+                       s->n_tris, (float4*)a->tri_w, d_status);
+    hipLaunchKernelGGL(rc_accel_roots_kernel, dim3((s->n_blas + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->bvh, (const uint32_t*)s->blas, s->n_blas,
+                       s->n_bvh_nodes, d_ranges, d_ranges + nb, nb, s->n_tri_idx, (uint32_t*)a->blas_root, d_status);
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+         hipMemcpy(&hstatus, d_status, 4, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(d_ranges); (void)hipFree(d_status);
+  if (!ok || hstatus != 0) { vxrc_accel_destroy(a); return -1; }
+  *out = a;
+  return 0;
+}
+
+extern "C" int vxrc_render_accel(vxrc_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                                 const vxrc_params_t* prm, uint32_t* dst, float* colors, void* stream) {
+  if (!a || !prm || !dst) return -1;
   if (width == 0 || height == 0 || y0 > y1 || y1 > height) return -1;
   if (prm->samples_per_pixel == 0) return -1;   // leaves every pixel black in the reference; refuse like the RTU path
   if (y0 == y1) return 0;
   uint32_t* st = vxrt_status_word_device();
   if (!st) return -1;
+  const vxrc_scene_t* s = &a->ref;
   RcDev d{};
   d.tlas = (const uint32_t*)s->tlas; d.n_tlas = s->n_tlas_nodes;
   d.blas = (const uint32_t*)s->blas; d.n_blas = s->n_blas;
   d.bvh = (const uint32_t*)s->bvh; d.n_bvh = s->n_bvh_nodes;
-  d.tri = (const float*)s->tri; d.n_tris = s->n_tris;
   d.triEx = (const float*)s->triEx;
-  d.triIdx = (const uint32_t*)s->triIdx; d.n_triIdx = s->n_tri_idx;
   d.tex = (const uint8_t*)s->tex; d.tex_bytes = s->tex_bytes;
   d.tlas_root = s->tlas_root;
+  d.nodes_c = (const uint4*)a->nodes_c; d.tri_w = (const float4*)a->tri_w; d.blas_root = (const uint32_t*)a->blas_root;
+  d.n_tri_idx = s->n_tri_idx;
   RcParams p{};
   for (int i = 0; i < 3; ++i) {
     p.cpos[i] = prm->camera_pos[i]; p.cfwd[i] = prm->camera_forward[i]; p.cright[i] = prm->camera_right[i]; p.cup[i] = prm->camera_up[i];
@@ -305,7 +553,37 @@ extern "C" int vxrc_render(const vxrc_scene_t* s, uint32_t width, uint32_t heigh
   }
   p.viewplane[0] = prm->viewplane[0]; p.viewplane[1] = prm->viewplane[1];
   p.spp = prm->samples_per_pixel; p.max_depth = prm->max_depth;
-  const dim3 grid((width + 15u) / 16u, (y1 - y0 + 3u) / 4u);
-  hipLaunchKernelGGL(rc_render_kernel, grid, dim3(64), 0, (hipStream_t)stream, d, p, width, height, y0, y1, dst, colors, st);
+  hipStream_t hs = (hipStream_t)stream;
+  RcArgs A{};
+  A.W = width; A.H = height; A.y0 = y0; A.y1 = y1;
+  A.tiles_x = (width + 7) / 8;
+  const uint64_t nt = (uint64_t)A.tiles_x * ((y1 - y0 + 7) / 8);
+  if (nt > 0x3ffffffull) return -1;
+  A.n_tiles = (uint32_t)nt;
+  A.per_shard = (A.n_tiles + RC_QUEUE_SHARDS - 1) / RC_QUEUE_SHARDS;
+  A.dst = dst; A.colors = colors; A.status = st; A.queue = a->ctl;
+  if (hipMemsetAsync(a->ctl, 0, RC_CTL_DWORDS * 4, hs) != hipSuccess) return -1;
+  static int per_cu = 0, cus = 0;
+  if (!per_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rc_persistent_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  }
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * cus, (nt + 3) / 4);
+  hipLaunchKernelGGL(rc_persistent_kernel, dim3(grid ? grid : 1), dim3(256), 0, hs, d, p, A);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// one-shot form: layout built, frame rendered, layout freed (tests, callers that render a scene once)
+extern "C" int vxrc_render(const vxrc_scene_t* s, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                           const vxrc_params_t* prm, uint32_t* dst, float* colors, void* stream) {
+  if (!s || !prm || !dst) return -1;
+  if (width == 0 || height == 0 || y0 > y1 || y1 > height) return -1;
+  if (prm->samples_per_pixel == 0) return -1;
+  vxrc_accel_t* a = nullptr;
+  if (vxrc_accel_build(s, stream, &a) != 0) return -1;
+  const int rc = vxrc_render_accel(a, width, height, y0, y1, prm, dst, colors, stream);
+  vxrc_accel_destroy(a);   // (synchronises the device)
+  return rc;
 }

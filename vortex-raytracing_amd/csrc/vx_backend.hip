@@ -79,6 +79,8 @@ struct vx_device {
   // acceleration layout of the scene last started, rebuilt only when one of the four traversal
   // buffers was re-uploaded or re-pointed (key = device pointers + upload versions)
   vxrt_accel_t* accel = nullptr;
+  vxrc_accel_t* rc_accel = nullptr;   // layout of the raycast twin's scene, rebuilt when one of its buffers is re-uploaded
+  uint64_t rc_key[16] = {0};
   uint64_t accel_key[14] = {0};
 
   int init() {
@@ -102,6 +104,7 @@ struct vx_device {
     (void)hipSetDevice(hip_dev);
     if (stream) (void)hipStreamSynchronize(stream);   // simx dtor waits for the run (vortex.cpp:69-71)
     if (accel) (void)vxrt_accel_destroy(accel);
+    if (rc_accel) (void)vxrc_accel_destroy(rc_accel);
     for (auto& kv : allocs) if (kv.second.dptr && !kv.second.pooled) (void)hipFree(kv.second.dptr);
     for (void* sl : slabs) (void)hipFree(sl);
     if (d_rays) (void)hipFree(d_rays);
@@ -182,6 +185,10 @@ struct vx_device {
     wait_idle();
     (void)hipSetDevice(hip_dev);
     if (accel_uses(it->second)) { (void)vxrt_accel_destroy(accel); accel = nullptr; }   // it references this buffer
+    if (rc_accel) {
+      const uint64_t lo = (uint64_t)it->second.dptr, hi = lo + it->second.span;
+      for (int i : {0, 2, 4, 6, 8, 10, 12}) if (rc_key[i] >= lo && rc_key[i] < hi && rc_key[i] != 0) { (void)vxrc_accel_destroy(rc_accel); rc_accel = nullptr; break; }
+    }
     if (it->second.pooled) free_slots.push_back(it->second.dptr);
     else if (it->second.dptr) (void)hipFree(it->second.dptr);
     used -= it->second.span;
@@ -438,7 +445,16 @@ int vx_device::start_raycast(uint64_t args_va) {
   if (y0 > y1) y0 = y1;
   if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
   if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
-  const int rc = vxrc_render(&sc, ka.dst_width, ka.dst_height, y0, y1, &pr, (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, stream);
+  const uint64_t key[16] = {(uint64_t)sc.tlas, r_tlas.a->version, (uint64_t)sc.blas, r_blas.a->version, (uint64_t)sc.bvh, r_bvh.a->version,
+                            (uint64_t)sc.tri, r_tri.a->version, (uint64_t)sc.triEx, r_triex.a->version, (uint64_t)sc.triIdx, r_idx.a->version,
+                            (uint64_t)sc.tex, r_tex.a->version, ((uint64_t)sc.n_bvh_nodes << 32) | sc.n_tri_idx, ((uint64_t)sc.tlas_root << 32) | sc.n_tris};
+  if (!rc_accel || std::memcmp(key, rc_key, sizeof key) != 0) {
+    if (rc_accel) { (void)vxrc_accel_destroy(rc_accel); rc_accel = nullptr; }
+    ++n_accel_builds;
+    if (vxrc_accel_build(&sc, stream, &rc_accel) != 0) { VXLOG("start: raycast scene rejected (malformed BVH2: child / triangle index out of range or child not after parent)"); return -1; }
+    std::memcpy(rc_key, key, sizeof key);
+  }
+  const int rc = vxrc_render_accel(rc_accel, ka.dst_width, ka.dst_height, y0, y1, &pr, (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, stream);
   if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
   if (rc != 0) { VXLOG("start: raycast launch rejected (shape check)"); return -1; }
   if (enqueue_readback() != 0) return -1;

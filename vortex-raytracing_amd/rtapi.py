@@ -149,6 +149,32 @@ def rc_render(scene, width, height, y0, y1, params, dst_ptr, colors_ptr=None, st
     check(L.vxrc_render(C.byref(scene), width, height, y0, y1, C.byref(params), dst_ptr, colors_ptr, stream), "vxrc_render")
 
 
+def rc_accel_build(scene, stream=None):
+    """vxrc_accel_build: the twin's acceleration layout for an RcScene; returns the opaque handle."""
+    L = _lib()
+    L.vxrc_accel_build.restype = C.c_int
+    L.vxrc_accel_build.argtypes = [C.POINTER(RcScene), C.c_void_p, C.POINTER(C.c_void_p)]
+    h = C.c_void_p()
+    check(L.vxrc_accel_build(C.byref(scene), stream, C.byref(h)), "vxrc_accel_build")
+    return h
+
+
+def rc_accel_destroy(accel):
+    if accel:
+        L = _lib()
+        L.vxrc_accel_destroy.restype = C.c_int
+        L.vxrc_accel_destroy.argtypes = [C.c_void_p]
+        check(L.vxrc_accel_destroy(accel), "vxrc_accel_destroy")
+
+
+def rc_render_accel(accel, width, height, y0, y1, params, dst_ptr, colors_ptr=None, stream=None):
+    """vxrc_render_accel: the software twin on a prebuilt layout."""
+    L = _lib()
+    L.vxrc_render_accel.restype = C.c_int
+    L.vxrc_render_accel.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RcParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    check(L.vxrc_render_accel(accel, width, height, y0, y1, C.byref(params), dst_ptr, colors_ptr, stream), "vxrc_render_accel")
+
+
 class AoParams(C.Structure):   # vxrt_ao_params_t
     _fields_ = [("spp", C.c_uint32), ("radius", C.c_float), ("seed", C.c_uint32), ("reserved", C.c_uint32)]
 

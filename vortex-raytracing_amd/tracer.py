@@ -215,3 +215,24 @@ class RcDeviceScene:
         s.tlas_root = int(scene["tlas_root"])
         s.tex_bytes = scene["tex"].size
         self.c = s
+        self._accel = None
+
+    @property
+    def accel(self):
+        """The twin's acceleration layout (vxrc_accel_build), built on first use; raises VxError for a malformed scene."""
+        if self._accel is None:
+            import torch
+            with torch.cuda.device(self.device):
+                self._accel = rtapi.rc_accel_build(self.c, torch.cuda.current_stream().cuda_stream)
+        return self._accel
+
+    def close(self):
+        if getattr(self, "_accel", None):
+            rtapi.rc_accel_destroy(self._accel)
+            self._accel = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
