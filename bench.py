@@ -4,7 +4,7 @@
 Metric (BASELINE.json): Mrays/s (primary + shadow) at 1920x1080 on the 1M-triangle "Sponza-class" BVH.  A step = one frame of
 the RTU test on that scene: camera ray -> closest hit -> Lambert shade with one occlusion ray toward the light per hit -> RGB8,
 i.e. one vxrt_render call through the C ABI (persistent traversal launch + EXACT launches + shading pass), scene already
-resident in HBM.  Frames are issued round robin on --frames-in-flight streams (default 4) so that the draining tail of one
+resident in HBM.  Frames are issued round robin on --frames-in-flight streams (default 2; measured 2 > 4 > 3: profiles/r02_g_frames_in_flight.txt) so that the draining tail of one
 frame's persistent launch overlaps the next frame's; --frames-in-flight 1 gives strictly serial frames.
 
 Multi-GPU (one process per GPU, torch.distributed over RCCL): ONE frame is split by 8-row tile rows of the reference grid
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-shadow", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU-seconds of host work for the main cpu_baseline leg")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
+    ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="frames kept in flight on as many HIP streams (vxrt_accel_frames_in_flight); 1 = strictly serial frames")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal of the N>1 code path where ranks share one GPU (shares gathered through host memory)")
