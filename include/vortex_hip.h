@@ -224,6 +224,24 @@ int vxrt_render_interleaved(vxrt_accel_t* accel, uint32_t width, uint32_t height
                             const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits,
                             float* colors, unsigned long long* rays_traced, void* stream);
 
+/* BLAS construction on the GPU, in the reference's formats.  Replaces, for one mesh, BVH::build + the 4-wide collapse + the
+ * quantiser of tests/regression/raytracing/bvh.cpp:30-264 (host code run at scene load in the reference; csrc/scene_builder.cpp
+ * is the CPU counterpart here).  Morton order + binary radix tree + 4-wide collapse by surface area; see csrc/bvh_builder.hip.
+ *   tri      device, n_tris x 36 B (tri_t); REORDERED IN PLACE so that a leaf is a range (bvh.cpp:126-128)
+ *   triEx    device, n_tris x 64 B (tri_ex_t), reordered alongside; may be NULL
+ *   tri_offset  added to every leaf's leftFirst (index of the mesh's first triangle in the scene's buffer, bvh.cpp:260)
+ *   leaf_max    largest leaf, 1..15 (0 = 4)
+ *   nodes    device, node_capacity x 52 B (bvh_quantized_node_t), node_capacity >= 2 * n_tris - 1 (the reference allocates
+ *            2 * numTris, scene.cpp:40); node 0 is the root, children follow their parent
+ * Synchronises `stream` once to read the counts back.  Returns 0; -1 on bad arguments, allocation failure or a box that cannot
+ * be quantised; -2 if the tree is deeper than the 32 levels the reference's trail supports (use the SAH builder). */
+typedef struct vxrt_bvh_info {
+  uint32_t n_nodes, n_leaves, max_leaf, max_depth;
+  float bounds[6];        /* of the mesh: lo xyz, hi xyz */
+} vxrt_bvh_info_t;
+int vxrt_bvh_build(void* tri, void* triEx, uint32_t n_tris, uint32_t tri_offset, uint32_t leaf_max,
+                   void* nodes, uint32_t node_capacity, vxrt_bvh_info_t* info, void* stream);
+
 /* vxrt_render with the fetch counters compiled in (diagnostic build of the same kernel, never
  * timed): counters = device u64[7]: rays, node fetches, instance fetches, triangle fetches,
  * shaded hits, textured hits, pixels written.  Counts are what the reference logs per ray in

@@ -70,7 +70,7 @@ def build(force=False, verbose=True):
         raise RuntimeError("hipcc not found at %s: the HIP path cannot be built" % HIPCC)
 
     hip_so = os.path.join(LIB, "libvortex-hip.so")
-    hip_src = [os.path.join(CSRC, f) for f in ("rt_kernels.hip", "rc_kernels.hip", "vx_backend.hip", "calib_kernels.hip")]
+    hip_src = [os.path.join(CSRC, f) for f in ("rt_kernels.hip", "rc_kernels.hip", "vx_backend.hip", "calib_kernels.hip", "bvh_builder.hip")]
     if force or _newer(hip_so, hip_src + hdrs):
         _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", hip_so] + hip_src)
 

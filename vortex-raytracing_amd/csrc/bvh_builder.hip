@@ -1,0 +1,397 @@
+// BLAS construction on the GPU, in the reference's node format.
+//
+// Reference: tests/regression/raytracing/bvh.cpp:30-264 -- BVH::build (binned SAH, binary), the collapse to 4-wide nodes and
+// the quantiser, all host code run once per mesh at scene load; triangles are reordered in place so that a leaf is a range
+// (bvh.cpp:126-128).  csrc/scene_builder.cpp is this package's CPU counterpart (threaded SAH, the quality builder).  This file
+// is the builder for geometry that changes per frame: the whole build is a dozen launches over data that never leaves HBM.
+//
+//   1. centroid bounds              one pass, wavefront reduction + 6 atomics per workgroup
+//   2. 63-bit Morton keys           21 bits per axis of the triangle's box centre
+//   3. radix sort (key, index)      rocPRIM device sort, 8 passes over 12 bytes per triangle
+//   4. binary radix tree            Karras 2012: every internal node finds its range and split independently (no recursion,
+//                                   no dependence between nodes); equal keys are told apart by their index
+//   5. boxes bottom-up              one thread per triangle climbs; the second thread to reach a node owns it
+//   6. collapse to 4-wide + quantise + emit, level by level: a node adopts its binary children and then, twice, replaces the
+//      adopted subtree of largest surface area by that subtree's two children; subtrees of <= leaf_max triangles become
+//      leaves (a subtree of the radix tree is a contiguous range of the sorted order).  Children are allocated after their
+//      parent, which is what vxrt_accel_build's validation asks of any tree.
+//   7. triangles (and their shading records) gathered into the sorted order.
+//
+// Quantisation follows the format (decode = origin + ldexp(q, e), rt_traversal.cpp:61-67) and is conservative by
+// construction: every q is checked against the decode's own rounding and the exponent is raised until all children fit.
+// Parity for a builder is what it is for scene_builder.cpp (the reference builder reads uninitialised bounds, bvh.cpp:79-86,
+// so its tree is not reproducible from its algorithm): structural invariants + every ray finding the brute-force distance.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+#include "rt_types.h"
+#include "../../include/vortex_hip.h"
+
+namespace {
+
+constexpr int BB_MAX_LEVELS = 64;   // launches of the collapse pass; a tree deeper than RT_MAX_LEVELS is reported, not emitted half-way
+
+struct Box3 { float lx, ly, lz, hx, hy, hz; };
+
+__device__ __forceinline__ int f2ord(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7fffffff); }
+
+__device__ __forceinline__ Box3 tri_box(const float* __restrict__ t) {
+  Box3 b;
+  b.lx = fminf(fminf(t[0], t[3]), t[6]); b.hx = fmaxf(fmaxf(t[0], t[3]), t[6]);
+  b.ly = fminf(fminf(t[1], t[4]), t[7]); b.hy = fmaxf(fmaxf(t[1], t[4]), t[7]);
+  b.lz = fminf(fminf(t[2], t[5]), t[8]); b.hz = fmaxf(fmaxf(t[2], t[5]), t[8]);
+  return b;
+}
+
+__global__ void bb_init_kernel(int* cb, uint32_t* counters, uint32_t n_counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3) cb[i] = 0x7fffffff;
+  else if (i < 6) cb[i] = (int)0x80000000;
+  if (i < n_counters) counters[i] = 0;
+}
+
+// ---- 1. bounds of the box centres ----
+__global__ __launch_bounds__(256) void bb_bounds_kernel(const float* __restrict__ tri, uint32_t n, int* __restrict__ cb) {
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const Box3 b = tri_box(tri + (size_t)i * 9);
+    const float c[3] = {0.5f * (b.lx + b.hx), 0.5f * (b.ly + b.hy), 0.5f * (b.lz + b.hz)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], c[a]); hi[a] = fmaxf(hi[a], c[a]); }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    for (int off = 32; off > 0; off >>= 1) { lo[a] = fminf(lo[a], __shfl_down(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off)); }
+  if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (lo[a] <= hi[a]) { atomicMin(cb + a, f2ord(lo[a])); atomicMax(cb + 3 + a, f2ord(hi[a])); }
+    }
+  }
+}
+
+// ---- 2. Morton keys ----
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {
+  uint64_t x = v & 0x1fffffu;
+  x = (x | x << 32) & 0x001f00000000ffffull;
+  x = (x | x << 16) & 0x001f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void bb_morton_kernel(const float* __restrict__ tri, uint32_t n, const int* __restrict__ cb,
+                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Box3 b = tri_box(tri + (size_t)i * 9);
+  const float c[3] = {0.5f * (b.lx + b.hx), 0.5f * (b.ly + b.hy), 0.5f * (b.lz + b.hz)};
+  uint32_t q[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float lo = ord2f(cb[a]), hi = ord2f(cb[3 + a]);
+    const float ext = hi - lo;
+    float t = ext > 0.0f ? (c[a] - lo) / ext * 2097152.0f : 0.0f;
+    if (!(t >= 0.0f)) t = 0.0f;            // (also a NaN centre)
+    if (t > 2097151.0f) t = 2097151.0f;
+    q[a] = (uint32_t)t;
+  }
+  keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+  vals[i] = i;
+}
+
+// ---- 4. binary radix tree (Karras, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees", 2012) ----
+// node ids: internal i in [0, n-1), leaf j as (n-1) + j; internal 0 is the root
+__device__ __forceinline__ int bb_delta(const uint64_t* __restrict__ k, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint64_t a = k[i], b = k[j];
+  return a == b ? 64 + __clz(i ^ j) : __clzll((long long)(a ^ b));
+}
+
+__global__ __launch_bounds__(256) void bb_tree_kernel(const uint64_t* __restrict__ keys, int n, uint2* __restrict__ child, uint2* __restrict__ range,
+                                                        uint32_t* __restrict__ parent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = bb_delta(keys, n, i, i + 1) - bb_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+  const int dmin = bb_delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (bb_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (bb_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = bb_delta(keys, n, i, j);
+  int s = 0;
+  for (int t = l;;) {
+    t = (t + 1) >> 1;
+    if (bb_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    if (t <= 1) break;
+  }
+  const int gamma = i + s * d + min(d, 0);
+  const int first = min(i, j), last = max(i, j);
+  const uint32_t left = first == gamma ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
+  const uint32_t right = last == gamma + 1 ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+  child[i] = make_uint2(left, right);
+  range[i] = make_uint2((uint32_t)first, (uint32_t)last);
+  parent[left] = (uint32_t)i;
+  parent[right] = (uint32_t)i;
+  if (i == 0) parent[0] = 0xffffffffu;
+}
+
+// ---- 5. boxes, bottom-up ----
+__device__ __forceinline__ float coherent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(256) void bb_fit_kernel(const float* __restrict__ tri, const uint32_t* __restrict__ vals, uint32_t n,
+                                                       const uint2* __restrict__ child, const uint32_t* __restrict__ parent,
+                                                       float* __restrict__ box /* 6 floats per node id */, uint32_t* __restrict__ flag) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  Box3 b = tri_box(tri + (size_t)vals[j] * 9);
+  uint32_t id = n - 1 + j;
+  for (;;) {
+    float* o = box + (size_t)id * 6;
+    o[0] = b.lx; o[1] = b.ly; o[2] = b.lz; o[3] = b.hx; o[4] = b.hy; o[5] = b.hz;
+    if (n == 1) return;
+    const uint32_t p = id == 0 ? 0xffffffffu : parent[id];
+    if (p == 0xffffffffu) return;                     // the root's box is written
+    __threadfence();
+    if (atomicAdd(flag + p, 1u) == 0u) return;        // the sibling subtree is not finished: its last thread continues
+    __threadfence();
+    const uint2 c = child[p];
+    const float* s = box + (size_t)(c.x == id ? c.y : c.x) * 6;
+    b.lx = fminf(b.lx, coherent_load(s + 0)); b.ly = fminf(b.ly, coherent_load(s + 1)); b.lz = fminf(b.lz, coherent_load(s + 2));
+    b.hx = fmaxf(b.hx, coherent_load(s + 3)); b.hy = fmaxf(b.hy, coherent_load(s + 4)); b.hz = fmaxf(b.hz, coherent_load(s + 5));
+    id = p;
+  }
+}
+
+// ---- 6. collapse + quantise + emit ----
+// smallest e with extent / 255 <= 2^e (bvh.cpp:215-264 picks ceil(log2(extent / 255))), from the float's own exponent: exact
+__device__ __forceinline__ int bb_pick_exp(float extent) {
+  if (!(extent > 0.0f) || extent > 3.0e38f) return 0;
+  int k;
+  const float m = frexpf(extent / 255.0f, &k);   // extent / 255 = m * 2^k, m in [0.5, 1)
+  int e = m == 0.5f ? k - 1 : k;
+  return max(-126, min(126, e));
+}
+
+// q_lo, q_hi of one axis of one child at exponent e; false if the child does not fit 8 bits there
+__device__ __forceinline__ bool bb_quant_axis(float origin, int e, float cmin, float cmax, uint32_t& qlo, uint32_t& qhi) {
+  const float s = ldexpf(1.0f, e);
+  float fl = floorf((cmin - origin) / s), fh = ceilf((cmax - origin) / s);
+  if (!(fl >= 0.0f)) fl = 0.0f;
+  if (!(fh >= fl)) fh = fl;
+  if (fh > 255.0f) return false;
+  int lo = (int)fl, hi = (int)fh;
+  if (lo > 255) return false;
+  // conservative after the decode's own rounding (origin + q * 2^e rounds once)
+  while (lo > 0 && origin + ldexpf((float)lo, e) > cmin) --lo;
+  while (hi < 255 && origin + ldexpf((float)hi, e) < cmax) ++hi;
+  if (origin + ldexpf((float)hi, e) < cmax) return false;
+  qlo = (uint32_t)lo; qhi = (uint32_t)hi;
+  return true;
+}
+
+struct CollapseArgs {
+  const uint2* child; const uint2* range; const float* box;
+  uint32_t n, leaf_max, tri_offset, node_capacity;
+  uint32_t* nodes;          // 13 dwords per node
+  uint32_t* counters;       // [0] nodes allocated, [1] leaves, [2] largest leaf, [3] deepest level, [4] error flags, [8 + L] items of level L
+  const uint2* in; uint2* out;
+  uint32_t level;
+};
+
+__device__ __forceinline__ Box3 bb_load_box(const float* box, uint32_t id) {
+  const float* p = box + (size_t)id * 6;
+  Box3 b; b.lx = p[0]; b.ly = p[1]; b.lz = p[2]; b.hx = p[3]; b.hy = p[4]; b.hz = p[5];
+  return b;
+}
+__device__ __forceinline__ float bb_area(const Box3& b) {
+  const float x = b.hx - b.lx, y = b.hy - b.ly, z = b.hz - b.lz;
+  return x * y + y * z + z * x;
+}
+
+__global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
+  const uint32_t n_items = A.counters[8 + A.level];
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += gridDim.x * blockDim.x) {
+    const uint2 item = A.in[it];
+    const uint32_t b = item.x, out = item.y;
+    const bool is_leaf_id = b >= A.n - 1;
+    const uint2 rg = is_leaf_id ? make_uint2(b - (A.n - 1), b - (A.n - 1)) : A.range[b];
+    const uint32_t count = rg.y - rg.x + 1;
+    const Box3 bx = bb_load_box(A.box, b);
+    uint32_t w[13];
+    w[0] = __float_as_uint(bx.lx); w[1] = __float_as_uint(bx.ly); w[2] = __float_as_uint(bx.lz);
+    int e[3] = {bb_pick_exp(bx.hx - bx.lx), bb_pick_exp(bx.hy - bx.ly), bb_pick_exp(bx.hz - bx.lz)};
+    uint8_t ch[4][7] = {};
+    if (count <= A.leaf_max) {
+      w[4] = rg.x + A.tri_offset;    // bvh.cpp:260: already offset by the mesh's first triangle
+      w[5] = count;
+      atomicAdd(A.counters + 1, 1u);
+      atomicMax(A.counters + 2, count);
+      atomicMax(A.counters + 3, A.level);
+    } else {
+      uint32_t c[4];
+      const uint2 c0 = A.child[b];
+      c[0] = c0.x; c[1] = c0.y;
+      uint32_t nc = 2;
+      Box3 cb[4];
+      cb[0] = bb_load_box(A.box, c[0]); cb[1] = bb_load_box(A.box, c[1]);
+      for (int round = 0; round < 2; ++round) {
+        int pick = -1; float best = -1.0f;
+        for (uint32_t k = 0; k < nc; ++k) {
+          if (c[k] >= A.n - 1) continue;
+          const uint2 r = A.range[c[k]];
+          if (r.y - r.x + 1 <= A.leaf_max) continue;      // becomes a leaf as it is
+          const float a = bb_area(cb[k]);
+          if (a > best) { best = a; pick = (int)k; }
+        }
+        if (pick < 0) break;
+        const uint2 g = A.child[c[pick]];
+        c[pick] = g.x; cb[pick] = bb_load_box(A.box, g.x);
+        c[nc] = g.y; cb[nc] = bb_load_box(A.box, g.y);
+        ++nc;
+      }
+      const uint32_t first = atomicAdd(A.counters + 0, nc);
+      if (first + nc > A.node_capacity) { atomicOr(A.counters + 4, 1u); continue; }
+      const float org[3] = {bx.lx, bx.ly, bx.lz};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        for (;;) {
+          bool ok = true;
+          for (uint32_t k = 0; k < nc && ok; ++k) {
+            const float cmin = a == 0 ? cb[k].lx : (a == 1 ? cb[k].ly : cb[k].lz);
+            const float cmax = a == 0 ? cb[k].hx : (a == 1 ? cb[k].hy : cb[k].hz);
+            uint32_t ql = 0, qh = 0;
+            ok = bb_quant_axis(org[a], e[a], cmin, cmax, ql, qh);
+            if (ok) { ch[k][1 + a] = (uint8_t)ql; ch[k][4 + a] = (uint8_t)qh; }
+          }
+          if (ok) break;
+          if (e[a] >= 126) { atomicOr(A.counters + 4, 2u); break; }
+          ++e[a];
+        }
+      }
+      for (uint32_t k = 0; k < nc; ++k) ch[k][0] = 1;
+      w[4] = first;     // relative to this BLAS's first node (rt_traversal.cpp:92,119)
+      w[5] = 0;
+      const uint32_t pos = atomicAdd(A.counters + 8 + A.level + 1, nc);
+      for (uint32_t k = 0; k < nc; ++k) A.out[pos + k] = make_uint2(c[k], first + k);
+    }
+    w[3] = (uint32_t)(uint8_t)(int8_t)e[0] | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16);   // imask = 0: BLAS node
+    const uint8_t* cbytes = &ch[0][0];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) w[6 + k] = (uint32_t)cbytes[4 * k] | ((uint32_t)cbytes[4 * k + 1] << 8) | ((uint32_t)cbytes[4 * k + 2] << 16) | ((uint32_t)cbytes[4 * k + 3] << 24);
+    uint32_t* o = A.nodes + (size_t)out * RT_NODE_DWORDS;
+#pragma unroll
+    for (int k = 0; k < RT_NODE_DWORDS; ++k) o[k] = w[k];
+  }
+}
+
+// ---- 7. gather into the sorted order ----
+__global__ __launch_bounds__(256) void bb_gather_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ vals, uint32_t n, uint32_t dwords,
+                                                          uint32_t* __restrict__ dst) {
+  const uint64_t total = (uint64_t)n * dwords;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t j = (uint32_t)(t / dwords), k = (uint32_t)(t % dwords);
+    dst[t] = src[(size_t)vals[j] * dwords + k];
+  }
+}
+
+struct Scratch {
+  std::vector<void*> ptrs;
+  template <class T> T* get(size_t count) {
+    void* p = nullptr;
+    if (hipMalloc(&p, count * sizeof(T) + 16) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return (T*)p;
+  }
+  ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+};
+
+}  // namespace
+
+extern "C" int vxrt_bvh_build(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tri_offset, uint32_t leaf_max,
+                              void* d_nodes, uint32_t node_capacity, vxrt_bvh_info_t* info, void* stream) {
+  if (!d_tri || !d_nodes || n_tris == 0 || n_tris > 0x3fffffffu) return -1;
+  if (leaf_max == 0) leaf_max = 4;
+  if (leaf_max > 15) leaf_max = 15;
+  if ((uint64_t)node_capacity < 2ull * n_tris - 1ull) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t n = n_tris;
+  Scratch sc;
+  const uint32_t n_counters = 8 + BB_MAX_LEVELS + 2;
+  int* cb = sc.get<int>(8);
+  uint32_t* counters = sc.get<uint32_t>(n_counters);
+  uint64_t* keys0 = sc.get<uint64_t>(n);
+  uint64_t* keys1 = sc.get<uint64_t>(n);
+  uint32_t* vals0 = sc.get<uint32_t>(n);
+  uint32_t* vals1 = sc.get<uint32_t>(n);
+  uint2* child = sc.get<uint2>(n);
+  uint2* range = sc.get<uint2>(n);
+  uint32_t* parent = sc.get<uint32_t>(2 * (size_t)n);
+  uint32_t* flag = sc.get<uint32_t>(n);
+  float* box = sc.get<float>(12 * (size_t)n);
+  uint2* q0 = sc.get<uint2>(n);
+  uint2* q1 = sc.get<uint2>(n);
+  uint32_t* gather = sc.get<uint32_t>((size_t)n * (d_triEx ? 16 : 9));
+  if (!cb || !counters || !keys0 || !keys1 || !vals0 || !vals1 || !child || !range || !parent || !flag || !box || !q0 || !q1 || !gather) return -1;
+  const uint32_t blocks = (n + 255u) / 256u;
+  const uint32_t wide = blocks < 4096u ? blocks : 4096u;
+
+  hipLaunchKernelGGL(bb_init_kernel, dim3(1), dim3(256), 0, s, cb, counters, n_counters);
+  if (hipMemsetAsync(flag, 0, (size_t)n * 4, s) != hipSuccess) return -1;
+  hipLaunchKernelGGL(bb_bounds_kernel, dim3(wide < 1024u ? wide : 1024u), dim3(256), 0, s, (const float*)d_tri, n, cb);
+  hipLaunchKernelGGL(bb_morton_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, n, cb, keys0, vals0);
+  size_t tmp_bytes = 0;
+  if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
+  void* tmp = sc.get<uint8_t>(tmp_bytes ? tmp_bytes : 16);
+  if (!tmp) return -1;
+  if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
+  if (n > 1) hipLaunchKernelGGL(bb_tree_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, s, keys1, (int)n, child, range, parent);
+  hipLaunchKernelGGL(bb_fit_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, vals1, n, child, parent, box, flag);
+
+  // root item: binary node 0 (or the single leaf) -> output node 0
+  const uint2 root_item = make_uint2(n > 1 ? 0u : 0u /* leaf id n-1+0 = 0 */, 0u);
+  const uint32_t init_counters[2] = {1u, 0u};   // one node allocated
+  if (hipMemcpyAsync(q0, &root_item, sizeof root_item, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+  if (hipMemcpyAsync(counters, init_counters, 4, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+  const uint32_t one = 1u;
+  if (hipMemcpyAsync(counters + 8, &one, 4, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+  CollapseArgs A;
+  A.child = child; A.range = range; A.box = box; A.n = n; A.leaf_max = leaf_max; A.tri_offset = tri_offset; A.node_capacity = node_capacity;
+  A.nodes = (uint32_t*)d_nodes; A.counters = counters;
+  for (uint32_t L = 0; L < (uint32_t)BB_MAX_LEVELS; ++L) {
+    A.in = (L & 1u) ? q1 : q0; A.out = (L & 1u) ? q0 : q1; A.level = L;
+    // (level L holds at most 4^L items)
+    uint32_t g = wide;
+    if (L < 8) { const uint32_t items = 1u << (2 * L); g = (items + 255u) / 256u < wide ? (items + 255u) / 256u : wide; }
+    hipLaunchKernelGGL(bb_collapse_kernel, dim3(g), dim3(256), 0, s, A);
+  }
+  // triangles (and shading records) into the sorted order, in place through a scratch copy (bvh.cpp:126-128 reorders in place)
+  hipLaunchKernelGGL(bb_gather_kernel, dim3(wide), dim3(256), 0, s, (const uint32_t*)d_tri, vals1, n, 9u, gather);
+  if (hipMemcpyAsync(d_tri, gather, (size_t)n * 36, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+  if (d_triEx) {
+    hipLaunchKernelGGL(bb_gather_kernel, dim3(wide), dim3(256), 0, s, (const uint32_t*)d_triEx, vals1, n, 16u, gather);
+    if (hipMemcpyAsync(d_triEx, gather, (size_t)n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+  }
+  std::vector<uint32_t> hc(n_counters);
+  float hb[6];
+  if (hipMemcpyAsync(hc.data(), counters, n_counters * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipMemcpyAsync(hb, box + (n > 1 ? 0 : 0), sizeof hb, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  if (hipGetLastError() != hipSuccess) return -1;
+  if (info) {
+    info->n_nodes = hc[0]; info->n_leaves = hc[1]; info->max_leaf = hc[2]; info->max_depth = hc[3];
+    for (int i = 0; i < 6; ++i) info->bounds[i] = hb[i];
+  }
+  if (hc[4] != 0u) return -1;                                  // capacity or exponent range exhausted
+  if (hc[8 + BB_MAX_LEVELS] != 0u) return -2;                  // deeper than the collapse pass goes
+  if (hc[3] >= (uint32_t)RT_MAX_LEVELS) return -2;             // deeper than the reference's trail (rt_traversal.h:8): use the SAH builder
+  return 0;
+}

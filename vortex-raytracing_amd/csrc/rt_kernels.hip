@@ -419,6 +419,9 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #ifndef RT_TRACE_DEAD_MAX
 #define RT_TRACE_DEAD_MAX 16   // ray-buffer jobs (incoherent rays): refill early
 #endif
+#ifndef RT_TRI_STEP
+#define RT_TRI_STEP 0       // 1: inlined leaves are tested one triangle per loop iteration
+#endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 64         // jobs reserved per global atomic (one 8x8 tile)
 #endif
@@ -535,6 +538,7 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 #define F_ANYHIT 2u
 #define F_SHADOW 8u      // render job is in its occlusion-ray phase
 #define F_WORLD 16u      // the active ray registers hold the world-space ray (TLAS level)
+#define F_INLEAF 64u     // RT_TRI_STEP, counting builds: `cur` is the rest of a leaf already entered
 #define F_RESUMED 32u    // EXACT launch: occlusion ray handed over by the main launch (its primary hit record is in memory)
 
 // Register budget is the lever here (profiles/r01_c_*: at 4 waves/SIMD the VALU pipe idles 58 % of
@@ -992,6 +996,30 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
           if (is_leaf_desc(cur)) {
             if (STATS) fx.node++;
             uint32_t leftFirst = cur & LEAF_FIRST_MASK, triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
+            if (RT_TRI_STEP && triCount != 0u) {
+              // one triangle per loop iteration: the lanes of a wavefront hold leaves of different sizes, and a loop over each
+              // lane's triangles runs as long as the largest one while the node lanes wait; stepping keeps `cur` = the rest of the
+              // leaf (first + 1, count - 1), so the next triangle is tested beside the other lanes' next node step
+              if (STATS && (flags & F_INLEAF)) fx.node--;   // (counted when the leaf was entered)
+              const float cdx = __uint_as_float(CTX(0)), cdy = __uint_as_float(CTX(1)), cdz = __uint_as_float(CTX(2));
+              const float4* tp = sc.tri_w + (size_t)leftFirst * 3;
+              const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+              if (STATS) fx.tri++;
+              float bx, by, bz;
+              const float d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
+              bool more = triCount > 1u, stop1 = false;
+              if (d < hitd) {
+                hitd = d;
+                flags |= F_FOUND;
+                if (!(JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW))) { CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(6) = CTX(8); CTX(7) = leftFirst; }
+                if (flags & F_ANYHIT) { stop1 = true; more = false; }
+                else if (!(path_m < hitd)) more = false;   // (rule 3)
+              }
+              if (STATS) flags = more ? (flags | F_INLEAF) : (flags & ~F_INLEAF);
+              if (more) cur += 1u - (1u << LEAF_FIRST_BITS);
+              else if (stop1) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
+              else pop_next();
+            } else {
             if (triCount == 0u) {   // leaf with more than 15 triangles: range kept in the reference node
               const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS;
               leftFirst = rn[4]; triCount = rn[5];
@@ -1029,6 +1057,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
             }
             if (stop) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
             else pop_next();
+            }   // !RT_TRI_STEP
           }
         }
       }
@@ -1779,6 +1808,8 @@ static uint32_t persistent_grid(K kernel, uint64_t jobs, int wg_threads = RT_WG_
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, wg_threads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    // measurement knob (tools/occupancy_sweep.sh): fewer resident workgroups per CU than the kernel allows
+    if (const char* e = getenv("VXRT_WGS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
     g = (uint64_t)per_cu * (uint64_t)cus;
     if (getenv("VXRT_DEBUG")) fprintf(stderr, "[vxrt] persistent grid: %d blocks/CU x %d CUs\n", per_cu, cus);
     std::lock_guard<std::mutex> lk(mu);

@@ -71,6 +71,28 @@ def accel_build(scene, stream=None):
     return h
 
 
+class BvhInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("max_leaf", C.c_uint32), ("max_depth", C.c_uint32),
+                ("bounds", C.c_float * 6)]
+
+
+class BvhTooDeep(RuntimeError):
+    """vxrt_bvh_build: the Morton-order tree is deeper than the 32 levels the reference's trail supports."""
+
+
+def bvh_build(tri_ptr, triEx_ptr, n_tris, nodes_ptr, node_capacity, tri_offset=0, leaf_max=0, stream=None):
+    """vxrt_bvh_build: BLAS of one mesh on the GPU, in the reference's node format; tri / triEx are reordered in place."""
+    L = _lib()
+    L.vxrt_bvh_build.restype = C.c_int
+    L.vxrt_bvh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(BvhInfo), C.c_void_p]
+    info = BvhInfo()
+    rc = L.vxrt_bvh_build(tri_ptr, triEx_ptr, n_tris, tri_offset, leaf_max, nodes_ptr, node_capacity, C.byref(info), stream)
+    if rc == -2:
+        raise BvhTooDeep("vxrt_bvh_build: tree depth %d exceeds the reference's 32 levels" % info.max_depth)
+    check(rc, "vxrt_bvh_build")
+    return info
+
+
 def accel_destroy(accel):
     if accel:
         check(_lib().vxrt_accel_destroy(accel), "vxrt_accel_destroy")

@@ -113,6 +113,69 @@ class DeviceScene:
         with torch.cuda.device(device):
             self.accel = rtapi.accel_build(s, torch.cuda.current_stream().cuda_stream)
 
+    @classmethod
+    def build_on_gpu(cls, tri, triEx=None, mat=None, tex=None, device="cuda:0", leaf_max=0):
+        """Scene of ONE mesh whose BLAS is built on the GPU (vxrt_bvh_build) from a triangle soup: tri float32 [n, 9]
+        (tri_t), triEx uint8/float32 [n, 64 B] (tri_ex_t; default: flat normals, material 0), mat / tex as the reference's
+        buffers (default: one grey material, no texture).  The single-node TLAS and the identity instance record are what
+        the reference's scene builder emits for one mesh (bvh.cpp:325-328, scene.cpp:84-99).  Returns a DeviceScene whose
+        buffers never existed on the host; .bvh_info holds the builder's counts."""
+        import torch
+        self = cls.__new__(cls)
+        self.device = device
+        n = int(np.asarray(tri).reshape(-1, 9).shape[0])
+        with torch.cuda.device(device):
+            t_tri = torch.from_numpy(np.ascontiguousarray(np.asarray(tri, np.float32).reshape(-1, 9))).to(device).view(torch.uint8).reshape(-1)
+            if triEx is None:
+                v = np.asarray(tri, np.float32).reshape(-1, 3, 3)
+                nrm = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+                nrm = (nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+                ex = np.zeros((n, 16), np.float32)
+                ex[:, 0:3] = ex[:, 3:6] = ex[:, 6:9] = nrm
+                triEx = ex
+            t_ex = torch.from_numpy(np.ascontiguousarray(triEx).view(np.uint8).reshape(-1)).to(device)
+            assert t_ex.numel() == n * 64
+            if mat is None:
+                m = np.zeros(22, np.float32)
+                m[3:6] = 0.8
+                mat = m.view(np.uint8).copy()
+                mat[64:68] = np.frombuffer(struct.pack("<i", -1), np.uint8)
+            t_mat = torch.from_numpy(np.ascontiguousarray(mat).view(np.uint8).reshape(-1)).to(device)
+            t_tex = torch.from_numpy(np.ascontiguousarray(tex if tex is not None and np.asarray(tex).size else np.zeros(4, np.uint8)).view(np.uint8).reshape(-1)).to(device)
+            cap = 2 * n
+            t_bvh = torch.zeros(cap * NODE_BYTES, dtype=torch.uint8, device=device)
+            stream = torch.cuda.current_stream().cuda_stream
+            info = rtapi.bvh_build(t_tri.data_ptr(), t_ex.data_ptr(), n, t_bvh.data_ptr(), cap, 0, leaf_max, stream)
+            t_bvh = t_bvh[: info.n_nodes * NODE_BYTES]
+            b = np.array(list(info.bounds), np.float32)
+            # TLAS: one node, the instance leaf (imask 1, leafData = blasIdx 0)
+            ext = np.maximum(b[3:] - b[:3], 0)
+            exps = [0 if not e > 0 else int(np.clip(np.ceil(np.log2(np.float32(e) / np.float32(255.0))), -126, 126)) for e in ext]
+            tl = struct.pack("<3f3bBII", float(b[0]), float(b[1]), float(b[2]), exps[0], exps[1], exps[2], 1, 0, 0) + bytes(28)
+            bl = np.zeros(40, np.float32)
+            bl[1:17] = np.eye(4, dtype=np.float32).reshape(-1)      # invTransform
+            bl[17:33] = np.eye(4, dtype=np.float32).reshape(-1)     # transform
+            t_tlas = torch.from_numpy(np.frombuffer(tl, np.uint8).copy()).to(device)
+            t_blas = torch.from_numpy(bl.view(np.uint8).copy()).to(device)
+            self.t = {"tlas": t_tlas, "blas": t_blas, "bvh": t_bvh, "tri": t_tri, "triEx": t_ex, "mat": t_mat, "tex": t_tex}
+            s = rtapi.VxrtScene()
+            for k, t in self.t.items():
+                setattr(s, k, t.data_ptr())
+            s.n_tlas_nodes, s.n_blas, s.n_bvh_nodes, s.n_tris = 1, 1, info.n_nodes, n
+            s.n_mats = t_mat.numel() // MAT_BYTES
+            s.tex_bytes = t_tex.numel()
+            self.c = s
+            self.bvh_info = info
+            self.accel = rtapi.accel_build(s, stream)
+        return self
+
+    def to_host(self):
+        """The scene buffers as a scene.Scene (numpy), e.g. to hand a GPU-built tree to the oracle."""
+        from .scene import Scene
+        bufs = {k: t.cpu().numpy() for k, t in self.t.items()}
+        bufs["triIdx"] = np.arange(bufs["tri"].size // TRI_BYTES, dtype=np.uint32).view(np.uint8)
+        return Scene(bufs, name="device")
+
     def close(self):
         if getattr(self, "accel", None):
             rtapi.accel_destroy(self.accel)
