@@ -230,7 +230,7 @@ int vxrt_render_interleaved(vxrt_accel_t* accel, uint32_t width, uint32_t height
  *   tri      device, n_tris x 36 B (tri_t); REORDERED IN PLACE so that a leaf is a range (bvh.cpp:126-128)
  *   triEx    device, n_tris x 64 B (tri_ex_t), reordered alongside; may be NULL
  *   tri_offset  added to every leaf's leftFirst (index of the mesh's first triangle in the scene's buffer, bvh.cpp:260)
- *   leaf_max    largest leaf, 1..15 (0 = 4)
+ *   leaf_max    largest leaf, 1..15 (0 = 2, the fastest to traverse on the 1M-triangle scene: profiles/r02_h_gpu_builder.jsonl)
  *   nodes    device, node_capacity x 52 B (bvh_quantized_node_t), node_capacity >= 2 * n_tris - 1 (the reference allocates
  *            2 * numTris, scene.cpp:40); node 0 is the root, children follow their parent
  * Synchronises `stream` once to read the counts back.  Returns 0; -1 on bad arguments, allocation failure or a box that cannot
@@ -241,6 +241,9 @@ typedef struct vxrt_bvh_info {
 } vxrt_bvh_info_t;
 int vxrt_bvh_build(void* tri, void* triEx, uint32_t n_tris, uint32_t tri_offset, uint32_t leaf_max,
                    void* nodes, uint32_t node_capacity, vxrt_bvh_info_t* info, void* stream);
+/* The builder keeps one grow-only scratch allocation per process (about 170 B per triangle of the largest build) so that a
+ * mesh rebuilt every frame allocates nothing; this returns it to the device. */
+void vxrt_bvh_release_scratch(void);
 
 /* vxrt_render with the fetch counters compiled in (diagnostic build of the same kernel, never
  * timed): counters = device u64[7]: rays, node fetches, instance fetches, triangle fetches,

@@ -81,7 +81,7 @@ def test_tiny_meshes(vrt, po, gpu_device, n):
     rng = np.random.default_rng(n)
     c = np.array([200.0, 100.0, 0.0], np.float32) + rng.uniform(-30, 30, size=(n, 1, 3)).astype(np.float32)
     tri = (c + rng.uniform(-25, 25, size=(n, 3, 3)).astype(np.float32)).reshape(n, 9)
-    ds = vrt.tracer.DeviceScene.build_on_gpu(tri, device=gpu_device)
+    ds = vrt.tracer.DeviceScene.build_on_gpu(tri, device=gpu_device, leaf_max=4)
     sc = ds.to_host()
     if n > 4:
         check_tree(sc)

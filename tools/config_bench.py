@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The other BASELINE.json configurations, measured once each on one MI355X (they are parity-test cases, not the
-bench line): prints one JSON object per configuration.  usage: python tools/config_bench.py [2] [3] [4] [5] [6] [--hair-strands N]   (6 = the raycast software twin, 7 = the vx_* call sequence)"""
+bench line): prints one JSON object per configuration.  usage: python tools/config_bench.py [2] [3] [4] [5] [6] [--hair-strands N]   (6 = the raycast software twin, 7 = the vx_* call sequence, 8 = the GPU-built BLAS against the SAH tree)"""
 import argparse, importlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -137,6 +137,48 @@ def main():
         out.append({"config": "drop-in vx_* sequence (ctypes host): Sponza-class, 1920x1080, primary + 1 shadow ray, serial frames", "rays_per_frame": int(rays),
                     "scene_upload_s": round(upload_s, 3), "ms_per_frame_start_wait": round(res[False], 4), "ms_per_frame_with_copy_from_dev": round(res[True], 4),
                     "mrays_s_start_wait": round(rays / res[False] / 1e3, 1), "mrays_s_with_copy": round(rays / res[True] / 1e3, 1)})
+    if 8 in a.configs:
+        # the BLAS built on the GPU (vxrt_bvh_build) against the CPU SAH builder: build time and what the tree is worth in the headline frame
+        t0 = time.time()
+        sc = vrt.scene.procedural("atrium", 8, 0, 3)
+        sah_build_s = time.time() - t0
+        tri = sc["tri"].view(np.float32).reshape(-1, 9)
+        ex = sc["triEx"].reshape(-1, 64)
+        perm = np.random.default_rng(1).permutation(len(tri))
+        tri, ex = tri[perm].copy(), ex[perm].copy()
+        W, H = 1920, 1080
+        light = (300.0, 480.0, 60.0)
+        base = render_cfg("SAH tree (CPU builder)", sc, W, H, light, 50)
+        n = len(tri)
+        s = torch.cuda.current_stream().cuda_stream
+        for leaf_max in (1, 2, 4, 8):
+            t_tri0, t_ex0 = torch.from_numpy(tri).to(dev), torch.from_numpy(ex).to(dev)
+            nodes = torch.zeros(2 * n * 52, dtype=torch.uint8, device=dev)
+            ts = []
+            for _ in range(6):
+                t_tri, t_ex = t_tri0.clone(), t_ex0.clone()
+                torch.cuda.synchronize()
+                t0 = time.time()
+                info = rtapi.bvh_build(t_tri.data_ptr(), t_ex.data_ptr(), n, nodes.data_ptr(), 2 * n, 0, leaf_max, s)
+                ts.append(time.time() - t0)
+            del t_tri0, t_ex0, t_tri, t_ex, nodes
+            ds = vrt.tracer.DeviceScene.build_on_gpu(tri, ex, sc["mat"], sc["tex"], dev, leaf_max=leaf_max)
+            p = rtapi.default_shade_params()
+            p.light_pos[:] = light
+            px = torch.zeros((H, W), dtype=torch.int32, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            rtapi.render(ds.accel, W, H, 0, H, p, px.data_ptr(), 1, None, None, cnt.data_ptr(), s)
+            torch.cuda.synchronize()
+            rays = int(cnt.item())
+            ms = timed(lambda: rtapi.render(ds.accel, W, H, 0, H, p, px.data_ptr(), 1, None, None, None, s), 50)
+            st = rtapi.render_stats(ds.accel, W, H, 0, H, p, px.data_ptr(), 1, s)
+            out.append({"config": "GPU-built BLAS (vxrt_bvh_build, leaf_max %d): Sponza-class, 1920x1080, primary + 1 shadow ray, serial frames" % leaf_max,
+                        "tris": n, "nodes": info.n_nodes, "leaves": info.n_leaves, "depth": info.max_depth,
+                        "build_ms_median": round(sorted(ts)[len(ts) // 2] * 1e3, 2), "build_ms_min": round(min(ts) * 1e3, 2), "cpu_sah_build_s": round(sah_build_s, 2),
+                        "rays_per_frame": rays, "ms_per_frame_serial": round(ms, 4), "mrays_s": round(rays / ms / 1e3, 1),
+                        "node_fetches_per_ray": round(st["node_fetches"] / st["rays"], 2), "tri_fetches_per_ray": round(st["tri_fetches"] / st["rays"], 2),
+                        "sah_tree_mrays_s": base["mrays_s"], "sah_tree_ms": base["ms_per_frame_serial"]})
+            ds.close()
     for o in out:
         print(json.dumps(o), flush=True)
 

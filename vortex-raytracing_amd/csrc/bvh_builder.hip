@@ -27,13 +27,14 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <vector>
 #include "rt_types.h"
 #include "../../include/vortex_hip.h"
 
 namespace {
 
-constexpr int BB_MAX_LEVELS = 64;   // launches of the collapse pass; a tree deeper than RT_MAX_LEVELS is reported, not emitted half-way
+constexpr int BB_MAX_LEVELS = 34;   // launches of the collapse pass; a tree deeper than RT_MAX_LEVELS is reported, not emitted half-way
 
 struct Box3 { float lx, ly, lz, hx, hy, hz; };
 
@@ -67,11 +68,18 @@ __global__ __launch_bounds__(256) void bb_bounds_kernel(const float* __restrict_
 #pragma unroll
   for (int a = 0; a < 3; ++a)
     for (int off = 32; off > 0; off >>= 1) { lo[a] = fminf(lo[a], __shfl_down(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off)); }
+  // one set of atomics per workgroup (six contended addresses: per wavefront they cost more than the pass itself)
+  __shared__ float s_lo[4][3], s_hi[4][3];
   if ((threadIdx.x & 63u) == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (lo[a] <= hi[a]) { atomicMin(cb + a, f2ord(lo[a])); atomicMax(cb + 3 + a, f2ord(hi[a])); }
-    }
+    for (int a = 0; a < 3; ++a) { s_lo[threadIdx.x >> 6][a] = lo[a]; s_hi[threadIdx.x >> 6][a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    const float l = fminf(fminf(s_lo[0][a], s_lo[1][a]), fminf(s_lo[2][a], s_lo[3][a]));
+    const float h = fmaxf(fmaxf(s_hi[0][a], s_hi[1][a]), fmaxf(s_hi[2][a], s_hi[3][a]));
+    if (l <= h) { atomicMin(cb + a, f2ord(l)); atomicMax(cb + 3 + a, f2ord(h)); }
   }
 }
 
@@ -145,7 +153,13 @@ __global__ __launch_bounds__(256) void bb_tree_kernel(const uint64_t* __restrict
 }
 
 // ---- 5. boxes, bottom-up ----
+// Two threads meet at every internal node; the second one needs the first one's box.  A release/acquire pair at agent scope
+// (__threadfence) costs an L2 write-back + invalidate per use on this chip (the XCDs' L2s are not coherent with each other):
+// 6 ms for a million triangles.  The boxes are therefore exchanged with relaxed agent-scope atomics -- stores that write through
+// to the coherence point, loads that read there -- and the only ordering needed, "box complete before the counter moves", is the
+// wavefront waiting for its own stores (s_waitcnt) before it issues the counter's atomic.
 __device__ __forceinline__ float coherent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(256) void bb_fit_kernel(const float* __restrict__ tri, const uint32_t* __restrict__ vals, uint32_t n,
                                                        const uint2* __restrict__ child, const uint32_t* __restrict__ parent,
@@ -156,13 +170,13 @@ __global__ __launch_bounds__(256) void bb_fit_kernel(const float* __restrict__ t
   uint32_t id = n - 1 + j;
   for (;;) {
     float* o = box + (size_t)id * 6;
-    o[0] = b.lx; o[1] = b.ly; o[2] = b.lz; o[3] = b.hx; o[4] = b.hy; o[5] = b.hz;
+    coherent_store(o + 0, b.lx); coherent_store(o + 1, b.ly); coherent_store(o + 2, b.lz);
+    coherent_store(o + 3, b.hx); coherent_store(o + 4, b.hy); coherent_store(o + 5, b.hz);
     if (n == 1) return;
     const uint32_t p = id == 0 ? 0xffffffffu : parent[id];
     if (p == 0xffffffffu) return;                     // the root's box is written
-    __threadfence();
-    if (atomicAdd(flag + p, 1u) == 0u) return;        // the sibling subtree is not finished: its last thread continues
-    __threadfence();
+    __builtin_amdgcn_s_waitcnt(0);                    // this wavefront's stores have completed
+    if (__hip_atomic_fetch_add(flag + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;   // the sibling subtree is not finished: its last thread continues
     const uint2 c = child[p];
     const float* s = box + (size_t)(c.x == id ? c.y : c.x) * 6;
     b.lx = fminf(b.lx, coherent_load(s + 0)); b.ly = fminf(b.ly, coherent_load(s + 1)); b.lz = fminf(b.lz, coherent_load(s + 2));
@@ -219,29 +233,27 @@ __device__ __forceinline__ float bb_area(const Box3& b) {
 
 __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
   const uint32_t n_items = A.counters[8 + A.level];
-  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += gridDim.x * blockDim.x) {
-    const uint2 item = A.in[it];
+  const uint32_t lane = threadIdx.x & 63u;
+  // (every lane of a wavefront runs every iteration: node slots and queue positions are handed out per wavefront, one atomic
+  // each, from a prefix sum over its lanes -- per item they would be 600,000 atomics on one address per level)
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n_items; base += gridDim.x * blockDim.x) {
+    const uint32_t it = base + threadIdx.x;
+    const bool act = it < n_items;
+    const uint2 item = act ? A.in[it] : make_uint2(A.n - 1, 0u);
     const uint32_t b = item.x, out = item.y;
     const bool is_leaf_id = b >= A.n - 1;
     const uint2 rg = is_leaf_id ? make_uint2(b - (A.n - 1), b - (A.n - 1)) : A.range[b];
     const uint32_t count = rg.y - rg.x + 1;
     const Box3 bx = bb_load_box(A.box, b);
-    uint32_t w[13];
-    w[0] = __float_as_uint(bx.lx); w[1] = __float_as_uint(bx.ly); w[2] = __float_as_uint(bx.lz);
-    int e[3] = {bb_pick_exp(bx.hx - bx.lx), bb_pick_exp(bx.hy - bx.ly), bb_pick_exp(bx.hz - bx.lz)};
-    uint8_t ch[4][7] = {};
-    if (count <= A.leaf_max) {
-      w[4] = rg.x + A.tri_offset;    // bvh.cpp:260: already offset by the mesh's first triangle
-      w[5] = count;
-      atomicAdd(A.counters + 1, 1u);
-      atomicMax(A.counters + 2, count);
-      atomicMax(A.counters + 3, A.level);
-    } else {
-      uint32_t c[4];
+    const bool leaf = count <= A.leaf_max;
+    uint32_t c[4] = {0, 0, 0, 0};
+    uint32_t nc = 0;
+    Box3 cb[4];
+    cb[0] = cb[1] = cb[2] = cb[3] = bx;
+    if (act && !leaf) {
       const uint2 c0 = A.child[b];
       c[0] = c0.x; c[1] = c0.y;
-      uint32_t nc = 2;
-      Box3 cb[4];
+      nc = 2;
       cb[0] = bb_load_box(A.box, c[0]); cb[1] = bb_load_box(A.box, c[1]);
       for (int round = 0; round < 2; ++round) {
         int pick = -1; float best = -1.0f;
@@ -249,8 +261,8 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
           if (c[k] >= A.n - 1) continue;
           const uint2 r = A.range[c[k]];
           if (r.y - r.x + 1 <= A.leaf_max) continue;      // becomes a leaf as it is
-          const float a = bb_area(cb[k]);
-          if (a > best) { best = a; pick = (int)k; }
+          const float ar = bb_area(cb[k]);
+          if (ar > best) { best = ar; pick = (int)k; }
         }
         if (pick < 0) break;
         const uint2 g = A.child[c[pick]];
@@ -258,7 +270,34 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
         c[nc] = g.y; cb[nc] = bb_load_box(A.box, g.y);
         ++nc;
       }
-      const uint32_t first = atomicAdd(A.counters + 0, nc);
+    }
+    // wavefront prefix sum of the child counts -> node slots and next-level queue positions
+    uint32_t incl = nc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += t; }
+    const uint32_t total = __shfl(incl, 63);
+    uint32_t node_base = 0, q_base = 0;
+    if (lane == 0 && total != 0u) { node_base = atomicAdd(A.counters + 0, total); q_base = atomicAdd(A.counters + 8 + A.level + 1, total); }
+    node_base = __shfl(node_base, 0); q_base = __shfl(q_base, 0);
+    const uint32_t first = node_base + incl - nc, pos = q_base + incl - nc;
+    const unsigned long long leafm = __ballot(act && leaf);
+    uint32_t lmax = act && leaf ? count : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lmax = max(lmax, (uint32_t)__shfl_down(lmax, off));
+    if (lane == 0 && leafm != 0ull) {
+      atomicAdd(A.counters + 1, (uint32_t)__popcll(leafm));
+      atomicMax(A.counters + 2, lmax);
+      atomicMax(A.counters + 3, A.level);
+    }
+    if (!act) continue;
+    uint32_t w[13];
+    w[0] = __float_as_uint(bx.lx); w[1] = __float_as_uint(bx.ly); w[2] = __float_as_uint(bx.lz);
+    int e[3] = {bb_pick_exp(bx.hx - bx.lx), bb_pick_exp(bx.hy - bx.ly), bb_pick_exp(bx.hz - bx.lz)};
+    uint8_t ch[4][7] = {};
+    if (leaf) {
+      w[4] = rg.x + A.tri_offset;    // bvh.cpp:260: already offset by the mesh's first triangle
+      w[5] = count;
+    } else {
       if (first + nc > A.node_capacity) { atomicOr(A.counters + 4, 1u); continue; }
       const float org[3] = {bx.lx, bx.ly, bx.lz};
 #pragma unroll
@@ -280,7 +319,6 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
       for (uint32_t k = 0; k < nc; ++k) ch[k][0] = 1;
       w[4] = first;     // relative to this BLAS's first node (rt_traversal.cpp:92,119)
       w[5] = 0;
-      const uint32_t pos = atomicAdd(A.counters + 8 + A.level + 1, nc);
       for (uint32_t k = 0; k < nc; ++k) A.out[pos + k] = make_uint2(c[k], first + k);
     }
     w[3] = (uint32_t)(uint8_t)(int8_t)e[0] | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16);   // imask = 0: BLAS node
@@ -303,29 +341,50 @@ __global__ __launch_bounds__(256) void bb_gather_kernel(const uint32_t* __restri
   }
 }
 
-struct Scratch {
-  std::vector<void*> ptrs;
+// Scratch: one grow-only device allocation per device, kept between builds (a scene rebuilt every frame must not pay a dozen
+// hipMalloc / hipFree pairs per build); vxrt_bvh_release_scratch() returns it.
+struct Arena {
+  void* base = nullptr; size_t cap = 0; size_t used = 0; int dev = -1;
   template <class T> T* get(size_t count) {
-    void* p = nullptr;
-    if (hipMalloc(&p, count * sizeof(T) + 16) != hipSuccess) return nullptr;
-    ptrs.push_back(p);
-    return (T*)p;
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (used + bytes > cap) return nullptr;
+    T* p = (T*)((char*)base + used);
+    used += bytes;
+    return p;
   }
-  ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
 };
+std::mutex g_arena_mu;
+Arena g_arena;
+
+bool arena_reserve(size_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (g_arena.base && (g_arena.dev != dev || g_arena.cap < bytes)) { (void)hipFree(g_arena.base); g_arena = Arena(); }
+  if (!g_arena.base) {
+    if (hipMalloc(&g_arena.base, bytes) != hipSuccess) { g_arena = Arena(); return false; }
+    g_arena.cap = bytes; g_arena.dev = dev;
+  }
+  g_arena.used = 0;
+  return true;
+}
 
 }  // namespace
 
 extern "C" int vxrt_bvh_build(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tri_offset, uint32_t leaf_max,
                               void* d_nodes, uint32_t node_capacity, vxrt_bvh_info_t* info, void* stream) {
   if (!d_tri || !d_nodes || n_tris == 0 || n_tris > 0x3fffffffu) return -1;
-  if (leaf_max == 0) leaf_max = 4;
+  if (leaf_max == 0) leaf_max = 2;
   if (leaf_max > 15) leaf_max = 15;
   if ((uint64_t)node_capacity < 2ull * n_tris - 1ull) return -1;
   hipStream_t s = (hipStream_t)stream;
   const uint32_t n = n_tris;
-  Scratch sc;
+  std::lock_guard<std::mutex> lk(g_arena_mu);   // (builds on one device are serialised on the scratch arena)
   const uint32_t n_counters = 8 + BB_MAX_LEVELS + 2;
+  size_t tmp_bytes = 0;
+  if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
+  const size_t per_tri = 2 * 8 + 2 * 4 + 2 * 8 + 2 * 4 + 4 + 12 * 4 + 2 * 8 + (d_triEx ? 64 : 36);
+  if (!arena_reserve((size_t)n * per_tri + tmp_bytes + 64 * 1024)) return -1;
+  Arena& sc = g_arena;
   int* cb = sc.get<int>(8);
   uint32_t* counters = sc.get<uint32_t>(n_counters);
   uint64_t* keys0 = sc.get<uint64_t>(n);
@@ -340,18 +399,15 @@ extern "C" int vxrt_bvh_build(void* d_tri, void* d_triEx, uint32_t n_tris, uint3
   uint2* q0 = sc.get<uint2>(n);
   uint2* q1 = sc.get<uint2>(n);
   uint32_t* gather = sc.get<uint32_t>((size_t)n * (d_triEx ? 16 : 9));
-  if (!cb || !counters || !keys0 || !keys1 || !vals0 || !vals1 || !child || !range || !parent || !flag || !box || !q0 || !q1 || !gather) return -1;
+  void* tmp = sc.get<uint8_t>(tmp_bytes ? tmp_bytes : 16);
+  if (!cb || !counters || !keys0 || !keys1 || !vals0 || !vals1 || !child || !range || !parent || !flag || !box || !q0 || !q1 || !gather || !tmp) return -1;
   const uint32_t blocks = (n + 255u) / 256u;
   const uint32_t wide = blocks < 4096u ? blocks : 4096u;
 
   hipLaunchKernelGGL(bb_init_kernel, dim3(1), dim3(256), 0, s, cb, counters, n_counters);
   if (hipMemsetAsync(flag, 0, (size_t)n * 4, s) != hipSuccess) return -1;
-  hipLaunchKernelGGL(bb_bounds_kernel, dim3(wide < 1024u ? wide : 1024u), dim3(256), 0, s, (const float*)d_tri, n, cb);
+  hipLaunchKernelGGL(bb_bounds_kernel, dim3(wide < 512u ? wide : 512u), dim3(256), 0, s, (const float*)d_tri, n, cb);
   hipLaunchKernelGGL(bb_morton_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, n, cb, keys0, vals0);
-  size_t tmp_bytes = 0;
-  if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
-  void* tmp = sc.get<uint8_t>(tmp_bytes ? tmp_bytes : 16);
-  if (!tmp) return -1;
   if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
   if (n > 1) hipLaunchKernelGGL(bb_tree_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, s, keys1, (int)n, child, range, parent);
   hipLaunchKernelGGL(bb_fit_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, vals1, n, child, parent, box, flag);
@@ -394,4 +450,10 @@ extern "C" int vxrt_bvh_build(void* d_tri, void* d_triEx, uint32_t n_tris, uint3
   if (hc[8 + BB_MAX_LEVELS] != 0u) return -2;                  // deeper than the collapse pass goes
   if (hc[3] >= (uint32_t)RT_MAX_LEVELS) return -2;             // deeper than the reference's trail (rt_traversal.h:8): use the SAH builder
   return 0;
+}
+
+extern "C" void vxrt_bvh_release_scratch(void) {
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  if (g_arena.base) (void)hipFree(g_arena.base);
+  g_arena = Arena();
 }
