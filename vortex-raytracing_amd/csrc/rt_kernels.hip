@@ -1895,7 +1895,15 @@ static void accel_free(vxrt_accel* a) {
 
 // next frame context, ordered on `s` behind its previous use
 static FrameCtx* acquire_ctx(vxrt_accel* a, hipStream_t s) {
-  FrameCtx& c = a->ctx[a->next_ctx++ % a->n_ctx];
+  // the context this stream used last (no event hop: the stream orders the two frames), else one never used, else round robin.
+  // (Plain round robin pairs contexts with streams only while the caller's stream rotation and the call count stay in step: an odd
+  // number of warm-up frames was enough to put every later frame behind a cross-stream event wait, -3 %.)
+  uint32_t pick = a->n_ctx;
+  for (uint32_t k = 0; k < a->n_ctx && pick == a->n_ctx; ++k) { const uint32_t i = (a->next_ctx + k) % a->n_ctx; if (a->ctx[i].busy && a->ctx[i].last_stream == s) pick = i; }
+  for (uint32_t k = 0; k < a->n_ctx && pick == a->n_ctx; ++k) { const uint32_t i = (a->next_ctx + k) % a->n_ctx; if (!a->ctx[i].busy) pick = i; }
+  if (pick == a->n_ctx) pick = a->next_ctx % a->n_ctx;
+  a->next_ctx = pick + 1;
+  FrameCtx& c = a->ctx[pick];
   if (!c.inited) {   // (a failed attempt is completed by the next one: every piece is created only if still missing)
     // the side stream carries the small EXACT launch over the a-priori list: highest priority, so that its few workgroups are
     // placed before the main launch fills every CU (an EXACT workgroup cannot co-reside with a full persistent grid: LDS)
