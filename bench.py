@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--level", type=int, default=8, help="atrium tessellation level; 8 -> 1,048,576 triangles")
     ap.add_argument("--shard", choices=["tilerows", "rows"], default="tilerows",
                     help="how ONE frame is split over the GPUs: interleaved 8-row tile rows (default) or contiguous row bands")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="with several GPUs: frames per set of launches and per collective (0 = up to 16, the timed steps split into equal groups)")
+    ap.add_argument("--rehearse-world", type=int, default=0,
+                    help="diagnostic, one GPU: do per frame what rank 0 of an N-GPU run does (its share of the frame, extraction, assembly) without the collective")
     ap.add_argument("--no-shadow", action="store_true")
     ap.add_argument("--settle-frames", type=int, default=160,
                     help="untimed frames before the warmup steps that bring the GPU clocks to their sustained state (0 = none)")
@@ -170,13 +174,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         a.gpus = world
+    # rehearsal of rank 0 of an N-GPU run on one GPU, without the network: everything a rank does per frame except the collective
+    rehearse = a.rehearse_world if (world == 1 and a.rehearse_world > 1) else 0
+    if rehearse:
+        world = rehearse
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU fallback for the hot path")
     if a.dist_backend == "gloo":
         local %= max(1, torch.cuda.device_count())   # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
-    if world > 1:
+    if world > 1 and not rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
@@ -201,13 +209,31 @@ def main():
     nfl = max(1, min(8, a.frames_in_flight))
     # frame i goes to stream i % nfl and framebuffer i % nfl; the accel keeps nfl frame contexts
     streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(nfl - 1)]
+    if os.environ.get("VXRT_BENCH_OWN_STREAMS"):
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
     # (with several ranks a framebuffer stays busy until its gather has run: twice as many, so that rendering never waits for the link)
-    frames = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(max(2, nfl) * (2 if world > 1 else 1))]
+    n_frames = max(2, nfl) * (2 if world > 1 else 1)
+    ig = None
+    # Several ranks: a rank's share of one frame is small against its GPU (4,080 tiles for 6,096 resident wavefronts at 1080p / 8)
+    # and takes as long as its slowest tile -- about half a full frame's time, whatever N.  The steps are therefore issued in batches
+    # of B frames per set of launches (vxrt_render_interleaved_batch) and assembled with one collective per batch.
+    B = 1
+    if world > 1 and a.shard == "tilerows":
+        # default: as large as a batch may be (16), but the K timed steps split into equal groups, at least one per stream
+        # (K = 20 -> 2 groups of 10, not 16 + 4)
+        n_groups = max(nfl, -(-a.steps // 16))
+        B = max(1, min(16, a.batch if a.batch > 0 else -(-a.steps // n_groups)))
+        ig = sharding.InterleavedGather(H, W, rank, world, dev, slots=n_frames, collective=not rehearse, batch=B)
+        frames = [ig.new_frame_buffer(dev) for _ in range(n_frames)]
+    else:
+        frames = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(n_frames)]
     counters = torch.zeros(8, dtype=torch.int64, device=dev)
 
-    def launch(buf, count_ptr=None, st=None):
+    def launch(buf, count_ptr=None, st=None, k=1):
         sp = (st or stream).cuda_stream
-        if world > 1 and a.shard == "tilerows":
+        if B > 1 and k > 0 and count_ptr is None and st is not None:
+            rtapi.render_interleaved_batch(ds.accel, W, H, rank, world, [params] * k, buf.data_ptr(), ig.frame_stride, shadow, None, sp)
+        elif world > 1 and a.shard == "tilerows":
             rtapi.render_interleaved(ds.accel, W, H, rank, world, params, buf.data_ptr(), shadow, None, None, count_ptr, sp)
         else:
             rtapi.render(ds.accel, W, H, y0, y1, params, buf.data_ptr(), shadow, None, None, count_ptr, sp)
@@ -226,7 +252,10 @@ def main():
     gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     gdone = [None] * len(frames)   # per framebuffer: event of the last gather that read it
 
-    def step(i, ev=None):
+    no_gather = bool(rehearse and os.environ.get("VXRT_BENCH_NO_GATHER"))   # (diagnostic: the share's launches alone)
+
+    def step(i, ev=None, k=1):
+        """Issues launch group i: k steps (k = 1 except with several ranks, where a group is a batch of up to B frames)."""
         b = i % len(frames)
         buf = frames[b]
         st = streams[i % nfl]
@@ -234,16 +263,15 @@ def main():
             st.wait_event(gdone[b])            # do not overwrite a frame that is still being gathered
         if ev is not None:
             ev[0].record(st)
-        launch(buf, st=st)
+        launch(buf, st=st, k=k)
         if ev is not None:
             ev[1].record(st)
-        if world > 1:
+        if world > 1 and not no_gather:
             # image assembly overlaps the next step's traversal: the gather runs on its own stream
             gather_stream.wait_stream(st)
             with torch.cuda.stream(gather_stream):
                 if a.shard == "tilerows":
-                    share = sharding.extract_interleaved(buf, H, rank, world)
-                    sharding.gather_interleaved(share if cdev != "cpu" else share.cpu(), H, W, rank, world)
+                    ig.gather(buf, b, via_cpu=(cdev == "cpu"))
                 else:
                     band = buf[y0:y1]
                     sharding.gather_frame(band if cdev != "cpu" else band.cpu(), H, W, rank, world)
@@ -260,28 +288,30 @@ def main():
         torch.cuda.synchronize()
         iso.append(e[0].elapsed_time(e[1]))
     iso_ms = sum(iso) / len(iso)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    def groups(n):     # n steps as launch groups of at most B
+        return [min(B, n - g) for g in range(0, n, B)]
+    timed_groups = groups(a.steps)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in timed_groups]
     # The GPU raises its clocks over the first tens of milliseconds of sustained load (measured: the frame period of a 20-step
     # run shrinks from 0.52 to 0.49 ms between its first and last step).  A short run would time that ramp, not the path, so the
     # clocks are brought to their sustained state first with untimed frames of the same kind; then the W warmup steps, which run as
     # the timed ones do (same streams, same frames in flight) and directly before them.
-    for i in range(a.settle_frames):
-        step(i)
-    for i in range(a.warmup):
-        step(i)
+    for i, k in enumerate(groups(a.settle_frames) + groups(a.warmup)):
+        step(i, k=k)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 and not rehearse:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i, evs[i])
+    for i, k in enumerate(timed_groups):
+        step(i, evs[i], k=k)
+    t_issued = time.perf_counter() - t0     # host time to issue the K steps (diagnostic: a host-bound run has t_issued ~ elapsed)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 and not rehearse:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 and not rehearse:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -298,7 +328,7 @@ def main():
     span_ms = max(evs[0][0].elapsed_time(e1) for _, e1 in evs)
     kern_ms = span_ms / a.steps
     if os.environ.get("VXRT_BENCH_TRACE") and rank == 0:   # start offset of every timed step on the GPU's clock (debugging the timed region itself)
-        print("step starts (ms):", " ".join("%.3f" % evs[0][0].elapsed_time(e0) for e0, _ in evs), "end %.3f" % span_ms, "host %.3f" % (elapsed * 1e3), file=sys.stderr)
+        print("step starts (ms):", " ".join("%.3f" % evs[0][0].elapsed_time(e0) for e0, _ in evs), "end %.3f" % span_ms, "host %.3f" % (elapsed * 1e3), "issued %.3f" % (t_issued * 1e3), file=sys.stderr)
 
     extras = {}
     if a.random_rays:
@@ -319,18 +349,18 @@ def main():
         for _ in range(2):
             rtapi.trace(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 and not rehearse:
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(reps):
             rtapi.trace(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 and not rehearse:
             dist.barrier()
         torch.cuda.synchronize()
         rt = time.perf_counter() - t1
-        if world > 1:
+        if world > 1 and not rehearse:
             t = torch.tensor([rt], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rt = float(t.item())
@@ -352,7 +382,7 @@ def main():
         if world == 1:
             par = "1 GPU: whole frame"
         elif a.shard == "tilerows":
-            par = "one frame split by interleaved 8-row tile rows (rank r: rows r, r+%d, ... of %d tile rows) x%d GPUs, RCCL gather of the shares to rank 0" % (world, (H + 7) // 8, world)
+            par = "one frame split by interleaved 8-row tile rows (rank r: rows r, r+%d, ... of %d tile rows) x%d GPUs, %d frames per set of launches, one RCCL gather of the shares to rank 0 per set" % (world, (H + 7) // 8, world, B)
         else:
             par = "one frame split into %d contiguous tile-aligned row bands, RCCL gather to rank 0" % world
         out = {
@@ -367,7 +397,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (procedural 'Sponza-class' atrium, seed 3; no Sponza/bunny asset exists offline)",
             "config": {"workload": "configs[2]: Sponza-class %d tris, %dx%d, primary + 1 shadow ray per hit%s" % (scene.n_tris, W, H, "" if shadow else " (shadow disabled)"),
-                       "rays_per_step": rays_all, "rays_per_step_rank0": rays_rank, "frames_in_flight": nfl, "clock_settle_frames_untimed": a.settle_frames, "parallelism": par,
+                       "rays_per_step": rays_all, "rays_per_step_rank0": rays_rank, "frames_in_flight": nfl, "frames_per_launch_group": B, "clock_settle_frames_untimed": a.settle_frames, "parallelism": par,
                        "bvh_nodes": scene.n_bvh_nodes, "bvh_depth": scene.info.get("max_depth")},
         }
         prof = load_profile_constants()
@@ -411,7 +441,7 @@ def main():
         if extras:
             out["extras"] = extras
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 and not rehearse:
         dist.destroy_process_group()
 
 

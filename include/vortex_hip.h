@@ -245,6 +245,16 @@ int vxrt_bvh_build(void* tri, void* triEx, uint32_t n_tris, uint32_t tri_offset,
  * mesh rebuilt every frame allocates nothing; this returns it to the device. */
 void vxrt_bvh_release_scratch(void);
 
+/* n_frames (1..VXRT_MAX_BATCH) consecutive frames of the same share in ONE set of launches: frame f is lit and shaded with
+ * params[f] (an array of n_frames entries: e.g. a moving light) and written to dst + f * dst_frame_stride (in pixels; each frame
+ * buffer addressed like vxrt_render_interleaved's).  A rank's share of a frame split N ways is small against the machine and takes
+ * as long as its slowest tile however small it is; a sequence of frames traced side by side keeps the GPU full, and the assembly
+ * of N shares becomes one collective per batch (bench.py --gpus N).  No optional outputs; scenes without reflective instances. */
+#define VXRT_MAX_BATCH 16
+int vxrt_render_interleaved_batch(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t phase, uint32_t stride, uint32_t n_frames,
+                                  const vxrt_shade_params_t* params, int shadow, uint32_t* dst, uint64_t dst_frame_stride,
+                                  unsigned long long* rays_traced, void* stream);
+
 /* vxrt_render with the fetch counters compiled in (diagnostic build of the same kernel, never
  * timed): counters = device u64[7]: rays, node fetches, instance fetches, triangle fetches,
  * shaded hits, textured hits, pixels written.  Counts are what the reference logs per ray in

@@ -225,3 +225,40 @@ def test_4k_frame_as_interleaved_tile_rows_equals_one_shot(vrt, po, gpu_device, 
     y0, y1 = 1076, 1084
     rpx, _, _, _ = po.render_ex(sc, w, h, po.shade_params(light_pos=LIGHT), 1, y0, y1)
     np.testing.assert_array_equal(frame.cpu().numpy().view(np.uint32)[y0:y1], rpx[y0:y1])
+
+
+def test_batch_of_frames_equals_the_frames_one_by_one(vrt, po, gpu_device, atrium):
+    """vxrt_render_interleaved_batch: 5 frames of one rank's share (rank 1 of 3) with a light that moves from frame to frame, in one
+    set of launches -- equal to the five frames rendered one by one, and frame 2 equal to the oracle's on its rows."""
+    import torch
+    sc, ds = atrium
+    w, h, rank, world, n = 488, 270, 1, 3, 5
+    ig = vrt.sharding.InterleavedGather(h, w, rank, world, gpu_device, slots=1, collective=False, batch=n)
+    plist = []
+    for f in range(n):
+        p = vrt.rtapi.default_shade_params()
+        p.light_pos[:] = (300.0 - 40.0 * f, 480.0 - 15.0 * f, 60.0 + 30.0 * f)
+        plist.append(p)
+    s = torch.cuda.current_stream().cuda_stream
+    buf = ig.new_frame_buffer(gpu_device)
+    buf.fill_(0x5A5A5A5A)
+    cnt = torch.zeros(1, dtype=torch.int64, device=gpu_device)
+    vrt.rtapi.render_interleaved_batch(ds.accel, w, h, rank, world, plist, buf.data_ptr(), ig.frame_stride, 1, cnt.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert vrt.rtapi.status(s) == 0
+    rows = vrt.sharding.interleaved_rows(h, rank, world)
+    other = np.setdiff1d(np.arange(ig.padded_height), rows)
+    total = 0
+    for f in range(n):
+        one = torch.full((ig.padded_height, w), 0x5A5A5A5A, dtype=torch.int32, device=gpu_device)
+        c1 = torch.zeros(1, dtype=torch.int64, device=gpu_device)
+        vrt.rtapi.render_interleaved(ds.accel, w, h, rank, world, plist[f], one.data_ptr(), 1, None, None, c1.data_ptr(), s)
+        torch.cuda.synchronize()
+        total += int(c1.item())
+        assert torch.equal(buf[f], one)
+        assert (buf[f].cpu().numpy()[other] == 0x5A5A5A5A).all()      # only this rank's rows are written
+    assert int(cnt.item()) == total
+    assert not torch.equal(buf[0], buf[4])                           # the light did move
+    opp = po.shade_params(light_pos=(300.0 - 80.0, 480.0 - 30.0, 60.0 + 60.0))
+    want, _, _, _ = po.render_ex(sc, w, h, opp, 1)
+    assert np.array_equal(buf[2].cpu().numpy().view(np.uint32)[rows], want[rows])

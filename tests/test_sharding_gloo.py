@@ -48,6 +48,26 @@ def test_interleaved_tile_rows_partition_the_frame_and_reassemble():
         parts = [sh.extract_interleaved(f, h, r, world) for r in range(world)]
         assert all(p.shape == (sh.padded_share_rows(h, world), w) for p in parts)
         assert torch.equal(sh.assemble_interleaved(parts, h, w, world), f)
+        # the per-frame path of bench.py: padded frame buffers, one strided copy per rank, one interleaving copy on rank 0
+        igs = [sh.InterleavedGather(h, w, r, world, "cpu", slots=1, collective=False) for r in range(world)]
+        assert igs[0].padded_height == sh.padded_share_rows(h, world) * world and igs[0].padded_height >= h
+        fp = igs[0].new_frame_buffer("cpu")
+        fp[:h] = f
+        for r in range(world):
+            igs[r].gather(fp, 0)
+            assert torch.equal(igs[r].shares[0][0], parts[r])
+            igs[0].recv[0][r].copy_(igs[r].shares[0])
+        assert torch.equal(igs[0].assemble(0), f)
+        # a batch of frames moves with the same three copies
+        igb = [sh.InterleavedGather(h, w, r, world, "cpu", slots=1, collective=False, batch=3) for r in range(world)]
+        fb = igb[0].new_frame_buffer("cpu")
+        for k in range(3):
+            fb[k, :h] = f + 1000 * k
+        for r in range(world):
+            igb[r].gather(fb, 0)
+            igb[0].recv[0][r].copy_(igb[r].shares[0])
+        got = igb[0].assemble(0)
+        assert got.shape == (3, h, w) and all(torch.equal(got[k], f + 1000 * k) for k in range(3))
     # balance: at 1080p over 8 ranks every rank gets 16 or 17 of the 135 tile rows
     n = [len(sh.interleaved_tile_rows(1080, r, 8)) for r in range(8)]
     assert max(n) - min(n) <= 1 and sum(n) == 135
@@ -70,7 +90,7 @@ def _worker(rank, world, port, mode, use_hip, q):
         p.light_pos[:] = (300.0, 480.0, 60.0)
         buf = torch.full((h, w), 0x5A5A5A5A, dtype=torch.int32, device=dev)
         s = torch.cuda.current_stream().cuda_stream
-        if mode == "tilerows":
+        if mode.startswith("tilerows"):
             vrt.rtapi.render_interleaved(ds.accel, w, h, rank, world, p, buf.data_ptr(), 1, None, None, None, s)
         else:
             y0, y1 = sh.row_bands(h, world)[rank]
@@ -85,6 +105,33 @@ def _worker(rank, world, port, mode, use_hip, q):
     if mode == "tilerows":
         share = sh.extract_interleaved(frame_local, h, rank, world)
         frame = sh.gather_interleaved(share, h, w, rank, world)
+    elif mode == "tilerows_batch":        # what bench.py does with several ranks: 3 frames per set of launches, one collective
+        ig = sh.InterleavedGather(h, w, rank, world, "cpu", slots=1, batch=3)
+        fb = ig.new_frame_buffer("cpu")
+        if use_hip:
+            plist = []
+            for k in range(3):
+                pk = vrt.rtapi.default_shade_params()
+                pk.light_pos[:] = (300.0 - 50.0 * k, 480.0, 60.0 + 40.0 * k)
+                plist.append(pk)
+            dbuf = torch.zeros(fb.shape, dtype=torch.int32, device=dev)
+            vrt.rtapi.render_interleaved_batch(ds.accel, w, h, rank, world, plist, dbuf.data_ptr(), ig.frame_stride, 1, None, s)
+            torch.cuda.synchronize()
+            assert vrt.rtapi.status(s) == 0
+            fb.copy_(dbuf.cpu())
+        else:
+            for k in range(3):
+                fb[k, :h] = frame_local + k
+        frame = ig.gather(fb, 0)
+        if frame is not None:
+            frame = frame.clone()
+    elif mode == "tilerows_prepared":     # what bench.py does per frame
+        ig = sh.InterleavedGather(h, w, rank, world, "cpu", slots=1)
+        fp = ig.new_frame_buffer("cpu")
+        fp[:h] = frame_local
+        frame = ig.gather(fp, 0)
+        if frame is not None:
+            frame = frame.clone()
     else:
         y0, y1 = sh.row_bands(h, world)[rank]
         frame = sh.gather_frame(frame_local[y0:y1].contiguous(), h, w, rank, world)
@@ -110,7 +157,32 @@ def _run(mode, use_hip):
     return frame
 
 
-@pytest.mark.parametrize("mode", ["tilerows", "rows"])
+def test_two_rank_batch_assembly():
+    frames = _run("tilerows_batch", False)
+    sys.path.insert(0, ROOT)
+    import importlib
+    vrt = importlib.import_module("vortex-raytracing_amd")
+    from oracle import pyoracle as po
+    want, _, _ = po.render(vrt.scene.procedural("cornell"), 40, 44)
+    assert frames.shape == (3, 44, 40)
+    for k in range(3):
+        assert np.array_equal(frames[k], (want.view(np.int32) + k).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_two_rank_batch_assembly_on_the_hip_path(po):
+    """Two processes share the box's GPU; each renders its share of THREE frames (a moving light) in one set of launches, one gloo gather."""
+    frames = _run("tilerows_batch", True)
+    sys.path.insert(0, ROOT)
+    import importlib
+    vrt = importlib.import_module("vortex-raytracing_amd")
+    sc = vrt.scene.procedural("atrium", 3, 0, 3)
+    for k in range(3):
+        want, _, _, _ = po.render_ex(sc, 328, 184, po.shade_params(light_pos=(300.0 - 50.0 * k, 480.0, 60.0 + 40.0 * k)), 1)
+        assert np.array_equal(frames[k], want)
+
+
+@pytest.mark.parametrize("mode", ["tilerows", "tilerows_prepared", "rows"])
 def test_two_rank_frame_assembly(mode):
     frame = _run(mode, False)
     sys.path.insert(0, ROOT)
@@ -122,7 +194,7 @@ def test_two_rank_frame_assembly(mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["tilerows", "rows"])
+@pytest.mark.parametrize("mode", ["tilerows", "tilerows_prepared", "rows"])
 def test_two_rank_frame_assembly_on_the_hip_path(mode, po):
     """Two processes share the box's GPU; each renders its share with the HIP kernels, gloo gathers, rank 0 assembles."""
     frame = _run(mode, True)

@@ -251,16 +251,21 @@ __device__ __forceinline__ uint32_t f2u_x86(float f) { return (uint32_t)(long lo
 // Occlusion ray of the shadow extension (no reference counterpart): from the hit point toward the
 // light, origin pushed 1e-3 along L like the reference's mirror bounce (closest.cpp:104), tmax = |L|.
 // I, L and dist are computed exactly as shade_eval computes them.
-__device__ __forceinline__ void shadow_ray(const ShadeParams& p, float ox, float oy, float oz, float dx, float dy, float dz,
+__device__ __forceinline__ void shadow_ray(float lpx, float lpy, float lpz, float ox, float oy, float oz, float dx, float dy, float dz,
                                            float hit_dist, float& sox, float& soy, float& soz, float& sdx, float& sdy, float& sdz, float& sdist) {
   const float Ix = ox + dx * hit_dist, Iy = oy + dy * hit_dist, Iz = oz + dz * hit_dist;
-  float Lx = p.lpos[0] - Ix, Ly = p.lpos[1] - Iy, Lz = p.lpos[2] - Iz;
+  float Lx = lpx - Ix, Ly = lpy - Iy, Lz = lpz - Iz;
   const float dist = sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
   const float il = 1.0f / dist;
   Lx *= il; Ly *= il; Lz *= il;
   sox = Ix + Lx * 0.001f; soy = Iy + Ly * 0.001f; soz = Iz + Lz * 0.001f;
   sdx = Lx; sdy = Ly; sdz = Lz;
   sdist = dist;
+}
+
+__device__ __forceinline__ void shadow_ray(const ShadeParams& p, float ox, float oy, float oz, float dx, float dy, float dz,
+                                           float hit_dist, float& sox, float& soy, float& soz, float& sdx, float& sdy, float& sdz, float& sdist) {
+  shadow_ray(p.lpos[0], p.lpos[1], p.lpos[2], ox, oy, oz, dx, dy, dz, hit_dist, sox, soy, soz, sdx, sdy, sdz, sdist);
 }
 
 // closest.cpp:57-90 for one hit: the non-reflected diffuse contribution `throughput * diffuse * (1 - reflectivity)`
@@ -495,6 +500,9 @@ struct PersistArgs {
   // (tile_order[queue position] = tile, sorted by cost within each shard's band) and where this frame's cost goes
   const uint32_t* tile_order; uint32_t* tile_cost;
   unsigned long long* wave_log;   // STATS only, optional: 16 u64 per wavefront (see vxrt_render_wave_log in the header)
+  // batch of frames in one launch (vxrt_render_interleaved_batch): the window's tiles repeat `frame_tiles` apart, frame f = tile /
+  // frame_tiles is shaded and lit with pbatch[f]; nullptr = one frame
+  const ShadeParams* pbatch; uint32_t frame_tiles;
 };
 
 // Domain of the fast (non-EXACT) traversal: every component of 1/d finite, non-zero and at most 2^64 in magnitude, every origin
@@ -611,7 +619,9 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   if (STATS && A.wave_log) { t_first = wall_clock64(); wl_tstart = __builtin_readcyclecounter(); }
 
   auto pixel_of = [&](uint32_t r, uint32_t& x, uint32_t& y) {
-    const uint32_t tile = r >> 6, l = r & 63u;
+    uint32_t tile = r >> 6;
+    const uint32_t l = r & 63u;
+    if (A.pbatch) tile %= A.frame_tiles;   // (a batch of frames: same window, frame_tiles tiles apart)
     x = (tile % A.tiles_x) * 8u + (l & 7u);
     y = A.y0 + (tile / A.tiles_x) * A.row_step + (l >> 3);
   };
@@ -629,7 +639,9 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
       if (JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW)) {
         const float pd = __uint_as_float(CTX(5));   // distance of this pixel's primary hit
         float sox, soy, soz, sdx, sdy, sdz, sdist;
-        shadow_ray(p, ox, oy, oz, dx, dy, dz, pd, sox, soy, soz, sdx, sdy, sdz, sdist);
+        float lpx = p.lpos[0], lpy = p.lpos[1], lpz = p.lpos[2];
+        if (A.pbatch) { const ShadeParams* q = A.pbatch + (job >> 6) / A.frame_tiles; lpx = q->lpos[0]; lpy = q->lpos[1]; lpz = q->lpos[2]; }
+        shadow_ray(lpx, lpy, lpz, ox, oy, oz, dx, dy, dz, pd, sox, soy, soz, sdx, sdy, sdz, sdist);
         ox = sox; oy = soy; oz = soz; dx = sdx; dy = sdy; dz = sdz;
         tmax_ = sdist;
       }
@@ -1095,7 +1107,9 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
           pixel_of(job, x, y);
           float ox, oy, oz, dx, dy, dz, sox, soy, soz, sdx, sdy, sdz, sdist;
           generate_ray(A.utab[x], A.vtab[y], ox, oy, oz, dx, dy, dz);
-          shadow_ray(p, ox, oy, oz, dx, dy, dz, hitd, sox, soy, soz, sdx, sdy, sdz, sdist);
+          float lpx = p.lpos[0], lpy = p.lpos[1], lpz = p.lpos[2];
+          if (A.pbatch) { const ShadeParams* q = A.pbatch + (job >> 6) / A.frame_tiles; lpx = q->lpos[0]; lpy = q->lpos[1]; lpz = q->lpos[2]; }
+          shadow_ray(lpx, lpy, lpz, ox, oy, oz, dx, dy, dz, hitd, sox, soy, soz, sdx, sdy, sdz, sdist);
           CTX(5) = __float_as_uint(hitd);
           flags = F_SHADOW;
           start_ray(sox, soy, soz, sdx, sdy, sdz, sdist, true);
@@ -1194,7 +1208,8 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
                                                       HitRec* __restrict__ hits, float* __restrict__ colors,
                                                       unsigned long long* counters, uint32_t* __restrict__ ctl_reset,
                                                       uint32_t lpt_blocks, const uint32_t* __restrict__ lpt_cost, uint32_t* __restrict__ lpt_order,
-                                                      uint32_t lpt_tiles, uint32_t lpt_per_shard) {
+                                                      uint32_t lpt_tiles, uint32_t lpt_per_shard,
+                                                      uint32_t batch = 1, const ShadeParams* __restrict__ pbatch = nullptr, uint64_t dst_frame_stride = 0) {
   // the first lpt_blocks workgroups sort the frame's tiles by cost for the context's next frame (see lpt_order_block)
   __shared__ uint32_t s_hist[2048 + 8];
   if (blockIdx.x < lpt_blocks) { lpt_order_block(blockIdx.x, lpt_cost, lpt_order, lpt_tiles, lpt_per_shard, s_hist); return; }
@@ -1204,12 +1219,14 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
   if (ctl_reset && blk == 0)
     for (uint32_t i = threadIdx.x; i < CTL_DWORDS; i += 256u) ctl_reset[i] = 0u;
   const uint64_t t = (uint64_t)blk * 256u + threadIdx.x;
-  const uint64_t n = (uint64_t)W * n_rows;   // local rows of the window (its tile rows x 8; rows past y1 are skipped)
+  const uint64_t n = (uint64_t)W * n_rows * batch;   // local rows of the window (its tile rows x 8; rows past y1 are skipped), per frame of the batch
   unsigned ntex = 0, npix = 0;
-  const uint32_t x = (uint32_t)(t % W), lr = (uint32_t)(t / W), y = frame_row(lr, y0, row_step);
+  const uint32_t x = (uint32_t)(t % W), vr = (uint32_t)(t / W);   // vr: row of the batch's stacked windows
+  const uint32_t frame = batch > 1 ? vr / n_rows : 0u, lr = vr - frame * n_rows, y = frame_row(lr, y0, row_step);
+  if (batch > 1 && t < n) { p = pbatch[frame]; dst += (size_t)frame * dst_frame_stride; }
   if (t < n && y < y1) {
     const size_t idx = (size_t)x + (size_t)y * W;
-    HitRec h = hb[hit_index(x, lr, (W + 7u) >> 3)];   // tile-major, 192 contiguous bytes per 8 pixels of a row
+    HitRec h = hb[hit_index(x, vr, (W + 7u) >> 3)];   // tile-major, 192 contiguous bytes per 8 pixels of a row
     const uint32_t occ_bit = h.blasIdx & 0x80000000u;
     const bool occ = occ_bit != 0u;
     h.blasIdx &= 0x7fffffffu;
@@ -1831,6 +1848,7 @@ struct FrameCtx {
   uint32_t* defer = nullptr;   // job list of the EXACT launch
   uint64_t defer_cap = 0;
   uint32_t* ctl = nullptr;     // control block (CTL_DWORDS), zero between frames
+  ShadeParams* pbatch = nullptr;   // per-frame shading parameters of a batch launch (VXRT_MAX_BATCH entries)
   bool ctl_dirty = false;      // a call failed after touching it: clear before the next use
   // mirror-bounce levels (allocated on first use; level 0 only holds `term`, one entry per pixel)
   struct Level {
@@ -1865,7 +1883,7 @@ struct vxrt_accel {
   // camera pixels whose primary ray has a zero direction component (u == 0 or v == 0): listed on the
   // host per (W, H, y0, y1) and traced by an EXACT launch on a side stream, concurrently with the main one
   uint32_t* apriori = nullptr; // [0] count, [1..] job ids
-  uint32_t ap_count = 0, ap_key[5] = {0, 0, 0, 0, 0};
+  uint32_t ap_count = 0, ap_key[6] = {0, 0, 0, 0, 0, 0};
   uint64_t ap_cap = 0;
   float max_reflectivity = 0.0f;   // over the instance records: > 0 enables the mirror-bounce path
   int device = 0;
@@ -1885,6 +1903,7 @@ static void accel_free(vxrt_accel* a) {
       (void)hipFree(l.rays); (void)hipFree(l.hits); (void)hipFree(l.parent); (void)hipFree(l.term); (void)hipFree(l.col);
       (void)hipFree(l.srays); (void)hipFree(l.stmax); (void)hipFree(l.shits);
     }
+    (void)hipFree(c.pbatch);
     if (c.side) (void)hipStreamDestroy(c.side);
     if (c.ev_in) (void)hipEventDestroy(c.ev_in);
     if (c.ev_side) (void)hipEventDestroy(c.ev_side);
@@ -2253,8 +2272,11 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
 static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                          const vxrt_shade_params_t* params, int shadow, uint32_t* dst, vxrt_hit_t* hits, float* colors,
                          unsigned long long* counters, int stats, void* stream, unsigned long long* wave_log = nullptr,
-                         const vxrt_ao_params_t* ao = nullptr, uint32_t* unoccluded = nullptr, uint32_t stride = 1) {
+                         const vxrt_ao_params_t* ao = nullptr, uint32_t* unoccluded = nullptr, uint32_t stride = 1,
+                         uint32_t batch = 1, uint64_t dst_frame_stride = 0) {
   if (!a || !params || !dst) return -1;
+  // batch > 1: `params` is an array of `batch` entries, frame f goes to dst + f * dst_frame_stride; plain frames without optional outputs
+  if (batch == 0 || batch > VXRT_MAX_BATCH || (batch > 1 && (hits || colors || stats || ao || wave_log))) return -1;
   if (ao && (stats || shadow)) return -1;
   if (stride == 0 || (stride > 1 && ((y0 & 7u) != 0 || ao))) return -1;   // interleaved tile rows: tile-aligned start, plain frames only
   if (!a->ref.triEx || !a->ref.mat || a->ref.n_mats == 0) return -1;  // shading needs them (closest.cpp:52-55)
@@ -2272,16 +2294,17 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   // tile rows of the window: every stride-th tile row of [y0, y1) starting with the one at y0
   const uint32_t tiles_x = (width + 7) / 8, tiles_y = ((y1 - y0 + 7) / 8 + stride - 1) / stride;
   const uint32_t row_step = 8u * stride;
-  const uint64_t n_tiles64 = (uint64_t)tiles_x * tiles_y;
+  const uint64_t n_tiles64 = (uint64_t)tiles_x * tiles_y * batch;
   if (n_tiles64 > 0x1ffffffull) return -1;
-  const uint32_t n_tiles = (uint32_t)n_tiles64;
+  const uint32_t n_tiles = (uint32_t)n_tiles64;            // of the whole batch
+  const uint32_t frame_tiles = tiles_x * tiles_y;
   dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   const SceneDev& sc = a->dev;
   FrameCtx* c = acquire_ctx(a, s);
   if (!c) return -1;
   // hit-record buffer between the two passes (one per frame in flight)
-  const uint64_t pixels = (uint64_t)tiles_x * ((height + 7) / 8 + 1) * 64u;   // tile-major records of any row window of the frame
+  const uint64_t pixels = batch > 1 ? (uint64_t)n_tiles * 64u : (uint64_t)tiles_x * ((height + 7) / 8 + 1) * 64u;   // tile-major records of any row window of the frame
   if (c->hitbuf_pixels < pixels) {
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     (void)hipFree(c->hitbuf);
@@ -2305,6 +2328,20 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.row_step = row_step; A.total = n_tiles * 64u;
   A.hits = (HitRec*)c->hitbuf; A.counters = counters; A.status = st; A.wave_log = wave_log;
   A.utab = a->uvtab; A.vtab = a->uvtab + width;
+  if (batch > 1) {
+    if (p.max_depth > 1 && a->max_reflectivity > 0.0f) return -1;
+    if (!c->pbatch && hipMalloc((void**)&c->pbatch, VXRT_MAX_BATCH * sizeof(ShadeParams)) != hipSuccess) return -1;
+    ShadeParams pb[VXRT_MAX_BATCH];
+    for (uint32_t f = 0; f < batch; ++f) {
+      for (int i = 0; i < 3; ++i) {
+        pb[f].amb[i] = params[f].ambient[i]; pb[f].lcol[i] = params[f].light_color[i];
+        pb[f].lpos[i] = params[f].light_pos[i]; pb[f].bg[i] = params[f].background[i];
+      }
+      pb[f].max_depth = params[f].max_depth;
+    }
+    if (hipMemcpyAsync(c->pbatch, pb, batch * sizeof(ShadeParams), hipMemcpyHostToDevice, s) != hipSuccess) return -1;   // (pageable source: staged before the call returns)
+    A.pbatch = c->pbatch; A.frame_tiles = frame_tiles;
+  }
   if (ensure_defer(c, A.total, s) != 0) return -1;
   A.defer_count = c->ctl; A.defer_list = c->defer; A.defer_cap = A.total;
   A.queue = c->ctl + 32;
@@ -2315,7 +2352,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   // and only for frames of more than LPT_MIN_TILES tiles: below, the sort launch costs more than the shorter tail saves
   // (1024x1024, 86 % background: -5 %; 1920x1080: +9 %; 3840x2160: +4 %; the sort on a side stream instead: worse, the
   // two extra event hops cost more than the kernel)
-  const bool lpt = lpt_on && (!stats || wave_log) && a->n_ctx == 1 && n_tiles >= LPT_MIN_TILES;   // (with frames in flight: no difference, measured)
+  const bool lpt = lpt_on && (!stats || wave_log) && a->n_ctx == 1 && batch == 1 && n_tiles >= LPT_MIN_TILES;   // (with frames in flight: no difference, measured)
   if (lpt) {
     if (c->lpt_cap < n_tiles) {
       if (hipStreamSynchronize(s) != hipSuccess) return -1;
@@ -2330,9 +2367,9 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     A.tile_order = c->lpt_valid ? c->tile_order : nullptr;
   }
   // a-priori EXACT list (camera rays with u == 0 or v == 0), rebuilt only when the window changes
-  if (a->ap_key[0] != width || a->ap_key[1] != height || a->ap_key[2] != y0 || a->ap_key[3] != y1 || a->ap_key[4] != stride || !a->apriori) {
+  if (a->ap_key[0] != width || a->ap_key[1] != height || a->ap_key[2] != y0 || a->ap_key[3] != y1 || a->ap_key[4] != stride || a->ap_key[5] != batch || !a->apriori) {
     std::vector<uint32_t> list(1, 0u);
-    for (uint32_t t = 0; t < n_tiles; ++t)
+    for (uint32_t t = 0; t < frame_tiles; ++t)
       for (uint32_t l = 0; l < 64; ++l) {
         const uint32_t x = (t % tiles_x) * 8u + (l & 7u), y = y0 + (t / tiles_x) * row_step + (l >> 3);
         if (x >= width || y >= y1) continue;
@@ -2340,6 +2377,9 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
         const float v = (float)(((double)y * 2.0 - (double)height) / (double)height);
         if (u == 0.0f || v == 0.0f) list.push_back(t * 64u + l);
       }
+    const size_t per_frame = list.size() - 1;
+    for (uint32_t f = 1; f < batch; ++f)
+      for (size_t i = 0; i < per_frame; ++i) list.push_back(list[1 + i] + f * frame_tiles * 64u);
     list[0] = (uint32_t)(list.size() - 1);
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (a->ap_cap < list.size()) {
@@ -2350,7 +2390,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     }
     if (hipMemcpy(a->apriori, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
     a->ap_count = list[0];
-    a->ap_key[0] = width; a->ap_key[1] = height; a->ap_key[2] = y0; a->ap_key[3] = y1; a->ap_key[4] = stride;
+    a->ap_key[0] = width; a->ap_key[1] = height; a->ap_key[2] = y0; a->ap_key[3] = y1; a->ap_key[4] = stride; a->ap_key[5] = batch;
   }
   // EXACT launch over the a-priori list on the side stream (ordered after everything already queued on
   // `s`: it writes hit records the previous frame's shading pass may still be reading), concurrent with
@@ -2369,9 +2409,21 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     X0.queue = c->ctl + 32 + 2 * CTL_QUEUE_DWORDS;
     X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = a->ap_count;
   }
+  // A window that is small against the machine (one rank's share of a frame split N ways: at 1080p / 8 GPUs 4,080 tiles for 6,096
+  // resident wavefronts) makes one launch a single round of tiles -- as long as its slowest tile, about half a full frame -- and a
+  // second frame's launch only gets the slots the first one leaves.  With several frames in flight each launch therefore takes
+  // its share of the machine (capacity / frames in flight): the frames run side by side, each wavefront working through several
+  // tiles, and the machine stays full.  (A full frame, many tiles per wavefront, keeps the whole grid: measured better.)
+  static const int grid_div_env = [] { const char* e = getenv("VXRT_GRID_DIV"); return e ? atoi(e) : 0; }();
+#define MAIN_GRID(K) [&]() -> uint32_t { \
+    uint32_t g = persistent_grid(K, A.total + (uint64_t)side_wgs * RT_WG_THREADS); \
+    const uint32_t cap = persistent_grid(K, ~0ull >> 8); \
+    uint32_t div = grid_div_env > 0 ? (uint32_t)grid_div_env : ((grid_div_env == 0 && a->n_ctx > 1 && (uint64_t)A.total < 2ull * 64ull * RT_WG_WAVES * cap) ? a->n_ctx : 1u); \
+    if (div > 1u) g = std::min<uint32_t>(g, std::max<uint32_t>(cap / div, 1u)); \
+    return std::max<uint32_t>(1u, g > side_wgs ? g - side_wgs : 1u); }()
 #define LAUNCH_P(J, ST, LD) do { \
     if (side_launch) hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(side_wgs), block, 0, side, sc, p, X0); \
-    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false>), dim3(std::max<uint32_t>(1u, persistent_grid(rt_persistent_kernel<J, ST, LD, false>, A.total + (uint64_t)side_wgs * RT_WG_THREADS) - side_wgs)), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
+    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false>), dim3(MAIN_GRID((rt_persistent_kernel<J, ST, LD, false>))), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, s, sc, p, X); } while (0)
 #define LAUNCH_PD(J, ST) do { if (sc.exact_decode) LAUNCH_P(J, ST, true); else LAUNCH_P(J, ST, false); } while (0)
   if (stats == 2)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 2); else LAUNCH_PD(JOB_RENDER, 2); }
@@ -2379,6 +2431,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   else             { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 0); else LAUNCH_PD(JOB_RENDER, 0); }
 #undef LAUNCH_PD
 #undef LAUNCH_P
+#undef MAIN_GRID
   // (the tile sort for the next frame rides in the shading launch; the AO / bounce tails have no such launch and skip it)
   const bool lpt_sort = lpt && !ao && !(p.max_depth > 1 && a->max_reflectivity > 0.0f);
   if (lpt && !lpt_sort) c->lpt_valid = false;
@@ -2395,13 +2448,13 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     if (render_bounce_tail(a, c, p, width, y0, y1, shadow, A.utab, A.vtab, dst, (HitRec*)hits, colors, counters, s) != 0) return -1;
     return release_ctx(c, s);
   }
-  const uint64_t npx = (uint64_t)width * tiles_y * 8u;
+  const uint64_t npx = (uint64_t)width * tiles_y * 8u * batch;
   const uint32_t lpt_blocks = lpt_sort ? QUEUE_SHARDS : 0u;
   dim3 sgrid((uint32_t)((npx + 255) / 256) + lpt_blocks);
   if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl,
                                 lpt_blocks, (const uint32_t*)c->tile_cost, c->tile_order, n_tiles, A.per_shard >> 6);
   else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl,
-                                lpt_blocks, (const uint32_t*)c->tile_cost, c->tile_order, n_tiles, A.per_shard >> 6);
+                                lpt_blocks, (const uint32_t*)c->tile_cost, c->tile_order, n_tiles, A.per_shard >> 6, batch, (const ShadeParams*)c->pbatch, dst_frame_stride);
   if (hipGetLastError() != hipSuccess) return -1;
   if (lpt_sort) c->lpt_valid = true;
   c->ctl_dirty = false;
@@ -2423,6 +2476,18 @@ int vxrt_render_interleaved(vxrt_accel_t* accel, uint32_t width, uint32_t height
   if (stride == 0 || phase >= stride) return -1;
   if ((uint64_t)phase * 8u >= height) return 0;   // more ranks than tile rows: nothing for this one
   return render_common(accel, width, height, phase * 8u, height, params, shadow, dst, hits, colors, rays_traced, false, stream, nullptr, nullptr, nullptr, stride);
+}
+
+// n_frames frames of the same window in ONE set of launches: frame f is lit and shaded with params[f] and written to dst + f *
+// dst_frame_stride.  One rank's share of a frame split N ways is a single round of tiles -- as long as its slowest tile, about half
+// a full frame's time however small the share -- so a sequence of frames is traced side by side instead.
+int vxrt_render_interleaved_batch(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t phase, uint32_t stride, uint32_t n_frames,
+                                  const vxrt_shade_params_t* params, int shadow, uint32_t* dst, uint64_t dst_frame_stride,
+                                  unsigned long long* rays_traced, void* stream) {
+  if (stride == 0 || phase >= stride || n_frames == 0) return -1;
+  if ((uint64_t)phase * 8u >= height) return 0;
+  return render_common(accel, width, height, phase * 8u, height, params, shadow, dst, nullptr, nullptr, rays_traced, false, stream, nullptr, nullptr, nullptr, stride,
+                       n_frames, dst_frame_stride);
 }
 
 // Same launches as vxrt_render with the fetch counters compiled in (slower; never the timed path).

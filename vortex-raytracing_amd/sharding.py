@@ -107,3 +107,66 @@ def gather_frame(band, height, width, rank, world, group=None):
     for r, (y0, y1) in enumerate(row_bands(height, world)):
         frame[y0:y1] = out[r][: y1 - y0]
     return frame
+
+
+class InterleavedGather:
+    """The per-frame image assembly of an N-rank run with everything that can be prepared once prepared once: frames are rendered
+    into buffers of padded height (padded_share_rows * world rows, so that a rank's share is ONE strided slice whatever
+    height % (8 * world) is), the share, the receive buffers and the assembled frame are preallocated per slot, and a frame costs
+    one strided copy on every rank + one gather + one interleaving copy on rank 0 -- three launches, not one per tile row
+    (1080 rows = 135 tile rows divide by no N > 1: the tile-row loop of extract/assemble_interleaved was the whole frame time).
+    batch > 1: a slot holds `batch` frames ([batch, padded_height, width], what vxrt_render_interleaved_batch fills) and the same
+    three launches move all of them."""
+
+    def __init__(self, height, width, rank, world, device, slots=2, dtype=None, group=None, collective=True, batch=1):
+        import torch
+        self.h, self.w, self.rank, self.world, self.group, self.batch = height, width, rank, world, group, batch
+        self.per = padded_share_rows(height, world) // TILE        # tile rows per rank, padded
+        self.padded_height = self.per * world * TILE
+        self.collective = collective                                # False: rehearsal of one rank without the network
+        self.dtype = dtype or torch.int32
+        self.shares = [torch.zeros((batch, self.per * TILE, width), dtype=self.dtype, device=device) for _ in range(slots)]
+        self.recv = self.full = None
+        if rank == 0:
+            self.recv = [[torch.zeros((batch, self.per * TILE, width), dtype=self.dtype, device=device) for _ in range(world)] for _ in range(slots)]
+            self.full = [torch.zeros((batch, self.per, world, TILE, width), dtype=self.dtype, device=device) for _ in range(slots)]
+
+    def new_frame_buffer(self, device):
+        """[padded_height, width] (batch 1) or [batch, padded_height, width]: what the render calls write this rank's rows into."""
+        import torch
+        shape = (self.padded_height, self.w) if self.batch == 1 else (self.batch, self.padded_height, self.w)
+        return torch.zeros(shape, dtype=self.dtype, device=device)
+
+    @property
+    def frame_stride(self):
+        """Pixels between two frames of a batch buffer (dst_frame_stride of vxrt_render_interleaved_batch)."""
+        return self.padded_height * self.w
+
+    def gather(self, frame, slot, via_cpu=False):
+        """frame: buffer from new_frame_buffer this rank rendered its tile rows into.  Returns the assembled frame(s) on rank 0
+        ([height, width] or [batch, height, width], views of a per-slot buffer), None elsewhere."""
+        import torch
+        import torch.distributed as dist
+        share = self.shares[slot]
+        share.view(self.batch, self.per, TILE, self.w).copy_(frame.view(self.batch, self.per, self.world, TILE, self.w)[:, :, self.rank])
+        if self.world > 1 and self.collective:
+            if via_cpu:     # gloo rehearsal: collectives on host tensors
+                out = [torch.empty_like(share, device="cpu") for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(share.cpu(), out, dst=0, group=self.group)
+                if self.rank == 0:
+                    for r in range(self.world):
+                        self.recv[slot][r].copy_(out[r])
+            else:
+                dist.gather(share, self.recv[slot] if self.rank == 0 else None, dst=0, group=self.group)
+        elif self.rank == 0:
+            self.recv[slot][0].copy_(share)
+        return self.assemble(slot)
+
+    def assemble(self, slot):
+        """Rank 0: the frame(s) from the shares received into `slot` (one interleaving copy)."""
+        import torch
+        if self.rank != 0:
+            return None
+        torch.stack([p.view(self.batch, self.per, TILE, self.w) for p in self.recv[slot]], dim=2, out=self.full[slot])
+        out = self.full[slot].view(self.batch, self.padded_height, self.w)[:, : self.h]
+        return out[0] if self.batch == 1 else out
