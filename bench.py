@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--shard", choices=["tilerows", "rows"], default="tilerows",
                     help="how ONE frame is split over the GPUs: interleaved 8-row tile rows (default) or contiguous row bands")
     ap.add_argument("--batch", type=int, default=0,
-                    help="with several GPUs: frames per set of launches and per collective (0 = up to 16, the timed steps split into equal groups)")
+                    help="frames per set of launches, and per collective with several GPUs (0 = automatic: up to 5 on one GPU, up to 16 with several, the timed steps split into equal groups; 1 = one frame per set of launches)")
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="diagnostic, one GPU: do per frame what rank 0 of an N-GPU run does (its share of the frame, extraction, assembly) without the collective")
     ap.add_argument("--no-shadow", action="store_true")
@@ -225,14 +225,23 @@ def main():
         B = max(1, min(16, a.batch if a.batch > 0 else -(-a.steps // n_groups)))
         ig = sharding.InterleavedGather(H, W, rank, world, dev, slots=n_frames, collective=not rehearse, batch=B)
         frames = [ig.new_frame_buffer(dev) for _ in range(n_frames)]
+    elif world == 1 and a.batch != 1 and nfl > 1:
+        # One GPU: whole frames in groups of up to 5 per set of launches (the same entry point with one rank).  Each wavefront then
+        # works through 5x as many tiles per launch, so ramp and tail of a launch weigh less -- the effect that lets a 3840x2160
+        # frame reach 10 Grays/s: +5..6 % (3..12 frames per set measured alike: profiles/r02_l_frame_batches.txt).
+        # --batch 1 = one frame per set of launches.
+        n_groups = max(nfl, -(-a.steps // 5))
+        B = max(1, min(16, a.batch if a.batch > 1 else -(-a.steps // n_groups)))
+        frames = [torch.zeros((B, H, W), dtype=torch.int32, device=dev) for _ in range(n_frames)]
     else:
         frames = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(n_frames)]
     counters = torch.zeros(8, dtype=torch.int64, device=dev)
+    frame_stride = ig.frame_stride if ig is not None else H * W
 
     def launch(buf, count_ptr=None, st=None, k=1):
         sp = (st or stream).cuda_stream
         if B > 1 and k > 0 and count_ptr is None and st is not None:
-            rtapi.render_interleaved_batch(ds.accel, W, H, rank, world, [params] * k, buf.data_ptr(), ig.frame_stride, shadow, None, sp)
+            rtapi.render_interleaved_batch(ds.accel, W, H, rank, world, [params] * k, buf.data_ptr(), frame_stride, shadow, None, sp)
         elif world > 1 and a.shard == "tilerows":
             rtapi.render_interleaved(ds.accel, W, H, rank, world, params, buf.data_ptr(), shadow, None, None, count_ptr, sp)
         else:

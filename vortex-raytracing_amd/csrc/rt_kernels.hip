@@ -1883,6 +1883,7 @@ struct vxrt_accel {
   // camera pixels whose primary ray has a zero direction component (u == 0 or v == 0): listed on the
   // host per (W, H, y0, y1) and traced by an EXACT launch on a side stream, concurrently with the main one
   uint32_t* apriori = nullptr; // [0] count, [1..] job ids
+  uint32_t* batch_order[VXRT_MAX_BATCH + 1] = {}; uint32_t bo_tiles = 0;   // band-major tile order of a batch of k frames of bo_tiles tiles each, per k
   uint32_t ap_count = 0, ap_key[6] = {0, 0, 0, 0, 0, 0};
   uint64_t ap_cap = 0;
   float max_reflectivity = 0.0f;   // over the instance records: > 0 enables the mirror-bounce path
@@ -1895,6 +1896,7 @@ static void accel_free(vxrt_accel* a) {
   (void)hipFree(a->nodes_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root);
   (void)hipFree(a->top_img); (void)hipFree(a->top_roots);
   (void)hipFree(a->uvtab); (void)hipFree(a->apriori);
+  for (uint32_t k = 0; k <= VXRT_MAX_BATCH; ++k) (void)hipFree(a->batch_order[k]);
   for (FrameCtx& c : a->ctx) {
     (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount); (void)hipFree(c.tile_cost); (void)hipFree(c.tile_order);
     (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_alb); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits); (void)hipFree(c.ao_list); (void)hipFree(c.ao_hdr);
@@ -2341,6 +2343,25 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     }
     if (hipMemcpyAsync(c->pbatch, pb, batch * sizeof(ShadeParams), hipMemcpyHostToDevice, s) != hipSuccess) return -1;   // (pageable source: staged before the call returns)
     A.pbatch = c->pbatch; A.frame_tiles = frame_tiles;
+    // tile order of a batch: band-major -- queue shard s (= the XCD that works on it) gets band s of EVERY frame, so that an
+    // XCD's L2 keeps holding one band's part of the BVH, as it does for a single frame; frame-major order would hand each XCD
+    // whole frames (measured at 8 frames per batch: slower than no batch at all)
+    if (a->bo_tiles != frame_tiles) {   // another window: drop the orders of the old one
+      if (hipDeviceSynchronize() != hipSuccess) return -1;
+      for (uint32_t k = 0; k <= VXRT_MAX_BATCH; ++k) { (void)hipFree(a->batch_order[k]); a->batch_order[k] = nullptr; }
+      a->bo_tiles = frame_tiles;
+    }
+    if (!a->batch_order[batch]) {
+      std::vector<uint32_t> ord;
+      ord.reserve(n_tiles);
+      const uint32_t band = (frame_tiles + QUEUE_SHARDS - 1) / QUEUE_SHARDS;
+      for (uint32_t sh = 0; sh < QUEUE_SHARDS; ++sh)
+        for (uint32_t f = 0; f < batch; ++f)
+          for (uint32_t t = sh * band; t < std::min(frame_tiles, (sh + 1) * band); ++t) ord.push_back(f * frame_tiles + t);
+      if (hipMalloc((void**)&a->batch_order[batch], ord.size() * sizeof(uint32_t)) != hipSuccess) return -1;
+      if (hipMemcpy(a->batch_order[batch], ord.data(), ord.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    }
+    A.tile_order = a->batch_order[batch];
   }
   if (ensure_defer(c, A.total, s) != 0) return -1;
   A.defer_count = c->ctl; A.defer_list = c->defer; A.defer_cap = A.total;
@@ -2366,8 +2387,9 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     A.tile_cost = c->tile_cost;
     A.tile_order = c->lpt_valid ? c->tile_order : nullptr;
   }
-  // a-priori EXACT list (camera rays with u == 0 or v == 0), rebuilt only when the window changes
-  if (a->ap_key[0] != width || a->ap_key[1] != height || a->ap_key[2] != y0 || a->ap_key[3] != y1 || a->ap_key[4] != stride || a->ap_key[5] != batch || !a->apriori) {
+  // a-priori EXACT list (camera rays with u == 0 or v == 0), rebuilt only when the window changes.  The list of a batch is the
+  // frames' lists one after the other, so a list built for F frames serves every batch <= F: the launch takes a prefix.
+  if (a->ap_key[0] != width || a->ap_key[1] != height || a->ap_key[2] != y0 || a->ap_key[3] != y1 || a->ap_key[4] != stride || a->ap_key[5] < batch || !a->apriori) {
     std::vector<uint32_t> list(1, 0u);
     for (uint32_t t = 0; t < frame_tiles; ++t)
       for (uint32_t l = 0; l < 64; ++l) {
@@ -2389,25 +2411,26 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
       a->ap_cap = list.size();
     }
     if (hipMemcpy(a->apriori, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
-    a->ap_count = list[0];
+    a->ap_count = (uint32_t)per_frame;      // per frame
     a->ap_key[0] = width; a->ap_key[1] = height; a->ap_key[2] = y0; a->ap_key[3] = y1; a->ap_key[4] = stride; a->ap_key[5] = batch;
   }
+  const uint32_t ap_count = a->ap_count * batch;   // of this launch: the first `batch` frames of the list
   // EXACT launch over the a-priori list on the side stream (ordered after everything already queued on
   // `s`: it writes hit records the previous frame's shading pass may still be reading), concurrent with
   // the main launch; then the main launch and the EXACT launch over whatever the main one deferred
   PersistArgs X = A, X0 = A;
   X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
   c->ctl_dirty = true;   // until the shading pass that zeroes the block again is enqueued
-  const bool side_launch = a->ap_count != 0;
+  const bool side_launch = ap_count != 0;
   // the a-priori EXACT launch needs a few workgroups (3,000 rays of a 1080p frame = 12); the main launch leaves that many slots
   // free: a persistent grid that fills every CU (LDS) would otherwise keep them waiting until its first workgroups retire, and
   // the frame would end on them (measured: 33 us after the main launch, profiles/r02_d_exact_timeline.txt)
-  const uint32_t side_wgs = side_launch ? std::min<uint32_t>(EXACT_GRID, (a->ap_count + 255u) / 256u) : 0u;
+  const uint32_t side_wgs = side_launch ? std::min<uint32_t>(EXACT_GRID, (ap_count + 255u) / 256u) : 0u;
   hipStream_t side = c->side;
   if (side_launch) {
     if (hipEventRecord(c->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, c->ev_in, 0) != hipSuccess) return -1;
     X0.queue = c->ctl + 32 + 2 * CTL_QUEUE_DWORDS;
-    X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = a->ap_count;
+    X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = ap_count;
   }
   // A window that is small against the machine (one rank's share of a frame split N ways: at 1080p / 8 GPUs 4,080 tiles for 6,096
   // resident wavefronts) makes one launch a single round of tiles -- as long as its slowest tile, about half a full frame -- and a
