@@ -424,6 +424,15 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #ifndef RT_TRACE_DEAD_MAX
 #define RT_TRACE_DEAD_MAX 16   // ray-buffer jobs (incoherent rays): refill early
 #endif
+#ifndef RT_WAVE_PRIO
+#define RT_WAVE_PRIO 0
+#endif
+#ifndef RT_PERTURB_VALU
+#define RT_PERTURB_VALU 0
+#endif
+#ifndef RT_PERTURB_SLEEP
+#define RT_PERTURB_SLEEP 0
+#endif
 #ifndef RT_PUSH_FAST
 #define RT_PUSH_FAST 0      // 1: wave-uniform LDS-only push path of the node step (fewer branches; measured +0.2 %: not worth the code)
 #endif
@@ -574,6 +583,19 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   // of the same pixel - same traversal code, so no phase mixing) before the whole tile is done
   constexpr uint32_t FINISH_MIN = JOB == JOB_RENDER_SHADOW ? RT_SHADOW_FINISH_MIN : 65u;
   const uint32_t lane = threadIdx.x & 63u;
+#if RT_WAVE_PRIO > 0
+  // distinct issue priorities for the wavefronts that share a SIMD (one from each of the CU's resident workgroups, which the dispatcher
+  // hands out 256 apart): with equal priorities the wavefronts of a SIMD fall into step -- all computing, then all waiting
+  if (!EXACT) {
+    const uint32_t pr = RT_WAVE_PRIO == 1 ? (blockIdx.x >> 8) & 3u : (RT_WAVE_PRIO == 2 ? blockIdx.x & 3u : ((blockIdx.x >> 8) & 1u) * 3u);
+    switch (pr) {   // (s_setprio takes an immediate)
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: __builtin_amdgcn_s_setprio(0); break;
+    }
+  }
+#endif
   // EXACT launch: the jobs are the entries of the deferral list the main launch left behind
   const uint32_t n_jobs = EXACT ? min(*A.defer_count, A.defer_cap) : (A.total_dev ? min(*A.total_dev, A.total) : A.total);
   const uint32_t per_shard = (EXACT || A.total_dev) ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
@@ -880,6 +902,13 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
           const uint4* np = sc.nodes_c + (size_t)ni * CNODE_VEC4;
           q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
         }
+#if RT_PERTURB_VALU > 0
+        // perturbation experiment (tools/ab_quick.sh): extra independent full-rate VALU work per node step
+        { float pa = arx, pb = ary;
+#pragma unroll
+          for (int k = 0; k < RT_PERTURB_VALU / 2; ++k) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(pa) : "v"(aix)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(pb) : "v"(aiy)); }
+          asm volatile("" :: "v"(pa), "v"(pb)); }
+#endif
         const uint32_t* ref_node = nullptr;
         if (LDEXP) ref_node = top ? sc.ref_tlas + (size_t)ni * RT_NODE_DWORDS : sc.ref_bvh + (size_t)(ni - sc.n_tlas) * RT_NODE_DWORDS;
         if (STATS) fx.node++;
@@ -1010,6 +1039,12 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
         }
         }   // !V2
       }
+#if RT_PERTURB_SLEEP > 0
+      // perturbation experiment: extra latency per loop iteration (64 clocks per unit) that uses no issue slot and overlaps no load:
+      // after the node step's results are in registers, before the next fetch is issued
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+      __builtin_amdgcn_s_sleep(RT_PERTURB_SLEEP);
+#endif
       if (STATS && A.wave_log) { const unsigned long long t1 = __builtin_readcyclecounter(); wl_tn += t1 - wl_t0; wl_t0 = t1; }
       RT_MARK("inst");
       if (__any(is_inst_desc(cur))) {
