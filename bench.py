@@ -415,6 +415,7 @@ def main():
         roof = {"bound": "valu", "achieved": None, "peak": round(SIMDS * CLOCK_GHZ, 1), "unit": "Gcycle/s (VALU issue cycles summed over the 1024 SIMDs)", "frac": None, "traffic": None,
                 "kernel": "rt_persistent_kernel<JOB_RENDER%s> (+ EXACT launches + rt_shade_kernel)" % ("_SHADOW" if shadow else ""),
                 "kernel_ms": round(kern_ms, 4), "kernel_ms_overlapped": round(ovl_ms, 4), "kernel_ms_isolated": round(iso_ms, 4),
+                "frames_per_launch": B, "launch_set_ms_overlapped": round(ovl_ms * a.steps / max(1, len(evs)), 4),
                 "frames_in_flight": nfl,
                 "why_valu": "the scene is cache-resident (measured HBM traffic = a few % of the HBM peak) and relieving the memory path measured neutral (LDS-staged "
                             "top of the tree: 39 % of node steps from LDS, -17 % vector-memory instructions, +0 %: profiles/r02_b_lds_top_counters.txt); what moves the time "
