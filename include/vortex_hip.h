@@ -241,6 +241,11 @@ typedef struct vxrt_bvh_info {
 } vxrt_bvh_info_t;
 int vxrt_bvh_build(void* tri, void* triEx, uint32_t n_tris, uint32_t tri_offset, uint32_t leaf_max,
                    void* nodes, uint32_t node_capacity, vxrt_bvh_info_t* info, void* stream);
+/* TLAS over instances on the GPU (reference: BVH::buildTLAS, bvh.cpp:266-421): instance_boxes = device, n_instances x 6 floats
+ * (world-space lo xyz, hi xyz of instance i = blas record i); nodes = device, node_capacity >= 2 * n_instances - 1 entries of 52 B;
+ * node 0 is the root, a leaf carries leafData = i, internal nodes UINT32_MAX, imask = 1.  Same return codes as vxrt_bvh_build. */
+int vxrt_tlas_build(const float* instance_boxes, uint32_t n_instances, void* nodes, uint32_t node_capacity,
+                    vxrt_bvh_info_t* info, void* stream);
 /* The builder keeps one grow-only scratch allocation per process (about 170 B per triangle of the largest build) so that a
  * mesh rebuilt every frame allocates nothing; this returns it to the device. */
 void vxrt_bvh_release_scratch(void);

@@ -161,3 +161,40 @@ def test_one_million_triangles(vrt, po, gpu_device):
     _, want_hits, _ = po.render(sc, w, h, opp, y0, y1)
     assert np.array_equal(_bits(hits[y0:y1].reshape(-1)), _bits(want_hits.reshape(h, w)[y0:y1].reshape(-1)))
     ds.close(); dr.close()
+
+
+@pytest.mark.parametrize("n_inst", [1, 6, 40])
+def test_multi_instance_scene_built_on_the_gpu(vrt, po, gpu_device, n_inst):
+    """Every mesh's BLAS with vxrt_bvh_build, the TLAS over the instances with vxrt_tlas_build (reference: buildTLAS,
+    bvh.cpp:266-421): TLAS invariants, the HIP traversal equal to the oracle on that scene, distances equal to those of the
+    scene the CPU builder makes of the same instances."""
+    rng = np.random.default_rng(3)
+    base = rng.uniform(-1, 1, size=(64, 9)).astype(np.float32)
+    xf = []
+    for i in range(n_inst):
+        m = np.eye(4, dtype=np.float32)
+        m[:3, 3] = (220 + 30 * (i % 8), 100 + 25 * ((i % 3) - 1), -150 + 60 * (i % 6) + 7 * (i // 6))
+        m[:3, :3] *= 35.0 if n_inst <= 6 else 12.0
+        xf.append(m)
+    ds = vrt.tracer.DeviceScene.build_on_gpu([base] * n_inst, transforms=xf, device=gpu_device)
+    sc = ds.to_host()
+    nodes = sc["tlas"].view(np.dtype([("o", "<f4", 3), ("e", "i1", 3), ("imask", "u1"), ("lf", "<u4"), ("ld", "<u4"), ("ch", "u1", (4, 7))]))
+    assert (nodes["imask"] == 1).all() and len(nodes) == ds.tlas_info.n_nodes
+    leaves = nodes[nodes["ld"] != 0xFFFFFFFF]
+    assert sorted(leaves["ld"].tolist()) == list(range(n_inst))           # one leaf per instance
+    internal = np.nonzero(nodes["ld"] == 0xFFFFFFFF)[0]
+    assert (nodes["lf"][internal] > internal).all()                       # children after their parent
+    if n_inst > 1:
+        assert len(internal) >= 1 and ds.tlas_info.max_depth >= 1
+    rays = po.camera_rays(64, 48)
+    rays = rays[(rays[:, 3:] != 0).all(1)]
+    got = gpu_trace(vrt, ds, rays)
+    want, _ = po.trace_canonical(sc, rays)
+    assert np.array_equal(_bits(got), _bits(want))
+    hit = got["dist"] < 1e29
+    assert hit.sum() > 20 and len(set(got["blasIdx"][hit])) >= min(4, n_inst)
+    cpu = vrt.scene.from_triangles([base] * n_inst, xf)
+    c, _ = po.trace_canonical(cpu, rays)
+    assert np.array_equal(c["dist"] < 1e29, hit)
+    np.testing.assert_allclose(got["dist"], c["dist"], rtol=2e-5)
+    ds.close()

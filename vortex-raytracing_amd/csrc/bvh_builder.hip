@@ -49,18 +49,28 @@ __device__ __forceinline__ Box3 tri_box(const float* __restrict__ t) {
   return b;
 }
 
-__global__ void bb_init_kernel(int* cb, uint32_t* counters, uint32_t n_counters) {
+// bounds to +-inf, counters to zero except: one node allocated (the root, output slot 0), one item on level 0 = (binary root, slot 0)
+// primitive i of the build: a triangle (stride 9) or, for the TLAS, an instance's world-space box (stride 6)
+__device__ __forceinline__ Box3 prim_box(const float* __restrict__ prims, uint32_t i, bool boxes) {
+  if (!boxes) return tri_box(prims + (size_t)i * 9);
+  const float* p = prims + (size_t)i * 6;
+  Box3 b; b.lx = p[0]; b.ly = p[1]; b.lz = p[2]; b.hx = p[3]; b.hy = p[4]; b.hz = p[5];
+  return b;
+}
+
+__global__ void bb_init_kernel(int* cb, uint32_t* counters, uint32_t n_counters, uint2* level0) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 3) cb[i] = 0x7fffffff;
   else if (i < 6) cb[i] = (int)0x80000000;
-  if (i < n_counters) counters[i] = 0;
+  if (i < n_counters) counters[i] = (i == 0 || i == 8) ? 1u : 0u;
+  if (i == 0) level0[0] = make_uint2(0u, 0u);   // (node id 0 is the binary root, or the only leaf when n == 1)
 }
 
 // ---- 1. bounds of the box centres ----
-__global__ __launch_bounds__(256) void bb_bounds_kernel(const float* __restrict__ tri, uint32_t n, int* __restrict__ cb) {
+__global__ __launch_bounds__(256) void bb_bounds_kernel(const float* __restrict__ tri, uint32_t n, int* __restrict__ cb, bool boxes) {
   float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const Box3 b = tri_box(tri + (size_t)i * 9);
+    const Box3 b = prim_box(tri, i, boxes);
     const float c[3] = {0.5f * (b.lx + b.hx), 0.5f * (b.ly + b.hy), 0.5f * (b.lz + b.hz)};
 #pragma unroll
     for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], c[a]); hi[a] = fmaxf(hi[a], c[a]); }
@@ -95,10 +105,10 @@ __device__ __forceinline__ uint64_t spread21(uint32_t v) {
 }
 
 __global__ __launch_bounds__(256) void bb_morton_kernel(const float* __restrict__ tri, uint32_t n, const int* __restrict__ cb,
-                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, bool boxes) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Box3 b = tri_box(tri + (size_t)i * 9);
+  const Box3 b = prim_box(tri, i, boxes);
   const float c[3] = {0.5f * (b.lx + b.hx), 0.5f * (b.ly + b.hy), 0.5f * (b.lz + b.hz)};
   uint32_t q[3];
 #pragma unroll
@@ -163,10 +173,10 @@ __device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic
 
 __global__ __launch_bounds__(256) void bb_fit_kernel(const float* __restrict__ tri, const uint32_t* __restrict__ vals, uint32_t n,
                                                        const uint2* __restrict__ child, const uint32_t* __restrict__ parent,
-                                                       float* __restrict__ box /* 6 floats per node id */, uint32_t* __restrict__ flag) {
+                                                       float* __restrict__ box /* 6 floats per node id */, uint32_t* __restrict__ flag, bool boxes) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  Box3 b = tri_box(tri + (size_t)vals[j] * 9);
+  Box3 b = prim_box(tri, vals[j], boxes);
   uint32_t id = n - 1 + j;
   for (;;) {
     float* o = box + (size_t)id * 6;
@@ -219,6 +229,7 @@ struct CollapseArgs {
   uint32_t* counters;       // [0] nodes allocated, [1] leaves, [2] largest leaf, [3] deepest level, [4] error flags, [8 + L] items of level L
   const uint2* in; uint2* out;
   uint32_t level;
+  const uint32_t* prim_ids;   // TLAS build: sorted position -> instance (blasIdx); nullptr = BLAS build
 };
 
 __device__ __forceinline__ Box3 bb_load_box(const float* box, uint32_t id) {
@@ -295,8 +306,8 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
     int e[3] = {bb_pick_exp(bx.hx - bx.lx), bb_pick_exp(bx.hy - bx.ly), bb_pick_exp(bx.hz - bx.lz)};
     uint8_t ch[4][7] = {};
     if (leaf) {
-      w[4] = rg.x + A.tri_offset;    // bvh.cpp:260: already offset by the mesh's first triangle
-      w[5] = count;
+      if (A.prim_ids) { w[4] = 0; w[5] = A.prim_ids[rg.x]; }   // TLAS leaf (bvh.cpp:325-328): leafData = blasIdx
+      else { w[4] = rg.x + A.tri_offset; w[5] = count; }       // bvh.cpp:260: already offset by the mesh's first triangle
     } else {
       if (first + nc > A.node_capacity) { atomicOr(A.counters + 4, 1u); continue; }
       const float org[3] = {bx.lx, bx.ly, bx.lz};
@@ -317,11 +328,11 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
         }
       }
       for (uint32_t k = 0; k < nc; ++k) ch[k][0] = 1;
-      w[4] = first;     // relative to this BLAS's first node (rt_traversal.cpp:92,119)
-      w[5] = 0;
+      w[4] = first;     // relative to this BLAS's first node (rt_traversal.cpp:92,119); TLAS: to its node 0
+      w[5] = A.prim_ids ? 0xffffffffu : 0u;   // internal TLAS nodes carry UINT32_MAX (bvh.cpp:417)
       for (uint32_t k = 0; k < nc; ++k) A.out[pos + k] = make_uint2(c[k], first + k);
     }
-    w[3] = (uint32_t)(uint8_t)(int8_t)e[0] | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16);   // imask = 0: BLAS node
+    w[3] = (uint32_t)(uint8_t)(int8_t)e[0] | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16) | (A.prim_ids ? 1u << 24 : 0u);   // imask: 1 = TLAS node
     const uint8_t* cbytes = &ch[0][0];
 #pragma unroll
     for (int k = 0; k < 7; ++k) w[6 + k] = (uint32_t)cbytes[4 * k] | ((uint32_t)cbytes[4 * k + 1] << 8) | ((uint32_t)cbytes[4 * k + 2] << 16) | ((uint32_t)cbytes[4 * k + 3] << 24);
@@ -370,11 +381,12 @@ bool arena_reserve(size_t bytes) {
 
 }  // namespace
 
-extern "C" int vxrt_bvh_build(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tri_offset, uint32_t leaf_max,
-                              void* d_nodes, uint32_t node_capacity, vxrt_bvh_info_t* info, void* stream) {
+static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tri_offset, uint32_t leaf_max,
+                        void* d_nodes, uint32_t node_capacity, vxrt_bvh_info_t* info, void* stream, bool boxes) {
   if (!d_tri || !d_nodes || n_tris == 0 || n_tris > 0x3fffffffu) return -1;
   if (leaf_max == 0) leaf_max = 2;
   if (leaf_max > 15) leaf_max = 15;
+  if (boxes) { leaf_max = 1; d_triEx = nullptr; }
   if ((uint64_t)node_capacity < 2ull * n_tris - 1ull) return -1;
   hipStream_t s = (hipStream_t)stream;
   const uint32_t n = n_tris;
@@ -404,24 +416,17 @@ extern "C" int vxrt_bvh_build(void* d_tri, void* d_triEx, uint32_t n_tris, uint3
   const uint32_t blocks = (n + 255u) / 256u;
   const uint32_t wide = blocks < 4096u ? blocks : 4096u;
 
-  hipLaunchKernelGGL(bb_init_kernel, dim3(1), dim3(256), 0, s, cb, counters, n_counters);
+  hipLaunchKernelGGL(bb_init_kernel, dim3(1), dim3(256), 0, s, cb, counters, n_counters, q0);
   if (hipMemsetAsync(flag, 0, (size_t)n * 4, s) != hipSuccess) return -1;
-  hipLaunchKernelGGL(bb_bounds_kernel, dim3(wide < 512u ? wide : 512u), dim3(256), 0, s, (const float*)d_tri, n, cb);
-  hipLaunchKernelGGL(bb_morton_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, n, cb, keys0, vals0);
+  hipLaunchKernelGGL(bb_bounds_kernel, dim3(wide < 512u ? wide : 512u), dim3(256), 0, s, (const float*)d_tri, n, cb, boxes);
+  hipLaunchKernelGGL(bb_morton_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, n, cb, keys0, vals0, boxes);
   if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
   if (n > 1) hipLaunchKernelGGL(bb_tree_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, s, keys1, (int)n, child, range, parent);
-  hipLaunchKernelGGL(bb_fit_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, vals1, n, child, parent, box, flag);
+  hipLaunchKernelGGL(bb_fit_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, vals1, n, child, parent, box, flag, boxes);
 
-  // root item: binary node 0 (or the single leaf) -> output node 0
-  const uint2 root_item = make_uint2(n > 1 ? 0u : 0u /* leaf id n-1+0 = 0 */, 0u);
-  const uint32_t init_counters[2] = {1u, 0u};   // one node allocated
-  if (hipMemcpyAsync(q0, &root_item, sizeof root_item, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
-  if (hipMemcpyAsync(counters, init_counters, 4, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
-  const uint32_t one = 1u;
-  if (hipMemcpyAsync(counters + 8, &one, 4, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
   CollapseArgs A;
   A.child = child; A.range = range; A.box = box; A.n = n; A.leaf_max = leaf_max; A.tri_offset = tri_offset; A.node_capacity = node_capacity;
-  A.nodes = (uint32_t*)d_nodes; A.counters = counters;
+  A.nodes = (uint32_t*)d_nodes; A.counters = counters; A.prim_ids = boxes ? vals1 : nullptr;
   for (uint32_t L = 0; L < (uint32_t)BB_MAX_LEVELS; ++L) {
     A.in = (L & 1u) ? q1 : q0; A.out = (L & 1u) ? q0 : q1; A.level = L;
     // (level L holds at most 4^L items)
@@ -429,9 +434,12 @@ extern "C" int vxrt_bvh_build(void* d_tri, void* d_triEx, uint32_t n_tris, uint3
     if (L < 8) { const uint32_t items = 1u << (2 * L); g = (items + 255u) / 256u < wide ? (items + 255u) / 256u : wide; }
     hipLaunchKernelGGL(bb_collapse_kernel, dim3(g), dim3(256), 0, s, A);
   }
-  // triangles (and shading records) into the sorted order, in place through a scratch copy (bvh.cpp:126-128 reorders in place)
-  hipLaunchKernelGGL(bb_gather_kernel, dim3(wide), dim3(256), 0, s, (const uint32_t*)d_tri, vals1, n, 9u, gather);
-  if (hipMemcpyAsync(d_tri, gather, (size_t)n * 36, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+  // triangles (and shading records) into the sorted order, in place through a scratch copy (bvh.cpp:126-128 reorders in place);
+  // instances stay where they are (a TLAS leaf names its instance)
+  if (!boxes) {
+    hipLaunchKernelGGL(bb_gather_kernel, dim3(wide), dim3(256), 0, s, (const uint32_t*)d_tri, vals1, n, 9u, gather);
+    if (hipMemcpyAsync(d_tri, gather, (size_t)n * 36, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+  }
   if (d_triEx) {
     hipLaunchKernelGGL(bb_gather_kernel, dim3(wide), dim3(256), 0, s, (const uint32_t*)d_triEx, vals1, n, 16u, gather);
     if (hipMemcpyAsync(d_triEx, gather, (size_t)n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
@@ -450,6 +458,18 @@ extern "C" int vxrt_bvh_build(void* d_tri, void* d_triEx, uint32_t n_tris, uint3
   if (hc[8 + BB_MAX_LEVELS] != 0u) return -2;                  // deeper than the collapse pass goes
   if (hc[3] >= (uint32_t)RT_MAX_LEVELS) return -2;             // deeper than the reference's trail (rt_traversal.h:8): use the SAH builder
   return 0;
+}
+
+extern "C" int vxrt_bvh_build(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tri_offset, uint32_t leaf_max,
+                              void* d_nodes, uint32_t node_capacity, vxrt_bvh_info_t* info, void* stream) {
+  return build_common(d_tri, d_triEx, n_tris, tri_offset, leaf_max, d_nodes, node_capacity, info, stream, false);
+}
+
+// TLAS over instances (reference: BVH::buildTLAS, bvh.cpp:266-421, host code there): the same pipeline over the instances'
+// world-space boxes, one instance per leaf (leafData = blasIdx, imask = 1), internal nodes marked UINT32_MAX.
+extern "C" int vxrt_tlas_build(const float* d_instance_boxes, uint32_t n_instances, void* d_nodes, uint32_t node_capacity,
+                               vxrt_bvh_info_t* info, void* stream) {
+  return build_common((void*)d_instance_boxes, nullptr, n_instances, 0, 1, d_nodes, node_capacity, info, stream, true);
 }
 
 extern "C" void vxrt_bvh_release_scratch(void) {

@@ -93,6 +93,19 @@ def bvh_build(tri_ptr, triEx_ptr, n_tris, nodes_ptr, node_capacity, tri_offset=0
     return info
 
 
+def tlas_build(boxes_ptr, n_instances, nodes_ptr, node_capacity, stream=None):
+    """vxrt_tlas_build: TLAS over n_instances world-space boxes (device, 6 floats each), in the reference's node format."""
+    L = _lib()
+    L.vxrt_tlas_build.restype = C.c_int
+    L.vxrt_tlas_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(BvhInfo), C.c_void_p]
+    info = BvhInfo()
+    rc = L.vxrt_tlas_build(boxes_ptr, n_instances, nodes_ptr, node_capacity, C.byref(info), stream)
+    if rc == -2:
+        raise BvhTooDeep("vxrt_tlas_build: tree depth %d exceeds the reference's 32 levels" % info.max_depth)
+    check(rc, "vxrt_tlas_build")
+    return info
+
+
 def accel_destroy(accel):
     if accel:
         check(_lib().vxrt_accel_destroy(accel), "vxrt_accel_destroy")

@@ -114,58 +114,76 @@ class DeviceScene:
             self.accel = rtapi.accel_build(s, torch.cuda.current_stream().cuda_stream)
 
     @classmethod
-    def build_on_gpu(cls, tri, triEx=None, mat=None, tex=None, device="cuda:0", leaf_max=0):
-        """Scene of ONE mesh whose BLAS is built on the GPU (vxrt_bvh_build) from a triangle soup: tri float32 [n, 9]
-        (tri_t), triEx uint8/float32 [n, 64 B] (tri_ex_t; default: flat normals, material 0), mat / tex as the reference's
-        buffers (default: one grey material, no texture).  The single-node TLAS and the identity instance record are what
-        the reference's scene builder emits for one mesh (bvh.cpp:325-328, scene.cpp:84-99).  Returns a DeviceScene whose
-        buffers never existed on the host; .bvh_info holds the builder's counts."""
+    def build_on_gpu(cls, tri, triEx=None, mat=None, tex=None, device="cuda:0", leaf_max=0, transforms=None):
+        """Scene whose BVHs are built on the GPU from triangle soups: every mesh's BLAS with vxrt_bvh_build, the TLAS over the
+        instances with vxrt_tlas_build.  tri: float32 [n, 9] (tri_t) or a list of such arrays (one per mesh); triEx: uint8 / float32
+        [n, 64 B] (tri_ex_t) or a list (default: flat normals, material 0); transforms: optional list of 4x4 object-to-world
+        matrices (default identity); mat / tex as the reference's buffers (default: one grey material, no texture).  Instance
+        records are what the reference's scene builder writes (scene.cpp:84-99).  The buffers never exist on the host; .bvh_info
+        holds the last mesh's builder counts, .tlas_info the TLAS's."""
         import torch
         self = cls.__new__(cls)
         self.device = device
-        n = int(np.asarray(tri).reshape(-1, 9).shape[0])
-        with torch.cuda.device(device):
-            t_tri = torch.from_numpy(np.ascontiguousarray(np.asarray(tri, np.float32).reshape(-1, 9))).to(device).view(torch.uint8).reshape(-1)
-            if triEx is None:
-                v = np.asarray(tri, np.float32).reshape(-1, 3, 3)
+        meshes = [np.ascontiguousarray(np.asarray(t, np.float32).reshape(-1, 9)) for t in (tri if isinstance(tri, (list, tuple)) else [tri])]
+        exs = list(triEx) if isinstance(triEx, (list, tuple)) else [triEx] * len(meshes) if triEx is None else [triEx]
+        if transforms is None:
+            transforms = [np.eye(4, dtype=np.float32)] * len(meshes)
+        assert len(exs) == len(meshes) == len(transforms)
+        for i, (m, e) in enumerate(zip(meshes, exs)):
+            if e is None:
+                v = m.reshape(-1, 3, 3)
                 nrm = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
                 nrm = (nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)).astype(np.float32)
-                ex = np.zeros((n, 16), np.float32)
+                ex = np.zeros((len(m), 16), np.float32)
                 ex[:, 0:3] = ex[:, 3:6] = ex[:, 6:9] = nrm
-                triEx = ex
-            t_ex = torch.from_numpy(np.ascontiguousarray(triEx).view(np.uint8).reshape(-1)).to(device)
-            assert t_ex.numel() == n * 64
+                exs[i] = ex
+            exs[i] = np.ascontiguousarray(exs[i]).view(np.uint8).reshape(-1, 64)
+            assert len(exs[i]) == len(m)
+        n = sum(len(m) for m in meshes)
+        with torch.cuda.device(device):
+            t_tri = torch.from_numpy(np.concatenate(meshes)).to(device).view(torch.uint8).reshape(-1)
+            t_ex = torch.from_numpy(np.concatenate(exs).reshape(-1)).to(device)
             if mat is None:
-                m = np.zeros(22, np.float32)
-                m[3:6] = 0.8
-                mat = m.view(np.uint8).copy()
+                m0 = np.zeros(22, np.float32)
+                m0[3:6] = 0.8
+                mat = m0.view(np.uint8).copy()
                 mat[64:68] = np.frombuffer(struct.pack("<i", -1), np.uint8)
             t_mat = torch.from_numpy(np.ascontiguousarray(mat).view(np.uint8).reshape(-1)).to(device)
             t_tex = torch.from_numpy(np.ascontiguousarray(tex if tex is not None and np.asarray(tex).size else np.zeros(4, np.uint8)).view(np.uint8).reshape(-1)).to(device)
             cap = 2 * n
             t_bvh = torch.zeros(cap * NODE_BYTES, dtype=torch.uint8, device=device)
             stream = torch.cuda.current_stream().cuda_stream
-            info = rtapi.bvh_build(t_tri.data_ptr(), t_ex.data_ptr(), n, t_bvh.data_ptr(), cap, 0, leaf_max, stream)
-            t_bvh = t_bvh[: info.n_nodes * NODE_BYTES]
-            b = np.array(list(info.bounds), np.float32)
-            # TLAS: one node, the instance leaf (imask 1, leafData = blasIdx 0)
-            ext = np.maximum(b[3:] - b[:3], 0)
-            exps = [0 if not e > 0 else int(np.clip(np.ceil(np.log2(np.float32(e) / np.float32(255.0))), -126, 126)) for e in ext]
-            tl = struct.pack("<3f3bBII", float(b[0]), float(b[1]), float(b[2]), exps[0], exps[1], exps[2], 1, 0, 0) + bytes(28)
-            bl = np.zeros(40, np.float32)
-            bl[1:17] = np.eye(4, dtype=np.float32).reshape(-1)      # invTransform
-            bl[17:33] = np.eye(4, dtype=np.float32).reshape(-1)     # transform
-            t_tlas = torch.from_numpy(np.frombuffer(tl, np.uint8).copy()).to(device)
-            t_blas = torch.from_numpy(bl.view(np.uint8).copy()).to(device)
+            blas = np.zeros((len(meshes), 40), np.float32)
+            boxes = np.zeros((len(meshes), 6), np.float32)
+            tri_off = node_off = 0
+            for i, m in enumerate(meshes):
+                info = rtapi.bvh_build(t_tri.data_ptr() + tri_off * TRI_BYTES, t_ex.data_ptr() + tri_off * 64, len(m),
+                                       t_bvh.data_ptr() + node_off * NODE_BYTES, cap - node_off, tri_off, leaf_max, stream)
+                xf = np.asarray(transforms[i], np.float64).reshape(4, 4)
+                blas[i].view(np.uint32)[0] = node_off                               # bvh_offset
+                blas[i, 1:17] = np.linalg.inv(xf).astype(np.float32).reshape(-1)    # invTransform
+                blas[i, 17:33] = xf.astype(np.float32).reshape(-1)                  # transform
+                b = np.array(list(info.bounds), np.float64)
+                corners = np.array([[b[3 * ((c >> k) & 1) + k] for k in range(3)] + [1.0] for c in range(8)])
+                wc = (corners @ xf.T)[:, :3].astype(np.float32)                     # world-space bounds of the instance (bvh.cpp:295-304)
+                boxes[i, :3], boxes[i, 3:] = wc.min(0), wc.max(0)
+                tri_off += len(m)
+                node_off += info.n_nodes
+            t_bvh = t_bvh[: node_off * NODE_BYTES]
+            t_boxes = torch.from_numpy(boxes).to(device)
+            t_tlas = torch.zeros(max(1, 2 * len(meshes)) * NODE_BYTES, dtype=torch.uint8, device=device)
+            tinfo = rtapi.tlas_build(t_boxes.data_ptr(), len(meshes), t_tlas.data_ptr(), max(1, 2 * len(meshes)), stream)
+            t_tlas = t_tlas[: tinfo.n_nodes * NODE_BYTES]
+            t_blas = torch.from_numpy(blas.view(np.uint8).reshape(-1).copy()).to(device)
             self.t = {"tlas": t_tlas, "blas": t_blas, "bvh": t_bvh, "tri": t_tri, "triEx": t_ex, "mat": t_mat, "tex": t_tex}
             s = rtapi.VxrtScene()
             for k, t in self.t.items():
                 setattr(s, k, t.data_ptr())
-            s.n_tlas_nodes, s.n_blas, s.n_bvh_nodes, s.n_tris = 1, 1, info.n_nodes, n
+            s.n_tlas_nodes, s.n_blas, s.n_bvh_nodes, s.n_tris = tinfo.n_nodes, len(meshes), node_off, n
             s.n_mats = t_mat.numel() // MAT_BYTES
             s.tex_bytes = t_tex.numel()
             self.c = s
-            self.bvh_info = info
+            self.bvh_info, self.tlas_info = info, tinfo
             self.accel = rtapi.accel_build(s, stream)
         return self
 
