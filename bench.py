@@ -222,7 +222,7 @@ def main():
         # default: as large as a batch may be (16), but the K timed steps split into equal groups, at least one per stream
         # (K = 20 -> 2 groups of 10, not 16 + 4)
         n_groups = max(nfl, -(-a.steps // 16))
-        B = max(1, min(16, a.batch if a.batch > 0 else -(-a.steps // n_groups)))
+        B = max(1, min(32, a.batch if a.batch > 0 else -(-a.steps // n_groups)))
         ig = sharding.InterleavedGather(H, W, rank, world, dev, slots=n_frames, collective=not rehearse, batch=B)
         frames = [ig.new_frame_buffer(dev) for _ in range(n_frames)]
     elif world == 1 and a.batch != 1 and nfl > 1:
@@ -231,7 +231,7 @@ def main():
         # frame reach 10 Grays/s: +5..6 % (3..12 frames per set measured alike: profiles/r02_l_frame_batches.txt).
         # --batch 1 = one frame per set of launches.
         n_groups = max(nfl, -(-a.steps // 5))
-        B = max(1, min(16, a.batch if a.batch > 1 else -(-a.steps // n_groups)))
+        B = max(1, min(32, a.batch if a.batch > 1 else -(-a.steps // n_groups)))
         frames = [torch.zeros((B, H, W), dtype=torch.int32, device=dev) for _ in range(n_frames)]
     else:
         frames = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(n_frames)]

@@ -255,7 +255,7 @@ void vxrt_bvh_release_scratch(void);
  * buffer addressed like vxrt_render_interleaved's).  A rank's share of a frame split N ways is small against the machine and takes
  * as long as its slowest tile however small it is; a sequence of frames traced side by side keeps the GPU full, and the assembly
  * of N shares becomes one collective per batch (bench.py --gpus N).  No optional outputs; scenes without reflective instances. */
-#define VXRT_MAX_BATCH 16
+#define VXRT_MAX_BATCH 32
 int vxrt_render_interleaved_batch(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t phase, uint32_t stride, uint32_t n_frames,
                                   const vxrt_shade_params_t* params, int shadow, uint32_t* dst, uint64_t dst_frame_stride,
                                   unsigned long long* rays_traced, void* stream);
