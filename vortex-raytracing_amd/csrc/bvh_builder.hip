@@ -38,6 +38,16 @@ constexpr int BB_MAX_LEVELS = 34;   // launches of the collapse pass; a tree dee
 
 struct Box3 { float lx, ly, lz, hx, hy, hz; };
 
+// One 48-byte record per node of the binary radix tree (internal i in [0, n-1), leaf j as n-1+j): everything the later passes
+// read about a node in three aligned 16-byte loads of ONE cache line (separate child / range / box arrays cost the collapse pass
+// some fifteen scattered lines per item).
+struct __attribute__((aligned(16))) BNode {
+  float lx, ly, lz; uint32_t left;
+  float hx, hy, hz; uint32_t right;
+  uint32_t first, last, pad0, pad1;
+};
+static_assert(sizeof(BNode) == 48, "record size");
+
 __device__ __forceinline__ int f2ord(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7fffffff); }
 
@@ -132,7 +142,7 @@ __device__ __forceinline__ int bb_delta(const uint64_t* __restrict__ k, int n, i
   return a == b ? 64 + __clz(i ^ j) : __clzll((long long)(a ^ b));
 }
 
-__global__ __launch_bounds__(256) void bb_tree_kernel(const uint64_t* __restrict__ keys, int n, uint2* __restrict__ child, uint2* __restrict__ range,
+__global__ __launch_bounds__(256) void bb_tree_kernel(const uint64_t* __restrict__ keys, int n, BNode* __restrict__ rec,
                                                         uint32_t* __restrict__ parent) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
@@ -155,8 +165,8 @@ __global__ __launch_bounds__(256) void bb_tree_kernel(const uint64_t* __restrict
   const int first = min(i, j), last = max(i, j);
   const uint32_t left = first == gamma ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
   const uint32_t right = last == gamma + 1 ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
-  child[i] = make_uint2(left, right);
-  range[i] = make_uint2((uint32_t)first, (uint32_t)last);
+  rec[i].left = left; rec[i].right = right;
+  rec[i].first = (uint32_t)first; rec[i].last = (uint32_t)last;
   parent[left] = (uint32_t)i;
   parent[right] = (uint32_t)i;
   if (i == 0) parent[0] = 0xffffffffu;
@@ -172,25 +182,25 @@ __device__ __forceinline__ float coherent_load(const float* p) { return __hip_at
 __device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(256) void bb_fit_kernel(const float* __restrict__ tri, const uint32_t* __restrict__ vals, uint32_t n,
-                                                       const uint2* __restrict__ child, const uint32_t* __restrict__ parent,
-                                                       float* __restrict__ box /* 6 floats per node id */, uint32_t* __restrict__ flag, bool boxes) {
+                                                       const uint32_t* __restrict__ parent, BNode* __restrict__ rec, uint32_t* __restrict__ flag, bool boxes) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   Box3 b = prim_box(tri, vals[j], boxes);
   uint32_t id = n - 1 + j;
+  rec[id].left = rec[id].right = 0xffffffffu; rec[id].first = rec[id].last = j;   // (a leaf: read back only by later launches)
   for (;;) {
-    float* o = box + (size_t)id * 6;
-    coherent_store(o + 0, b.lx); coherent_store(o + 1, b.ly); coherent_store(o + 2, b.lz);
-    coherent_store(o + 3, b.hx); coherent_store(o + 4, b.hy); coherent_store(o + 5, b.hz);
+    BNode* o = rec + id;
+    coherent_store(&o->lx, b.lx); coherent_store(&o->ly, b.ly); coherent_store(&o->lz, b.lz);
+    coherent_store(&o->hx, b.hx); coherent_store(&o->hy, b.hy); coherent_store(&o->hz, b.hz);
     if (n == 1) return;
     const uint32_t p = id == 0 ? 0xffffffffu : parent[id];
     if (p == 0xffffffffu) return;                     // the root's box is written
     __builtin_amdgcn_s_waitcnt(0);                    // this wavefront's stores have completed
     if (__hip_atomic_fetch_add(flag + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;   // the sibling subtree is not finished: its last thread continues
-    const uint2 c = child[p];
-    const float* s = box + (size_t)(c.x == id ? c.y : c.x) * 6;
-    b.lx = fminf(b.lx, coherent_load(s + 0)); b.ly = fminf(b.ly, coherent_load(s + 1)); b.lz = fminf(b.lz, coherent_load(s + 2));
-    b.hx = fmaxf(b.hx, coherent_load(s + 3)); b.hy = fmaxf(b.hy, coherent_load(s + 4)); b.hz = fmaxf(b.hz, coherent_load(s + 5));
+    const uint32_t l = rec[p].left, r = rec[p].right;   // (written by the previous launch)
+    const BNode* s = rec + (l == id ? r : l);
+    b.lx = fminf(b.lx, coherent_load(&s->lx)); b.ly = fminf(b.ly, coherent_load(&s->ly)); b.lz = fminf(b.lz, coherent_load(&s->lz));
+    b.hx = fmaxf(b.hx, coherent_load(&s->hx)); b.hy = fmaxf(b.hy, coherent_load(&s->hy)); b.hz = fmaxf(b.hz, coherent_load(&s->hz));
     id = p;
   }
 }
@@ -223,7 +233,7 @@ __device__ __forceinline__ bool bb_quant_axis(float origin, int e, float cmin, f
 }
 
 struct CollapseArgs {
-  const uint2* child; const uint2* range; const float* box;
+  const BNode* rec;
   uint32_t n, leaf_max, tri_offset, node_capacity;
   uint32_t* nodes;          // 13 dwords per node
   uint32_t* counters;       // [0] nodes allocated, [1] leaves, [2] largest leaf, [3] deepest level, [4] error flags, [8 + L] items of level L
@@ -232,10 +242,15 @@ struct CollapseArgs {
   const uint32_t* prim_ids;   // TLAS build: sorted position -> instance (blasIdx); nullptr = BLAS build
 };
 
-__device__ __forceinline__ Box3 bb_load_box(const float* box, uint32_t id) {
-  const float* p = box + (size_t)id * 6;
-  Box3 b; b.lx = p[0]; b.ly = p[1]; b.lz = p[2]; b.hx = p[3]; b.hy = p[4]; b.hz = p[5];
-  return b;
+struct BRec { Box3 box; uint32_t left, right, first, last; };
+__device__ __forceinline__ BRec bb_load_rec(const BNode* __restrict__ rec, uint32_t id) {
+  const float4* p = (const float4*)(rec + id);
+  const float4 a = p[0], b = p[1], c = p[2];
+  BRec r;
+  r.box.lx = a.x; r.box.ly = a.y; r.box.lz = a.z; r.left = __float_as_uint(a.w);
+  r.box.hx = b.x; r.box.hy = b.y; r.box.hz = b.z; r.right = __float_as_uint(b.w);
+  r.first = __float_as_uint(c.x); r.last = __float_as_uint(c.y);
+  return r;
 }
 __device__ __forceinline__ float bb_area(const Box3& b) {
   const float x = b.hx - b.lx, y = b.hy - b.ly, z = b.hz - b.lz;
@@ -252,34 +267,43 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
     const bool act = it < n_items;
     const uint2 item = act ? A.in[it] : make_uint2(A.n - 1, 0u);
     const uint32_t b = item.x, out = item.y;
-    const bool is_leaf_id = b >= A.n - 1;
-    const uint2 rg = is_leaf_id ? make_uint2(b - (A.n - 1), b - (A.n - 1)) : A.range[b];
+    const BRec me = bb_load_rec(A.rec, b);
+    const uint2 rg = make_uint2(me.first, me.last);
     const uint32_t count = rg.y - rg.x + 1;
-    const Box3 bx = bb_load_box(A.box, b);
+    const Box3 bx = me.box;
     const bool leaf = count <= A.leaf_max;
+    // (all arrays below are indexed with compile-time constants only -- unrolled loops, selects on k == pick -- so that they
+    // live in registers: with dynamic indices they went to scratch and a level took as long as ~250 dependent scratch accesses)
     uint32_t c[4] = {0, 0, 0, 0};
     uint32_t nc = 0;
-    Box3 cb[4];
-    cb[0] = cb[1] = cb[2] = cb[3] = bx;
+    BRec cr[4];
+    cr[0] = cr[1] = cr[2] = cr[3] = me;
     if (act && !leaf) {
-      const uint2 c0 = A.child[b];
-      c[0] = c0.x; c[1] = c0.y;
+      c[0] = me.left; c[1] = me.right;
       nc = 2;
-      cb[0] = bb_load_box(A.box, c[0]); cb[1] = bb_load_box(A.box, c[1]);
+      cr[0] = bb_load_rec(A.rec, c[0]); cr[1] = bb_load_rec(A.rec, c[1]);
+#pragma unroll
       for (int round = 0; round < 2; ++round) {
         int pick = -1; float best = -1.0f;
-        for (uint32_t k = 0; k < nc; ++k) {
-          if (c[k] >= A.n - 1) continue;
-          const uint2 r = A.range[c[k]];
-          if (r.y - r.x + 1 <= A.leaf_max) continue;      // becomes a leaf as it is
-          const float ar = bb_area(cb[k]);
-          if (ar > best) { best = ar; pick = (int)k; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if ((uint32_t)k < nc && cr[k].last - cr[k].first + 1 > A.leaf_max) {   // (else it becomes a leaf as it is; a single triangle always does)
+            const float ar = bb_area(cr[k].box);
+            if (ar > best) { best = ar; pick = k; }
+          }
         }
-        if (pick < 0) break;
-        const uint2 g = A.child[c[pick]];
-        c[pick] = g.x; cb[pick] = bb_load_box(A.box, g.x);
-        c[nc] = g.y; cb[nc] = bb_load_box(A.box, g.y);
-        ++nc;
+        if (pick >= 0) {
+          uint32_t gl = 0, gr = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (k == pick) { gl = cr[k].left; gr = cr[k].right; }
+          const BRec L = bb_load_rec(A.rec, gl), R = bb_load_rec(A.rec, gr);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (k == pick) { c[k] = gl; cr[k] = L; }
+            if ((uint32_t)k == nc) { c[k] = gr; cr[k] = R; }
+          }
+          ++nc;
+        }
       }
     }
     // wavefront prefix sum of the child counts -> node slots and next-level queue positions
@@ -287,10 +311,21 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += t; }
     const uint32_t total = __shfl(incl, 63);
-    uint32_t node_base = 0, q_base = 0;
-    if (lane == 0 && total != 0u) { node_base = atomicAdd(A.counters + 0, total); q_base = atomicAdd(A.counters + 8 + A.level + 1, total); }
-    node_base = __shfl(node_base, 0); q_base = __shfl(q_base, 0);
-    const uint32_t first = node_base + incl - nc, pos = q_base + incl - nc;
+    // ... and one pair of atomics per WORKGROUP (same-address atomics from every wavefront of a level are what the level waits for)
+    __shared__ uint32_t s_tot[4], s_base[2];
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane == 0) s_tot[wv] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t bt = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+      s_base[0] = bt ? atomicAdd(A.counters + 0, bt) : 0u;
+      s_base[1] = bt ? atomicAdd(A.counters + 8 + A.level + 1, bt) : 0u;
+    }
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t k = 0; k < wv; ++k) woff += s_tot[k];
+    const uint32_t first = s_base[0] + woff + incl - nc, pos = s_base[1] + woff + incl - nc;
+    __syncthreads();   // (s_tot / s_base are rewritten by the next iteration)
     const unsigned long long leafm = __ballot(act && leaf);
     uint32_t lmax = act && leaf ? count : 0u;
 #pragma unroll
@@ -304,7 +339,7 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
     uint32_t w[13];
     w[0] = __float_as_uint(bx.lx); w[1] = __float_as_uint(bx.ly); w[2] = __float_as_uint(bx.lz);
     int e[3] = {bb_pick_exp(bx.hx - bx.lx), bb_pick_exp(bx.hy - bx.ly), bb_pick_exp(bx.hz - bx.lz)};
-    uint8_t ch[4][7] = {};
+    uint32_t ql[4][3] = {}, qh[4][3] = {};
     if (leaf) {
       if (A.prim_ids) { w[4] = 0; w[5] = A.prim_ids[rg.x]; }   // TLAS leaf (bvh.cpp:325-328): leafData = blasIdx
       else { w[4] = rg.x + A.tri_offset; w[5] = count; }       // bvh.cpp:260: already offset by the mesh's first triangle
@@ -315,27 +350,38 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
       for (int a = 0; a < 3; ++a) {
         for (;;) {
           bool ok = true;
-          for (uint32_t k = 0; k < nc && ok; ++k) {
-            const float cmin = a == 0 ? cb[k].lx : (a == 1 ? cb[k].ly : cb[k].lz);
-            const float cmax = a == 0 ? cb[k].hx : (a == 1 ? cb[k].hy : cb[k].hz);
-            uint32_t ql = 0, qh = 0;
-            ok = bb_quant_axis(org[a], e[a], cmin, cmax, ql, qh);
-            if (ok) { ch[k][1 + a] = (uint8_t)ql; ch[k][4 + a] = (uint8_t)qh; }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if ((uint32_t)k < nc && ok) {
+              const float cmin = a == 0 ? cr[k].box.lx : (a == 1 ? cr[k].box.ly : cr[k].box.lz);
+              const float cmax = a == 0 ? cr[k].box.hx : (a == 1 ? cr[k].box.hy : cr[k].box.hz);
+              ok = bb_quant_axis(org[a], e[a], cmin, cmax, ql[k][a], qh[k][a]);
+            }
           }
           if (ok) break;
           if (e[a] >= 126) { atomicOr(A.counters + 4, 2u); break; }
           ++e[a];
         }
       }
-      for (uint32_t k = 0; k < nc; ++k) ch[k][0] = 1;
       w[4] = first;     // relative to this BLAS's first node (rt_traversal.cpp:92,119); TLAS: to its node 0
       w[5] = A.prim_ids ? 0xffffffffu : 0u;   // internal TLAS nodes carry UINT32_MAX (bvh.cpp:417)
-      for (uint32_t k = 0; k < nc; ++k) A.out[pos + k] = make_uint2(c[k], first + k);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if ((uint32_t)k < nc) A.out[pos + k] = make_uint2(c[k], first + k);
     }
     w[3] = (uint32_t)(uint8_t)(int8_t)e[0] | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16) | (A.prim_ids ? 1u << 24 : 0u);   // imask: 1 = TLAS node
-    const uint8_t* cbytes = &ch[0][0];
+    // children: 4 x { meta, lo x y z, hi x y z } = 28 bytes from dword 6 on
+    uint64_t cbits[4];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) w[6 + k] = (uint32_t)cbytes[4 * k] | ((uint32_t)cbytes[4 * k + 1] << 8) | ((uint32_t)cbytes[4 * k + 2] << 16) | ((uint32_t)cbytes[4 * k + 3] << 24);
+    for (int k = 0; k < 4; ++k) {
+      const bool on = !leaf && (uint32_t)k < nc;
+      cbits[k] = on ? (1ull | ((uint64_t)ql[k][0] << 8) | ((uint64_t)ql[k][1] << 16) | ((uint64_t)ql[k][2] << 24) |
+                       ((uint64_t)qh[k][0] << 32) | ((uint64_t)qh[k][1] << 40) | ((uint64_t)qh[k][2] << 48)) : 0ull;   // 7 bytes
+    }
+    // pack the four 7-byte groups back to back
+    const unsigned __int128 lo128 = (unsigned __int128)cbits[0] | ((unsigned __int128)cbits[1] << 56) | ((unsigned __int128)cbits[2] << 112);
+    const unsigned __int128 hi128 = ((unsigned __int128)cbits[2] >> 16) | ((unsigned __int128)cbits[3] << 40);
+    w[6] = (uint32_t)lo128; w[7] = (uint32_t)(lo128 >> 32); w[8] = (uint32_t)(lo128 >> 64); w[9] = (uint32_t)(lo128 >> 96);
+    w[10] = (uint32_t)hi128; w[11] = (uint32_t)(hi128 >> 32); w[12] = (uint32_t)(hi128 >> 64);
     uint32_t* o = A.nodes + (size_t)out * RT_NODE_DWORDS;
 #pragma unroll
     for (int k = 0; k < RT_NODE_DWORDS; ++k) o[k] = w[k];
@@ -383,7 +429,7 @@ bool arena_reserve(size_t bytes) {
 
 static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tri_offset, uint32_t leaf_max,
                         void* d_nodes, uint32_t node_capacity, vxrt_bvh_info_t* info, void* stream, bool boxes) {
-  if (!d_tri || !d_nodes || n_tris == 0 || n_tris > 0x3fffffffu) return -1;
+  if (!d_tri || !d_nodes || n_tris == 0 || n_tris > 0x0fffffffu) return -1;   // (the radix-tree search probes positions up to 3 n in 32-bit arithmetic)
   if (leaf_max == 0) leaf_max = 2;
   if (leaf_max > 15) leaf_max = 15;
   if (boxes) { leaf_max = 1; d_triEx = nullptr; }
@@ -394,7 +440,7 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   const uint32_t n_counters = 8 + BB_MAX_LEVELS + 2;
   size_t tmp_bytes = 0;
   if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
-  const size_t per_tri = 2 * 8 + 2 * 4 + 2 * 8 + 2 * 4 + 4 + 12 * 4 + 2 * 8 + (d_triEx ? 64 : 36);
+  const size_t per_tri = 2 * 8 + 2 * 4 + 2 * 48 + 2 * 4 + 4 + 2 * 8 + (d_triEx ? 64 : 36);
   if (!arena_reserve((size_t)n * per_tri + tmp_bytes + 64 * 1024)) return -1;
   Arena& sc = g_arena;
   int* cb = sc.get<int>(8);
@@ -403,16 +449,14 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   uint64_t* keys1 = sc.get<uint64_t>(n);
   uint32_t* vals0 = sc.get<uint32_t>(n);
   uint32_t* vals1 = sc.get<uint32_t>(n);
-  uint2* child = sc.get<uint2>(n);
-  uint2* range = sc.get<uint2>(n);
+  BNode* rec = sc.get<BNode>(2 * (size_t)n);
   uint32_t* parent = sc.get<uint32_t>(2 * (size_t)n);
   uint32_t* flag = sc.get<uint32_t>(n);
-  float* box = sc.get<float>(12 * (size_t)n);
   uint2* q0 = sc.get<uint2>(n);
   uint2* q1 = sc.get<uint2>(n);
   uint32_t* gather = sc.get<uint32_t>((size_t)n * (d_triEx ? 16 : 9));
   void* tmp = sc.get<uint8_t>(tmp_bytes ? tmp_bytes : 16);
-  if (!cb || !counters || !keys0 || !keys1 || !vals0 || !vals1 || !child || !range || !parent || !flag || !box || !q0 || !q1 || !gather || !tmp) return -1;
+  if (!cb || !counters || !keys0 || !keys1 || !vals0 || !vals1 || !rec || !parent || !flag || !q0 || !q1 || !gather || !tmp) return -1;
   const uint32_t blocks = (n + 255u) / 256u;
   const uint32_t wide = blocks < 4096u ? blocks : 4096u;
 
@@ -421,11 +465,11 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   hipLaunchKernelGGL(bb_bounds_kernel, dim3(wide < 512u ? wide : 512u), dim3(256), 0, s, (const float*)d_tri, n, cb, boxes);
   hipLaunchKernelGGL(bb_morton_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, n, cb, keys0, vals0, boxes);
   if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
-  if (n > 1) hipLaunchKernelGGL(bb_tree_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, s, keys1, (int)n, child, range, parent);
-  hipLaunchKernelGGL(bb_fit_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, vals1, n, child, parent, box, flag, boxes);
+  if (n > 1) hipLaunchKernelGGL(bb_tree_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, s, keys1, (int)n, rec, parent);
+  hipLaunchKernelGGL(bb_fit_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, vals1, n, parent, rec, flag, boxes);
 
   CollapseArgs A;
-  A.child = child; A.range = range; A.box = box; A.n = n; A.leaf_max = leaf_max; A.tri_offset = tri_offset; A.node_capacity = node_capacity;
+  A.rec = rec; A.n = n; A.leaf_max = leaf_max; A.tri_offset = tri_offset; A.node_capacity = node_capacity;
   A.nodes = (uint32_t*)d_nodes; A.counters = counters; A.prim_ids = boxes ? vals1 : nullptr;
   for (uint32_t L = 0; L < (uint32_t)BB_MAX_LEVELS; ++L) {
     A.in = (L & 1u) ? q1 : q0; A.out = (L & 1u) ? q0 : q1; A.level = L;
@@ -445,14 +489,15 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
     if (hipMemcpyAsync(d_triEx, gather, (size_t)n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
   }
   std::vector<uint32_t> hc(n_counters);
-  float hb[6];
+  BNode hroot;
   if (hipMemcpyAsync(hc.data(), counters, n_counters * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-  if (hipMemcpyAsync(hb, box + (n > 1 ? 0 : 0), sizeof hb, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipMemcpyAsync(&hroot, rec, sizeof hroot, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;   // record 0: the root (or the only leaf)
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   if (hipGetLastError() != hipSuccess) return -1;
   if (info) {
     info->n_nodes = hc[0]; info->n_leaves = hc[1]; info->max_leaf = hc[2]; info->max_depth = hc[3];
-    for (int i = 0; i < 6; ++i) info->bounds[i] = hb[i];
+    info->bounds[0] = hroot.lx; info->bounds[1] = hroot.ly; info->bounds[2] = hroot.lz;
+    info->bounds[3] = hroot.hx; info->bounds[4] = hroot.hy; info->bounds[5] = hroot.hz;
   }
   if (hc[4] != 0u) return -1;                                  // capacity or exponent range exhausted
   if (hc[8 + BB_MAX_LEVELS] != 0u) return -2;                  // deeper than the collapse pass goes
