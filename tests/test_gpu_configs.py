@@ -262,3 +262,35 @@ def test_batch_of_frames_equals_the_frames_one_by_one(vrt, po, gpu_device, atriu
     opp = po.shade_params(light_pos=(300.0 - 80.0, 480.0 - 30.0, 60.0 + 60.0))
     want, _, _, _ = po.render_ex(sc, w, h, opp, 1)
     assert np.array_equal(buf[2].cpu().numpy().view(np.uint32)[rows], want[rows])
+
+
+@pytest.mark.parametrize("w,h,rank,world,n", [(173, 99, 0, 2, 3), (64, 40, 4, 5, 2), (200, 120, 0, 1, 7), (96, 8, 0, 3, 32)])
+def test_batches_of_ragged_frames(vrt, po, gpu_device, w, h, rank, world, n):
+    """Widths and heights that are no multiples of the tile size, more ranks than some frames have tile rows for, one rank
+    (whole frames), the largest batch: every frame of the batch equals the same frame rendered alone."""
+    import torch
+    sc = vrt.scene.procedural("blob", 3, 0, 2)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    vrt.rtapi.accel_frames_in_flight(ds.accel, 2)
+    ig = vrt.sharding.InterleavedGather(h, w, rank, world, gpu_device, slots=1, collective=False, batch=n)
+    plist = []
+    for f in range(n):
+        p = vrt.rtapi.default_shade_params()
+        p.light_pos[:] = (100.0 + 13.0 * f, 200.0, -60.0 + 9.0 * f)
+        p.background[:] = (0.1 + 0.02 * f, 0.35, 0.25)
+        plist.append(p)
+    s = torch.cuda.current_stream().cuda_stream
+    buf = ig.new_frame_buffer(gpu_device).reshape(n, ig.padded_height, w)
+    buf.fill_(0x5A5A5A5A)
+    vrt.rtapi.render_interleaved_batch(ds.accel, w, h, rank, world, plist, buf.data_ptr(), ig.frame_stride, 1, None, s)
+    torch.cuda.synchronize()
+    assert vrt.rtapi.status(s) == 0
+    for f in range(n):
+        one = torch.full((ig.padded_height, w), 0x5A5A5A5A, dtype=torch.int32, device=gpu_device)
+        vrt.rtapi.render_interleaved(ds.accel, w, h, rank, world, plist[f], one.data_ptr(), 1, None, None, None, s)
+        torch.cuda.synchronize()
+        assert torch.equal(buf[f], one), "frame %d" % f
+    if world == 1:
+        want, _, _, _ = po.render_ex(sc, w, h, po.shade_params(light_pos=(100.0 + 13.0 * 3, 200.0, -60.0 + 27.0), background=(0.16, 0.35, 0.25)), 1)
+        assert np.array_equal(buf[3].cpu().numpy().view(np.uint32)[:h], want)
+    ds.close()
