@@ -450,6 +450,17 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 // launch, of the EXACT launch over the deferred list and of the a-priori EXACT launch
 #define CTL_QUEUE_DWORDS (QUEUE_SHARDS * QUEUE_STRIDE)
 #define CTL_DWORDS (32u + 3u * CTL_QUEUE_DWORDS)
+// Frames (camera tiles + their occlusion rays): 7 wavefronts per SIMD (72 VGPRs, 6 stack levels in LDS).  With frames traced in
+// batches -- many tiles per wavefront, so ramp and tail of a launch no longer decide -- occupancy pays: 7 / 8 wavefronts are +5.3 /
+// +5.6 % on the headline frame (one frame per launch: +-1 %, measured in round 2), 8 loses 3 % on serial frames, 7 gains 2 %
+// there.  Ray buffers (JOB_TRACE) keep 6 wavefronts and 8 LDS levels: deep incoherent traversals (hairball AO) lose 2 % to the
+// shorter LDS stack at 7 (profiles/r02_o_occupancy.txt).
+#ifndef RT_WAVES_RENDER
+#define RT_WAVES_RENDER 7
+#endif
+#ifndef RT_LDS_STACK_RENDER
+#define RT_LDS_STACK_RENDER 6
+#endif
 #ifndef LDS_STACK
 #define LDS_STACK 8         // stack levels kept in LDS per lane (4 KiB per wavefront); deeper ones go to scratch
 #endif
@@ -571,7 +582,9 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 // STATS: 0 = the timed kernel; 1 = counting build in the reference's order (ordered occlusion, no leaf helpers: its fetch counts equal
 // the canonical restatement's); 2 = counting build of the traversal the timed kernel actually performs (unordered occlusion, helpers)
 template <int JOB, int STATS, bool LDEXP, bool EXACT>
-__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_PER_EU) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JOB_TRACE ? RT_WAVES_PER_EU : RT_WAVES_RENDER)) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+  // stack levels in LDS: what the instantiation's occupancy leaves room for (160 KB per CU)
+  constexpr int LSTK = (EXACT || JOB == JOB_TRACE) ? LDS_STACK : RT_LDS_STACK_RENDER;
   constexpr int WG_WAVES = EXACT ? 4 : RT_WG_WAVES;
   constexpr bool USE_TOP = RT_TOP_NODES > 0 && !EXACT && !LDEXP;   // (the ldexp decode reads exponents from the reference node by index)
   // V2 node step: only where every slab value is finite (bounded scene -- checked by the accel build, which selects the LDEXP
@@ -600,7 +613,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   const uint32_t n_jobs = EXACT ? min(*A.defer_count, A.defer_cap) : (A.total_dev ? min(*A.total_dev, A.total) : A.total);
   const uint32_t per_shard = (EXACT || A.total_dev) ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
 
-  __shared__ uint2 s_stk[WG_WAVES][LDS_STACK][64];   // stack levels below the register top, 8 B entries, conflict-free rows
+  __shared__ uint2 s_stk[WG_WAVES][LSTK][64];   // stack levels below the register top, 8 B entries, conflict-free rows
   // 0-2 active dir, 3-4 hit bx/by (bz = 1 - bx - by is re-derived when the record is written), 5 distance of the pixel's
   // primary hit while its occlusion ray is traced, 6 hit blasIdx, 7 hit triIdx, 8 blasIdx
   __shared__ uint32_t s_ctx[WG_WAVES][9][64];
@@ -626,7 +639,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   // V2 keeps the stack as two planes in the same LDS block (descriptors, then path maxima): rank-addressed scatter writes need no
   // register pairs, and there is no register-cached top to shuffle
   uint32_t* const stk_d = (uint32_t*)&s_stk[threadIdx.x >> 6][0][0] + lane;
-  float* const stk_m = (float*)stk_d + LDS_STACK * 64;
+  float* const stk_m = (float*)stk_d + LSTK * 64;
   uint32_t ovf_d[RT_STACK_ENTRIES];
   float ovf_m[RT_STACK_ENTRIES];
   // wave-uniform job-queue state
@@ -735,19 +748,19 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   volatile uint32_t* const vovf_d = ovf_d;
   volatile float* const vovf_m = ovf_m;
   auto stk_write = [&](int slot, uint32_t d, float m) {   // V2, general form
-    if (slot < LDS_STACK) { stk_d[slot * 64] = d; stk_m[slot * 64] = m; }
-    else { vovf_d[slot - LDS_STACK] = d; vovf_m[slot - LDS_STACK] = m; }
+    if (slot < LSTK) { stk_d[slot * 64] = d; stk_m[slot * 64] = m; }
+    else { vovf_d[slot - LSTK] = d; vovf_m[slot - LSTK] = m; }
   };
   auto push = [&](uint32_t d, float m) {
     if (V2) { stk_write(sp, d, m); ++sp; return; }
     if (tos_d != DESC_DONE) {
-      if (sp < LDS_STACK) lstk[sp * 64] = make_uint2(tos_d, __float_as_uint(tos_m));
-      else { ovf_d[sp - LDS_STACK] = tos_d; ovf_m[sp - LDS_STACK] = tos_m; }
+      if (sp < LSTK) lstk[sp * 64] = make_uint2(tos_d, __float_as_uint(tos_m));
+      else { ovf_d[sp - LSTK] = tos_d; ovf_m[sp - LSTK] = tos_m; }
       ++sp;
     }
     tos_d = d; tos_m = m;
   };
-  auto push_lds = [&](uint32_t d, float m) {   // caller: sp < LDS_STACK for this lane
+  auto push_lds = [&](uint32_t d, float m) {   // caller: sp < LSTK for this lane
     if (tos_d != DESC_DONE) { lstk[sp * 64] = make_uint2(tos_d, __float_as_uint(tos_m)); ++sp; }
     tos_d = d; tos_m = m;
   };
@@ -756,7 +769,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
   auto pop_next = [&]() {
     cur = DESC_DONE;
     if (V2) {
-      if (!__any(sp > LDS_STACK)) {   // wave-uniform: every entry any lane can pop is in LDS (the common case by far)
+      if (!__any(sp > LSTK)) {   // wave-uniform: every entry any lane can pop is in LDS (the common case by far)
         while (sp > 0) {
           --sp;
           const uint32_t d = stk_d[sp * 64];
@@ -768,8 +781,8 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
       while (sp > 0) {
         --sp;
         uint32_t d; float m;
-        if (sp < LDS_STACK) { d = stk_d[sp * 64]; m = stk_m[sp * 64]; }
-        else { d = vovf_d[sp - LDS_STACK]; m = vovf_m[sp - LDS_STACK]; }
+        if (sp < LSTK) { d = stk_d[sp * 64]; m = stk_m[sp * 64]; }
+        else { d = vovf_d[sp - LSTK]; m = vovf_m[sp - LSTK]; }
         if (m < hitd) { cur = d; path_m = m; break; }
       }
       return;
@@ -779,8 +792,8 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
       const float m = tos_m;
       if (sp > 0) {
         --sp;
-        if (sp < LDS_STACK) { const uint2 e = lstk[sp * 64]; tos_d = e.x; tos_m = __uint_as_float(e.y); }
-        else { tos_d = ovf_d[sp - LDS_STACK]; tos_m = ovf_m[sp - LDS_STACK]; }
+        if (sp < LSTK) { const uint2 e = lstk[sp * 64]; tos_d = e.x; tos_m = __uint_as_float(e.y); }
+        else { tos_d = ovf_d[sp - LSTK]; tos_m = ovf_m[sp - LSTK]; }
       } else {
         tos_d = DESC_DONE;
       }
@@ -953,7 +966,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
             r2 = 1 - m02 - m12 + m23;
             r3 = 0 - m03 - m13 - m23;
           }
-          if (!__any(sp + 4 > LDS_STACK)) {
+          if (!__any(sp + 4 > LSTK)) {
             // common case, wave-uniform: four free LDS slots above every lane's stack.  ALL four children are written, without
             // predication, to the distinct slots sp + ((n - 1 - r_k) & 3): a child to visit (r_k < n) lands at sp + (n - 1 - r_k), far
             // ones first and the nearest on top; the others (r_k >= n) land above the new top, where nothing is live
@@ -974,7 +987,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
             }
           } else {
             if (n != 0) {
-              if (sp + n > LDS_STACK + RT_STACK_ENTRIES) atomicOr(A.status, STATUS_STACK_OVERFLOW);
+              if (sp + n > LSTK + RT_STACK_ENTRIES) atomicOr(A.status, STATUS_STACK_OVERFLOW);
               else {
                 const int t = sp + n - 1;
                 if (ok[0]) stk_write(t - r0, desc[0], fmaxf(path_m, D[0]));
@@ -997,7 +1010,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
           const bool v0 = c[0].d < __builtin_inff(), v1 = c[1].d < __builtin_inff(), v2 = c[2].d < __builtin_inff(), v3 = c[3].d < __builtin_inff();
           if (v0 || v1 || v2 || v3) {
             bool more = true;
-            if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
+            if (sp + 4 > LSTK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
             cur = v0 ? c[0].desc : (v1 ? c[1].desc : (v2 ? c[2].desc : c[3].desc));
             if (more) {
               if (v1 && v0) push(c[1].desc, c[1].d);
@@ -1011,7 +1024,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
           order_children(c);   // valid children first (d < inf), nearest in c[0]
           // (path_m and the candidates' distances are never NaN -- a filtered child carries +inf -- so the maxima need no
           // canonicalising v_max x, x in front of them)
-          if (RT_PUSH_FAST && !V2 && !__any(sp + 3 > LDS_STACK)) {
+          if (RT_PUSH_FAST && !V2 && !__any(sp + 3 > LSTK)) {
             // wave-uniform common case: the three possible pushes of every lane stay inside the LDS part of its stack, so a push
             // is "spill the register top to its LDS slot, take the new top" without the LDS / scratch split and its exec juggling
             if (c[0].d < __builtin_inff()) {
@@ -1026,7 +1039,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : RT_WAVES_P
           } else
           if (c[0].d < __builtin_inff()) {
             bool more = true;
-            if (sp + 4 > LDS_STACK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
+            if (sp + 4 > LSTK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
             // far first so that the nearest pending sibling is on top (:98-103)
             if (more && c[3].d < __builtin_inff()) push(c[3].desc, vmax_nonan(path_m, c[3].d));
             if (more && c[2].d < __builtin_inff()) push(c[2].desc, vmax_nonan(path_m, c[2].d));
