@@ -453,8 +453,14 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 // Frames (camera tiles + their occlusion rays): 7 wavefronts per SIMD (72 VGPRs, 6 stack levels in LDS).  With frames traced in
 // batches -- many tiles per wavefront, so ramp and tail of a launch no longer decide -- occupancy pays: 7 / 8 wavefronts are +5.3 /
 // +5.6 % on the headline frame (one frame per launch: +-1 %, measured in round 2), 8 loses 3 % on serial frames, 7 gains 2 %
-// there.  Ray buffers (JOB_TRACE) keep 6 wavefronts and 8 LDS levels: deep incoherent traversals (hairball AO) lose 2 % to the
-// shorter LDS stack at 7 (profiles/r02_o_occupancy.txt).
+// there.  Ray buffers (JOB_TRACE): 7 wavefronts with 7 LDS levels -- they need one context slot less, which pays for the seventh
+// level -- +2.5 % on random rays, hairball AO and diffuse bounce unchanged (with 6 levels AO lost 2 %): profiles/r02_o_occupancy.txt.
+#ifndef RT_WAVES_TRACE
+#define RT_WAVES_TRACE 7
+#endif
+#ifndef RT_LDS_STACK_TRACE
+#define RT_LDS_STACK_TRACE 7
+#endif
 #ifndef RT_WAVES_RENDER
 #define RT_WAVES_RENDER 7
 #endif
@@ -582,9 +588,9 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 // STATS: 0 = the timed kernel; 1 = counting build in the reference's order (ordered occlusion, no leaf helpers: its fetch counts equal
 // the canonical restatement's); 2 = counting build of the traversal the timed kernel actually performs (unordered occlusion, helpers)
 template <int JOB, int STATS, bool LDEXP, bool EXACT>
-__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JOB_TRACE ? RT_WAVES_PER_EU : RT_WAVES_RENDER)) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JOB_TRACE ? RT_WAVES_TRACE : RT_WAVES_RENDER)) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
   // stack levels in LDS: what the instantiation's occupancy leaves room for (160 KB per CU)
-  constexpr int LSTK = (EXACT || JOB == JOB_TRACE) ? LDS_STACK : RT_LDS_STACK_RENDER;
+  constexpr int LSTK = EXACT ? LDS_STACK : (JOB == JOB_TRACE ? RT_LDS_STACK_TRACE : RT_LDS_STACK_RENDER);
   constexpr int WG_WAVES = EXACT ? 4 : RT_WG_WAVES;
   constexpr bool USE_TOP = RT_TOP_NODES > 0 && !EXACT && !LDEXP;   // (the ldexp decode reads exponents from the reference node by index)
   // V2 node step: only where every slab value is finite (bounded scene -- checked by the accel build, which selects the LDEXP
@@ -616,10 +622,12 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   __shared__ uint2 s_stk[WG_WAVES][LSTK][64];   // stack levels below the register top, 8 B entries, conflict-free rows
   // 0-2 active dir, 3-4 hit bx/by (bz = 1 - bx - by is re-derived when the record is written), 5 distance of the pixel's
   // primary hit while its occlusion ray is traced, 6 hit blasIdx, 7 hit triIdx, 8 blasIdx
-  __shared__ uint32_t s_ctx[WG_WAVES][9][64];
+  // (ray buffers have no "primary hit kept while the occlusion ray runs": slot 5 is dropped there, 8 slots + 7 stack levels fit 7 workgroups per CU)
+  constexpr int NCTX = (!EXACT && JOB == JOB_TRACE) ? 8 : 9;
+  __shared__ uint32_t s_ctx[WG_WAVES][NCTX][64];
   uint2* const lstk = &s_stk[threadIdx.x >> 6][0][lane];
   uint32_t* const ctx = &s_ctx[threadIdx.x >> 6][0][lane];
-#define CTX(i) ctx[(i) * 64]
+#define CTX(i) ctx[((NCTX == 8 && (i) > 5) ? (i) - 1 : (i)) * 64]
   // top of the tree staged in LDS (north_star: "BVH nodes staged through LDS"): the first levels are what every ray of every
   // tile walks, and a ds_read_b128 does not queue behind the CU's vector-memory pipeline
   __shared__ uint4 s_top[USE_TOP ? 4 : 1][USE_TOP ? RT_TOP_NODES : 1];
