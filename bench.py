@@ -241,7 +241,10 @@ def main():
     def launch(buf, count_ptr=None, st=None, k=1):
         sp = (st or stream).cuda_stream
         if B > 1 and k > 0 and count_ptr is None and st is not None:
-            rtapi.render_interleaved_batch(ds.accel, W, H, rank, world, [params] * k, buf.data_ptr(), frame_stride, shadow, None, sp)
+            if world == 1:
+                rtapi.render_batch(ds.accel, W, H, [params] * k, buf.data_ptr(), frame_stride, shadow, None, sp)
+            else:
+                rtapi.render_interleaved_batch(ds.accel, W, H, rank, world, [params] * k, buf.data_ptr(), frame_stride, shadow, None, sp)
         elif world > 1 and a.shard == "tilerows":
             rtapi.render_interleaved(ds.accel, W, H, rank, world, params, buf.data_ptr(), shadow, None, None, count_ptr, sp)
         else:
@@ -389,7 +392,7 @@ def main():
 
     if rank == 0:
         if world == 1:
-            par = "1 GPU: whole frame"
+            par = "1 GPU: whole frames, %d per set of launches (vxrt_render_batch), %d sets in flight" % (B, nfl) if B > 1 else "1 GPU: whole frame"
         elif a.shard == "tilerows":
             par = "one frame split by interleaved 8-row tile rows (rank r: rows r, r+%d, ... of %d tile rows) x%d GPUs, %d frames per set of launches, one RCCL gather of the shares to rank 0 per set" % (world, (H + 7) // 8, world, B)
         else:

@@ -282,7 +282,10 @@ def test_batches_of_ragged_frames(vrt, po, gpu_device, w, h, rank, world, n):
     s = torch.cuda.current_stream().cuda_stream
     buf = ig.new_frame_buffer(gpu_device).reshape(n, ig.padded_height, w)
     buf.fill_(0x5A5A5A5A)
-    vrt.rtapi.render_interleaved_batch(ds.accel, w, h, rank, world, plist, buf.data_ptr(), ig.frame_stride, 1, None, s)
+    if world == 1:
+        vrt.rtapi.render_batch(ds.accel, w, h, plist, buf.data_ptr(), ig.frame_stride, 1, None, s)     # the whole-frame entry point
+    else:
+        vrt.rtapi.render_interleaved_batch(ds.accel, w, h, rank, world, plist, buf.data_ptr(), ig.frame_stride, 1, None, s)
     torch.cuda.synchronize()
     assert vrt.rtapi.status(s) == 0
     for f in range(n):

@@ -2599,6 +2599,12 @@ int vxrt_render_interleaved_batch(vxrt_accel_t* accel, uint32_t width, uint32_t 
                        n_frames, dst_frame_stride);
 }
 
+// n_frames whole frames in one set of launches (vxrt_render_interleaved_batch with a single rank)
+int vxrt_render_batch(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t n_frames, const vxrt_shade_params_t* params, int shadow,
+                      uint32_t* dst, uint64_t dst_frame_stride, unsigned long long* rays_traced, void* stream) {
+  return vxrt_render_interleaved_batch(accel, width, height, 0, 1, n_frames, params, shadow, dst, dst_frame_stride, rays_traced, stream);
+}
+
 // Same launches as vxrt_render with the fetch counters compiled in (slower; never the timed path).
 // counters: device u64[7] = rays, node fetches, instance fetches, triangle fetches, shaded hits,
 // textured hits, pixels written -- the inputs of the algorithmic-bytes formula.

@@ -255,6 +255,15 @@ def render_interleaved_batch(accel, width, height, phase, stride, params_list, d
           "vxrt_render_interleaved_batch")
 
 
+def render_batch(accel, width, height, params_list, dst_ptr, dst_frame_stride, shadow=0, rays_ptr=None, stream=None):
+    """vxrt_render_batch: len(params_list) whole frames in one set of launches; frame f -> dst + f * dst_frame_stride pixels."""
+    L = _lib()
+    L.vxrt_render_batch.restype = C.c_int
+    L.vxrt_render_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ShadeParams), C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    arr = (ShadeParams * len(params_list))(*params_list)
+    check(L.vxrt_render_batch(accel, width, height, len(params_list), arr, int(shadow), dst_ptr, dst_frame_stride, rays_ptr, stream), "vxrt_render_batch")
+
+
 def render_stats(accel, width, height, y0, y1, params, dst_ptr, shadow=0, stream=None, timed=False):
     """Runs the counting build of the render kernels once; returns the counters + algorithmic bytes.  timed=True counts the
     traversal the timed kernel performs (unordered occlusion rays, leaf helpers) instead of the reference-order one."""
