@@ -1,0 +1,119 @@
+"""GPU: randomized parity.  Random triangle soups (slivers, zero-area and duplicated triangles among them) as 1-4 instances under
+random rotations, non-uniform scales and translations; camera rays, random rays, rays with zero direction components (the EXACT
+path) and rays starting inside the geometry; closest hit, first accepted hit, and occlusion with a per-ray bound.  The HIP
+traversal must return the oracle's hit records bit for bit -- on the tree the CPU builder makes and on the tree built on the GPU."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import gpu_trace, _bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _rot(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _soup(rng, n):
+    c = rng.uniform(-1, 1, size=(n, 1, 3))
+    size = rng.choice([0.02, 0.1, 0.4, 1.0], size=(n, 1, 1))
+    t = (c + rng.uniform(-1, 1, size=(n, 3, 3)) * size).astype(np.float32)
+    t[rng.integers(0, n, max(1, n // 20)), 2] = t[rng.integers(0, n, max(1, n // 20)), 1]      # a few degenerate (and copied) corners
+    t[: n // 25] = t[n // 25: 2 * (n // 25)]                                                      # duplicated triangles
+    t[rng.integers(0, n, n // 10), :, rng.integers(0, 3)] = np.float32(0.25)                     # axis-aligned flats (zero-thickness boxes)
+    return t.reshape(n, 9)
+
+
+def _rays(rng, po, lo, hi):
+    cam = po.camera_rays(48, 32)
+    n = 1500
+    o = rng.uniform(lo - 20, hi + 20, size=(n, 3))
+    tgt = rng.uniform(lo, hi, size=(n, 3))
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rnd = np.concatenate([o, d], 1)
+    inside = np.concatenate([rng.uniform(lo, hi, size=(300, 3)), rng.normal(size=(300, 3))], 1)
+    axis = np.zeros((300, 6))
+    axis[:, :3] = rng.uniform(lo - 5, hi + 5, size=(300, 3))
+    k = rng.integers(0, 3, 300)
+    axis[np.arange(300), 3 + k] = rng.choice([-1.0, 1.0], 300)                 # two zero components
+    axis[:150, 3 + (k[:150] + 1) % 3] = rng.uniform(-1, 1, 150)              # ... or one
+    return np.concatenate([cam, rnd, inside, axis]).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("builder", ["cpu", "gpu"])
+def test_random_scenes_and_rays(vrt, po, gpu_device, seed, builder):
+    rng = np.random.default_rng(1000 + seed)
+    n_inst = int(rng.integers(1, 5))
+    meshes, xf = [], []
+    for i in range(n_inst):
+        meshes.append(_soup(rng, int(rng.integers(40, 400))))
+        m = np.eye(4)
+        m[:3, :3] = _rot(rng) @ np.diag(rng.uniform(8, 40, 3))
+        m[:3, 3] = (rng.uniform(150, 400), rng.uniform(40, 160), rng.uniform(-150, 150))
+        xf.append(m.astype(np.float32))
+    if builder == "cpu":
+        sc = vrt.scene.from_triangles(meshes, xf)
+        ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    else:
+        ds = vrt.tracer.DeviceScene.build_on_gpu(meshes, transforms=xf, device=gpu_device, leaf_max=int(rng.integers(1, 5)))
+        sc = ds.to_host()
+    lo, hi = np.array([100.0, 0.0, -200.0]), np.array([450.0, 200.0, 200.0])
+    rays = _rays(rng, po, lo, hi)
+    got = gpu_trace(vrt, ds, rays)
+    want, _ = po.trace_canonical(sc, rays)
+    assert np.array_equal(_bits(got), _bits(want)), "closest hit"
+    assert (got["dist"] < 1e29).sum() > 100
+    got_any = gpu_trace(vrt, ds, rays, mode=1)
+    want_any, _ = po.trace_canonical(sc, rays, any_hit=True)
+    assert np.array_equal(_bits(got_any), _bits(want_any)), "first accepted hit"
+    tmax = rng.uniform(10, 300, len(rays)).astype(np.float32)
+    got_t = gpu_trace(vrt, ds, rays, mode=1, tmax=tmax)
+    want_t, _ = po.trace_canonical(sc, rays, tmax=tmax, any_hit=True)
+    assert np.array_equal(_bits(got_t), _bits(want_t)), "bounded occlusion rays"
+    assert 0 < (got_t["dist"] < 1e29).sum() < (got_any["dist"] < 1e29).sum()
+    ds.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_scenes_frames_with_shadow(vrt, po, gpu_device, seed):
+    """The frame path on the same kind of scenes: pixels, hit records and the occluded set against the oracle, single frames and a
+    batch of three with different lights."""
+    import torch
+    from test_gpu_parity import gpu_render
+    rng = np.random.default_rng(2000 + seed)
+    meshes, xf = [], []
+    for i in range(int(rng.integers(1, 4))):
+        meshes.append(_soup(rng, int(rng.integers(100, 500))))
+        m = np.eye(4)
+        m[:3, :3] = _rot(rng) @ np.diag(rng.uniform(20, 60, 3))
+        m[:3, 3] = (rng.uniform(180, 350), rng.uniform(60, 140), rng.uniform(-100, 100))
+        xf.append(m.astype(np.float32))
+    sc = vrt.scene.from_triangles(meshes, xf)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    w, h = 104, 72
+    lights = [(float(rng.uniform(50, 300)), float(rng.uniform(150, 400)), float(rng.uniform(-200, 200))) for _ in range(3)]
+    plist = []
+    for L in lights:
+        p = vrt.rtapi.default_shade_params()
+        p.light_pos[:] = L
+        plist.append(p)
+    px, hits, col, nrays = gpu_render(vrt, ds, w, h, shadow=1, params=plist[0])
+    want_px, want_hits, want_col, want_n = po.render_ex(sc, w, h, po.shade_params(light_pos=lights[0]), 1)
+    assert np.array_equal(px, want_px) and np.array_equal(_bits(hits.reshape(-1)), _bits(want_hits.reshape(-1))) and nrays == want_n
+    assert (hits["dist"] < 1e29).mean() > 0.01
+    buf = torch.zeros((3, h, w), dtype=torch.int32, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.render_batch(ds.accel, w, h, plist, buf.data_ptr(), w * h, 1, None, s)
+    torch.cuda.synchronize()
+    assert vrt.rtapi.status(s) == 0
+    for f in range(3):
+        want_f, _, _, _ = po.render_ex(sc, w, h, po.shade_params(light_pos=lights[f]), 1)
+        assert np.array_equal(buf[f].cpu().numpy().view(np.uint32), want_f), "frame %d of the batch" % f
+    ds.close()
