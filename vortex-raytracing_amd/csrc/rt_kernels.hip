@@ -424,6 +424,9 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #ifndef RT_TRACE_DEAD_MAX
 #define RT_TRACE_DEAD_MAX 16   // ray-buffer jobs (incoherent rays): refill early
 #endif
+#ifndef RT_QUEUE_PREFETCH
+#define RT_QUEUE_PREFETCH 0   // 1: a wavefront reserves its next tile while it traces the current one (hides the queue atomic's round trip)
+#endif
 #ifndef RT_WAVE_PRIO
 #define RT_WAVE_PRIO 0
 #endif
@@ -654,6 +657,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   bool queue_empty = false;
   uint32_t shard = blockIdx.x % QUEUE_SHARDS;   // blocks b and b+8 share an XCD (observed dispatch order; speed only)
   uint32_t tries = 0, loc_next = 0, loc_end = 0;
+  uint32_t pref_base = 0; bool pref_valid = false;   // RT_QUEUE_PREFETCH: queue position reserved ahead (lane 0), for the current shard
   uint32_t loc_off = 0;           // job id = queue position + loc_off (tile order indirection of render jobs)
   uint32_t lpt_tile = 0xFFFFFFFFu; unsigned long long lpt_t0 = 0;   // tile being timed for A.tile_cost
   Fetches fx;
@@ -823,10 +827,20 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             const uint32_t s_lo = shard * per_shard;
             const uint32_t s_n = s_lo < n_jobs ? min(per_shard, n_jobs - s_lo) : 0u;
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(A.queue + shard * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
+            if (RT_QUEUE_PREFETCH && !EXACT && JOB != JOB_TRACE && pref_valid) {
+              base = pref_base;          // reserved while the previous tile was being traced: its round trip is long over
+              pref_valid = false;
+            } else {
+              if (lane == 0) base = atomicAdd(A.queue + shard * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
+            }
             base = __shfl(base, 0);
             if (base < s_n) {
               loc_next = s_lo + base; loc_end = s_lo + min(base + (uint32_t)RT_CHUNK, s_n);
+              if (RT_QUEUE_PREFETCH && !EXACT && JOB != JOB_TRACE) {
+                // reserve this wavefront's NEXT tile of the shard now; the returned position is first read at the next fetch
+                if (lane == 0) pref_base = atomicAdd(A.queue + shard * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
+                pref_valid = true;
+              }
               if (JOB != JOB_TRACE && !EXACT && (A.tile_order || A.tile_cost)) {   // one chunk = one 8x8 tile
                 const uint32_t pos = loc_next >> 6;
                 const uint32_t tile = A.tile_order ? A.tile_order[pos] : pos;
@@ -841,6 +855,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             }
             shard = (shard + 1u) % QUEUE_SHARDS;
             ++tries;
+            pref_valid = false;   // (a reservation past the shard's end was consumed above; the next shard starts without one)
           }
           if (tries >= QUEUE_SHARDS) queue_empty = true;
         }
