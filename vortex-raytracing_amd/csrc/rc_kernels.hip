@@ -33,7 +33,12 @@
 #define RC_LARGE_FLOAT 1e30f
 #define RC_EPSILON 1e-6f
 #define RC_STACK 64             // BVH_STACK_SIZE of the reference (deeper = undefined behaviour there, status bit here)
-#define RC_LDS_STACK 16         // stack entries kept in LDS per lane; deeper ones in scratch
+#ifndef RC_LDS_STACK
+#define RC_LDS_STACK 12         // stack entries kept in LDS per lane; deeper ones in scratch (12 + 6 wavefronts per SIMD: +2 % over 16 + 5)
+#endif
+#ifndef RC_WAVES
+#define RC_WAVES 6              // wavefronts per SIMD the kernel is compiled for
+#endif
 #define RC_STATUS_STACK 1u      // same bits as the RTU path's status word
 #define RC_STATUS_ITER 2u
 #define RC_STATUS_BAD_SCENE 4u
@@ -198,7 +203,7 @@ struct RcArgs {
   uint32_t* dst; float* colors; uint32_t* status; uint32_t* queue;
 };
 
-__global__ __launch_bounds__(256, 5) void rc_persistent_kernel(RcDev sc, RcParams p, RcArgs A) {
+__global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, RcParams p, RcArgs A) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   __shared__ uint32_t s_stk[4][RC_LDS_STACK][64];
   // 0-2 world origin, 3-5 world direction, 6-8 object direction, 9-11 hit bx/by/bz, 12 hit blasIdx, 13 hit triIdx
