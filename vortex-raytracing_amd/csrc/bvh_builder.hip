@@ -32,6 +32,10 @@
 #include "rt_types.h"
 #include "../../include/vortex_hip.h"
 
+#ifndef BB_EXTENDED_MORTON
+#define BB_EXTENDED_MORTON 1
+#endif
+
 namespace {
 
 constexpr int BB_MAX_LEVELS = 34;   // launches of the collapse pass; a tree deeper than RT_MAX_LEVELS is reported, not emitted half-way
@@ -130,7 +134,27 @@ __global__ __launch_bounds__(256) void bb_morton_kernel(const float* __restrict_
     if (t > 2097151.0f) t = 2097151.0f;
     q[a] = (uint32_t)t;
   }
+#if BB_EXTENDED_MORTON
+  // extended Morton order (Vinkler et al. 2017): the next bit always comes from the axis whose cell is still the longest, so an
+  // elongated scene is not cut across its short axes as often as along its long one (plain interleaving gives every axis 21 bits
+  // whatever its extent).  The axis sequence depends on the bounds only: the same for every thread.
+  float e3[3] = {ord2f(cb[3]) - ord2f(cb[0]), ord2f(cb[4]) - ord2f(cb[1]), ord2f(cb[5]) - ord2f(cb[2])};
+  int used[3] = {0, 0, 0};
+  uint64_t key = 0;
+  for (int b = 0; b < 63; ++b) {
+    int a = -1; float best = -1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (used[k] < 21 && e3[k] > best) { best = e3[k]; a = k; }
+    const uint32_t qa = a == 0 ? q[0] : (a == 1 ? q[1] : q[2]);
+    const int ua = a == 0 ? used[0] : (a == 1 ? used[1] : used[2]);
+    key = (key << 1) | ((qa >> (20 - ua)) & 1u);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (k == a) { used[k]++; e3[k] *= 0.5f; }
+  }
+  keys[i] = key;
+#else
   keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+#endif
   vals[i] = i;
 }
 
