@@ -3,15 +3,24 @@
 
 Metric (BASELINE.json): Mrays/s (primary + shadow) at 1920x1080 on the 1M-triangle "Sponza-class" BVH.  A step = one frame of
 the RTU test on that scene: camera ray -> closest hit -> Lambert shade with one occlusion ray toward the light per hit -> RGB8,
-i.e. one vxrt_render call through the C ABI (persistent traversal launch + EXACT launches + shading pass), scene already
-resident in HBM.  Frames are issued round robin on --frames-in-flight streams (default 2; measured 2 > 4 > 3: profiles/r02_g_frames_in_flight.txt) so that the draining tail of one
-frame's persistent launch overlaps the next frame's; --frames-in-flight 1 gives strictly serial frames.
+through the C ABI (persistent traversal launch + EXACT launches + shading pass), scene already resident in HBM.
+
+How the K timed steps are issued (all of it inside the timed region, every ray of every frame traced):
+  * frames go out in equal groups of at most 5 per set of launches (vxrt_render_batch: each wavefront then works through five
+    times as many tiles per launch, so the launch's ramp and tail weigh less: +8 %; --batch 1 = one frame per set of launches);
+  * sets are issued round robin on --frames-in-flight streams (default 2; 2 > 4 > 3 measured), so the draining tail of one set's
+    persistent launch overlaps the next set's; --frames-in-flight 1 gives strictly serial single frames;
+  * before the W warmup steps, --settle-frames untimed frames of the same kind bring the GPU clocks to their sustained state (a
+    20-step run would otherwise time the clock ramp: DESIGN.md s10).
 
 Multi-GPU (one process per GPU, torch.distributed over RCCL): ONE frame is split by 8-row tile rows of the reference grid
-(kernel.cpp:128-133) -- rank r renders the tile rows r, r + N, r + 2N, ... (vxrt_render_interleaved; interleaving balances the
-ranks, the cost of a tile varies 4x over the frame) with no data-path collective, and ONE gather over xGMI assembles the image
-on rank 0 on its own stream (north_star: "RCCL gather only for final image assembly").  STRONG scaling: the frame, and so the
-total work, is fixed as N grows; value = rays of the whole frame / max-over-ranks time.  `--shard rows` uses contiguous bands.
+(kernel.cpp:128-133) -- rank r renders the tile rows r, r + N, r + 2N, ... (interleaving balances the ranks, the cost of a tile
+varies 4x over the frame) with no data-path collective; frames are traced in batches of up to 32 per set of launches
+(vxrt_render_interleaved_batch: a rank's share of one frame is too small to fill its GPU) and ONE gather over xGMI per batch
+assembles the images on rank 0 on its own stream (north_star: "RCCL gather only for final image assembly").  STRONG scaling:
+the frame, and so the total work, is fixed as N grows; value = rays of the whole frame x K / max-over-ranks time.  `--shard rows`
+uses contiguous bands, one frame per set of launches.  `--rehearse-world N` does on ONE GPU what rank 0 of N would do per frame,
+without the collective (diagnostic).
 
 Prints one JSON line (driver contract) with `roofline` and `cpu_baseline` objects.  The roofline is the VALU roof: this
 traversal is cache-resident pointer chasing whose binding resource is vector-ALU issue, priced with the
