@@ -203,3 +203,26 @@ def test_two_rank_frame_assembly_on_the_hip_path(mode, po):
     vrt = importlib.import_module("vortex-raytracing_amd")
     want, _, _, _ = po.render_ex(vrt.scene.procedural("atrium", 3, 0, 3), 328, 184, po.shade_params(light_pos=(300.0, 480.0, 60.0)), 1)
     assert np.array_equal(frame, want)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_end_to_end():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with two ranks sharing the
+    box's GPU and gloo for the collectives: the batched frame path, the assembly and the one JSON line of rank 0."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--settle-frames", "4", "--level", "4",
+           "--dist-backend", "gloo", "--no-cpu-baseline", "--random-rays", "65536"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["frames_per_launch_group"] == 3 and d["config"]["rays_per_step"] > d["config"]["rays_per_step_rank0"] > 0
+    assert "interleaved" in d["config"]["parallelism"]
