@@ -825,7 +825,11 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
         if (loc_next == loc_end) {   // wave-uniform: reserve the next chunk, stealing from other shards when the home shard is dry
           while (tries < QUEUE_SHARDS) {
             const uint32_t s_lo = shard * per_shard;
-            const uint32_t s_n = s_lo < n_jobs ? min(per_shard, n_jobs - s_lo) : 0u;
+            // a shard past the end of the job range costs no atomic (an EXACT launch with nothing deferred used to pay eight per
+            // wavefront to find eight empty shards).  Written as an explicit range test: folded into `s_n == 0` on a select, this
+            // compiler dropped the `s_lo < n_jobs` half of the condition and the wavefronts ran past the end of the job list.
+            if (!(s_lo < n_jobs)) { shard = (shard + 1u) % QUEUE_SHARDS; ++tries; continue; }
+            const uint32_t s_n = min(per_shard, n_jobs - s_lo);
             uint32_t base = 0;
             if (RT_QUEUE_PREFETCH && !EXACT && JOB != JOB_TRACE && pref_valid) {
               base = pref_base;          // reserved while the previous tile was being traced: its round trip is long over
@@ -2232,7 +2236,10 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   ShadeParams p{};
 #define LAUNCH_T(ST, LD) do { \
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, false>, n)), dim3(RT_WG_THREADS), 0, s, a->dev, p, A); \
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, true>), dim3(EXACT_GRID), dim3(256), 0, s, a->dev, p, X); } while (0)
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, true>), dim3(std::max<uint32_t>(EXACT_GRID, persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, true>, n / 8, 256))), dim3(256), 0, s, a->dev, p, X); } while (0)
+  // (the EXACT launch's grid grows with the ray buffer -- a workgroup per 2,048 rays, up to the machine: how many rays were deferred
+  // is known on the device only, and a buffer of axis-parallel rays defers all of them; with nothing deferred its wavefronts find
+  // every shard empty without an atomic and exit)
   if (stats_counters) { if (a->dev.exact_decode) LAUNCH_T(1, true); else LAUNCH_T(1, false); }
   else                { if (a->dev.exact_decode) LAUNCH_T(0, true); else LAUNCH_T(0, false); }
 #undef LAUNCH_T
