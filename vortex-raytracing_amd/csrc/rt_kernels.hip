@@ -2472,6 +2472,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
         pb[f].lpos[i] = params[f].light_pos[i]; pb[f].bg[i] = params[f].background[i];
       }
       pb[f].max_depth = params[f].max_depth;
+      if (params[f].max_depth > 1 && a->max_reflectivity > 0.0f) return -1;   // (mirror bounces: single frames only)
     }
     // (by value through the kernel arguments: captured when the launch is enqueued, whatever the caller does with `params` next)
     ShadeBatch sb;
