@@ -66,6 +66,8 @@ def parse():
                     help="frames kept in flight on as many HIP streams (vxrt_accel_frames_in_flight); 1 = strictly serial frames")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal of the N>1 code path where ranks share one GPU (shares gathered through host memory)")
+    ap.add_argument("--one-rank-group", action="store_true",
+                    help="diagnostic, one GPU: run the N > 1 code path (process group, interleaved batches, dist.gather, barriers, all_reduce) with a group of ONE rank -- the RCCL calls of the multi-GPU run on a 1-GPU box")
     ap.add_argument("--random-rays", type=int, default=16777216,
                     help="second leg (SURVEY s8d 'random rays vs fixed BVH'): N incoherent rays per GPU through vxrt_trace, reported under extras; 0 = skip")
     return ap.parse_args()
@@ -172,8 +174,44 @@ def load_profile_constants():
     return None
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, as fresh child processes (one per
+    GPU, `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`), BEFORE anything in this process touches
+    HIP (device_count does not initialise the GPU on this image), relay rank 0's JSON line and exit with the children's code.
+    Never exec: the parent stays a plain process.  Fewer than N visible devices is an error, not an N=1 run."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if a.dist_backend == "nccl" and have < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to report an N=%d run as N=%d\n" % (a.gpus, have, have, a.gpus))
+        return 3
+    if have < 1:
+        sys.stderr.write("bench.py needs a HIP device: there is no CPU fallback for the hot path\n")
+        return 3
+    with socket.socket() as so:      # a free rendezvous port on the loopback
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
+    if r.returncode == 0 and len(lines) != 1:
+        sys.stderr.write("bench.py: the %d ranks printed %d JSON lines, expected exactly one (rank 0)\n" % (a.gpus, len(lines)))
+        return 4
+    for l in lines:
+        print(l, flush=True)
+    return r.returncode
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(spawn_ranks(a))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -182,7 +220,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        a.gpus = world
+        # a launcher started a different number of ranks than --gpus names: the line would claim the wrong N
+        raise SystemExit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d" % (a.gpus, world))
     # rehearsal of rank 0 of an N-GPU run on one GPU, without the network: everything a rank does per frame except the collective
     rehearse = a.rehearse_world if (world == 1 and a.rehearse_world > 1) else 0
     if rehearse:
@@ -191,15 +230,32 @@ def main():
         raise SystemExit("bench.py needs a HIP device: there is no CPU fallback for the hot path")
     if a.dist_backend == "gloo":
         local %= max(1, torch.cuda.device_count())   # rehearsal: ranks may share a GPU
+    elif local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no device (LOCAL_RANK %d, %d visible): one GPU per rank with the nccl backend" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
-    if world > 1 and not rehearse:
+    multi = world > 1 or a.one_rank_group          # take the N-rank code path (shares, batches, image assembly)
+    grouped = multi and not rehearse                # ... with a process group and its collectives
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     cdev = dev if a.dist_backend == "nccl" else "cpu"   # where collectives' tensors live
+    # what the line reports about the job: the group's own world size and the device each rank runs on
+    my_dev = "%s (%s)" % (dev, torch.cuda.get_device_name(local))
+    rank_devices = [my_dev]
+    dist_world = 1
+    if grouped:
+        dist_world = dist.get_world_size()
+        rank_devices = [None] * dist_world
+        dist.all_gather_object(rank_devices, my_dev)
 
     vrt = importlib.import_module("vortex-raytracing_amd")
     rtapi, sharding = vrt.rtapi, vrt.sharding
@@ -221,20 +277,20 @@ def main():
     if os.environ.get("VXRT_BENCH_OWN_STREAMS"):
         streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
     # (with several ranks a framebuffer stays busy until its gather has run: twice as many, so that rendering never waits for the link)
-    n_frames = max(2, nfl) * (2 if world > 1 else 1)
+    n_frames = max(2, nfl) * (2 if multi else 1)
     ig = None
     # Several ranks: a rank's share of one frame is small against its GPU (4,080 tiles for 6,096 resident wavefronts at 1080p / 8)
     # and takes as long as its slowest tile -- about half a full frame's time, whatever N.  The steps are therefore issued in batches
     # of B frames per set of launches (vxrt_render_interleaved_batch) and assembled with one collective per batch.
     B = 1
-    if world > 1 and a.shard == "tilerows":
+    if multi and a.shard == "tilerows":
         # default: as large as a batch may be (16), but the K timed steps split into equal groups, at least one per stream
         # (K = 20 -> 2 groups of 10, not 16 + 4)
         n_groups = max(nfl, -(-a.steps // 16))
         B = max(1, min(32, a.batch if a.batch > 0 else -(-a.steps // n_groups)))
-        ig = sharding.InterleavedGather(H, W, rank, world, dev, slots=n_frames, collective=not rehearse, batch=B)
+        ig = sharding.InterleavedGather(H, W, rank, world, dev, slots=n_frames, collective=not rehearse, batch=B, single_rank_collective=a.one_rank_group)
         frames = [ig.new_frame_buffer(dev) for _ in range(n_frames)]
-    elif world == 1 and a.batch != 1 and nfl > 1:
+    elif not multi and a.batch != 1 and nfl > 1:
         # One GPU: whole frames in groups of up to 5 per set of launches (the same entry point with one rank).  Each wavefront then
         # works through 5x as many tiles per launch, so ramp and tail of a launch weigh less -- the effect that lets a 3840x2160
         # frame reach 10 Grays/s: +5..6 % (3..12 frames per set measured alike: profiles/r02_l_frame_batches.txt).
@@ -250,11 +306,11 @@ def main():
     def launch(buf, count_ptr=None, st=None, k=1):
         sp = (st or stream).cuda_stream
         if B > 1 and k > 0 and count_ptr is None and st is not None:
-            if world == 1:
+            if not multi:
                 rtapi.render_batch(ds.accel, W, H, [params] * k, buf.data_ptr(), frame_stride, shadow, None, sp)
             else:
                 rtapi.render_interleaved_batch(ds.accel, W, H, rank, world, [params] * k, buf.data_ptr(), frame_stride, shadow, None, sp)
-        elif world > 1 and a.shard == "tilerows":
+        elif multi and a.shard == "tilerows":
             rtapi.render_interleaved(ds.accel, W, H, rank, world, params, buf.data_ptr(), shadow, None, None, count_ptr, sp)
         else:
             rtapi.render(ds.accel, W, H, y0, y1, params, buf.data_ptr(), shadow, None, None, count_ptr, sp)
@@ -270,7 +326,7 @@ def main():
         algo_timed = rtapi.render_stats(ds.accel, W, H, 0, H, params, frames[0].data_ptr(), shadow, sptr, timed=True)  # the traversal that is timed
 
     rtapi.accel_frames_in_flight(ds.accel, nfl)
-    gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    gather_stream = torch.cuda.Stream(device=dev) if multi else None
     gdone = [None] * len(frames)   # per framebuffer: event of the last gather that read it
 
     no_gather = bool(rehearse and os.environ.get("VXRT_BENCH_NO_GATHER"))   # (diagnostic: the share's launches alone)
@@ -287,7 +343,7 @@ def main():
         launch(buf, st=st, k=k)
         if ev is not None:
             ev[1].record(st)
-        if world > 1 and not no_gather:
+        if multi and not no_gather:
             # image assembly overlaps the next step's traversal: the gather runs on its own stream
             gather_stream.wait_stream(st)
             with torch.cuda.stream(gather_stream):
@@ -320,7 +376,7 @@ def main():
     for i, k in enumerate(groups(a.settle_frames) + groups(a.warmup)):
         step(i, k=k)
     torch.cuda.synchronize()
-    if world > 1 and not rehearse:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -328,11 +384,11 @@ def main():
         step(i, evs[i], k=k)
     t_issued = time.perf_counter() - t0     # host time to issue the K steps (diagnostic: a host-bound run has t_issued ~ elapsed)
     torch.cuda.synchronize()
-    if world > 1 and not rehearse:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1 and not rehearse:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -370,18 +426,18 @@ def main():
         for _ in range(2):
             rtapi.trace(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
         torch.cuda.synchronize()
-        if world > 1 and not rehearse:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(reps):
             rtapi.trace(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr)
         torch.cuda.synchronize()
-        if world > 1 and not rehearse:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         rt = time.perf_counter() - t1
-        if world > 1 and not rehearse:
+        if grouped:
             t = torch.tensor([rt], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rt = float(t.item())
@@ -400,7 +456,7 @@ def main():
         del rays, hits
 
     if rank == 0:
-        if world == 1:
+        if not multi:
             par = "1 GPU: whole frames, %d per set of launches (vxrt_render_batch), %d sets in flight" % (B, nfl) if B > 1 else "1 GPU: whole frame"
         elif a.shard == "tilerows":
             par = "one frame split by interleaved 8-row tile rows (rank r: rows r, r+%d, ... of %d tile rows) x%d GPUs, %d frames per set of launches, one RCCL gather of the shares to rank 0 per set" % (world, (H + 7) // 8, world, B)
@@ -419,6 +475,7 @@ def main():
             "data": "synthetic (procedural 'Sponza-class' atrium, seed 3; no Sponza/bunny asset exists offline)",
             "config": {"workload": "configs[2]: Sponza-class %d tris, %dx%d, primary + 1 shadow ray per hit%s" % (scene.n_tris, W, H, "" if shadow else " (shadow disabled)"),
                        "rays_per_step": rays_all, "rays_per_step_rank0": rays_rank, "frames_in_flight": nfl, "frames_per_launch_group": B, "clock_settle_frames_untimed": a.settle_frames, "parallelism": par,
+                       "world_size": dist_world, "rank_devices": rank_devices, "dist_backend": (a.dist_backend if grouped else None),
                        "bvh_nodes": scene.n_bvh_nodes, "bvh_depth": scene.info.get("max_depth")},
         }
         prof = load_profile_constants()
@@ -463,7 +520,7 @@ def main():
         if extras:
             out["extras"] = extras
         print(json.dumps(out), flush=True)
-    if world > 1 and not rehearse:
+    if grouped:
         dist.destroy_process_group()
 
 

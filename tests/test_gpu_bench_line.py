@@ -32,3 +32,87 @@ def test_driver_command_prints_one_well_formed_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and 0 < cb["value"] < 1000 and cb["unit"] == "Mrays/s" and cb["sample"]
     assert d["extras"]["random_rays_mrays_s"] > 500
+
+
+def _bench(args, timeout=900, env=None):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+def test_plain_command_with_two_gpus_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver starts --gpus 1) must be a 2-rank run: bench.py starts
+    its ranks as child processes before touching HIP.  Here the two ranks share the box's one GPU and gather over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = _bench(["--gpus", "2", "--dist-backend", "gloo", "--steps", "6", "--warmup", "2", "--settle-frames", "4", "--level", "4",
+                "--no-cpu-baseline", "--random-rays", "65536"], timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and len(d["config"]["rank_devices"]) == 2 and d["config"]["dist_backend"] == "gloo"
+    assert d["steps"] == 6 and d["value"] > 0 and d["config"]["rays_per_step"] > d["config"]["rays_per_step_rank0"] > 0
+
+
+def test_more_gpus_than_the_box_has_is_an_error_not_a_one_gpu_line():
+    import torch
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = _bench(["--gpus", str(n + 7), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--random-rays", "0"], timeout=300, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")], r.stdout[-500:]
+    assert "device" in r.stderr
+
+
+_NCCL_ONE_RANK = r"""
+import importlib, os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+sh = importlib.import_module("vortex-raytracing_amd.sharding")
+h, w, B = 1080, 1920, 3
+ig = sh.InterleavedGather(h, w, 0, 1, "cuda:0", slots=2, batch=B, single_rank_collective=True)
+fb = ig.new_frame_buffer("cuda:0")
+g = torch.Generator(device="cuda:0").manual_seed(7)
+fb.copy_(torch.randint(0, 1 << 24, fb.shape, generator=g, device="cuda:0", dtype=torch.int32))
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):          # as bench.py does: the assembly runs on its own stream
+    out = ig.gather(fb, 1)
+    t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    objs = [None]
+    dist.all_gather_object(objs, "cuda:0")
+side.synchronize()
+assert out.shape == (B, h, w) and torch.equal(out, fb[:, :h]) and float(t.item()) == 1.5 and objs == ["cuda:0"]
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+"""
+
+
+def test_rccl_gather_of_the_image_assembly_runs_with_a_one_rank_group():
+    """The N > 1 run's collectives (dist.gather of the shares on device tensors, the all_reduce of the timing, the barrier) on the
+    nccl = RCCL backend with a group of ONE rank: the first RCCL call ever made by this code must not be on the driver's 8-GPU node."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    r = subprocess.run([sys.executable, "-c", _NCCL_ONE_RANK % (ROOT, port)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_the_multi_rank_code_path_of_bench_runs_over_rccl_with_a_one_rank_group():
+    """bench.py's whole N > 1 path -- nccl process group on the device, interleaved batches, dist.gather on its own stream, barriers,
+    all_reduce of the timing -- with a group of one rank on the box's GPU (--one-rank-group)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = _bench(["--gpus", "1", "--one-rank-group", "--steps", "20", "--warmup", "5", "--settle-frames", "10", "--level", "5",
+                "--no-cpu-baseline", "--random-rays", "65536"], timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["dist_backend"] == "nccl" and d["config"]["world_size"] == 1
+    assert d["config"]["frames_per_launch_group"] == 10 and "interleaved" in d["config"]["parallelism"] and d["value"] > 0

@@ -118,12 +118,15 @@ class InterleavedGather:
     batch > 1: a slot holds `batch` frames ([batch, padded_height, width], what vxrt_render_interleaved_batch fills) and the same
     three launches move all of them."""
 
-    def __init__(self, height, width, rank, world, device, slots=2, dtype=None, group=None, collective=True, batch=1):
+    def __init__(self, height, width, rank, world, device, slots=2, dtype=None, group=None, collective=True, batch=1,
+                 single_rank_collective=False):
         import torch
         self.h, self.w, self.rank, self.world, self.group, self.batch = height, width, rank, world, group, batch
         self.per = padded_share_rows(height, world) // TILE        # tile rows per rank, padded
         self.padded_height = self.per * world * TILE
         self.collective = collective                                # False: rehearsal of one rank without the network
+        # True: a group of ONE rank still goes through dist.gather (the RCCL call of the N-rank run, exercised on a 1-GPU box)
+        self.single_rank_collective = single_rank_collective
         self.dtype = dtype or torch.int32
         self.shares = [torch.zeros((batch, self.per * TILE, width), dtype=self.dtype, device=device) for _ in range(slots)]
         self.recv = self.full = None
@@ -149,7 +152,7 @@ class InterleavedGather:
         import torch.distributed as dist
         share = self.shares[slot]
         share.view(self.batch, self.per, TILE, self.w).copy_(frame.view(self.batch, self.per, self.world, TILE, self.w)[:, :, self.rank])
-        if self.world > 1 and self.collective:
+        if self.collective and (self.world > 1 or self.single_rank_collective):
             if via_cpu:     # gloo rehearsal: collectives on host tensors
                 out = [torch.empty_like(share, device="cpu") for _ in range(self.world)] if self.rank == 0 else None
                 dist.gather(share.cpu(), out, dst=0, group=self.group)
