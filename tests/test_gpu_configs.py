@@ -104,6 +104,57 @@ def test_headline_frame_bands_match_oracle(vrt, po, gpu_device, atrium):
     assert checked > 50000   # rays compared
 
 
+def test_the_timed_call_itself_matches_oracle(vrt, po, gpu_device, atrium):
+    """What bench.py times: vxrt_render_batch, 1920x1080, 5 frames per set of launches with a light that moves from frame to
+    frame, sets alternating on two streams, no optional outputs.  Two 8-row bands of frames 0 and 4 of the LAST set against the
+    oracle -- the first band holds the v == 0 row, both hold the u == 0 column, i.e. the pixels the EXACT launches trace; every
+    set equal to the first (contexts and streams cannot matter); and the same frames rendered one by one with the hit-record
+    output requested give the same pixels."""
+    import torch
+    sc, ds = atrium
+    w, h, n, sets = 1920, 1080, 5, 6
+    lights = [(300.0 - 35.0 * f, 480.0 - 12.0 * f, 60.0 + 25.0 * f) for f in range(n)]
+    plist = []
+    for f in range(n):
+        p = vrt.rtapi.default_shade_params()
+        p.light_pos[:] = lights[f]
+        plist.append(p)
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(2)]
+    bufs = [torch.full((n, h, w), 0x5A5A5A5A, dtype=torch.int32, device=gpu_device) for _ in range(sets)]
+    cnt = torch.zeros(1, dtype=torch.int64, device=gpu_device)
+    vrt.rtapi.accel_frames_in_flight(ds.accel, 2)
+    try:
+        torch.cuda.synchronize()
+        for i in range(sets):
+            vrt.rtapi.render_batch(ds.accel, w, h, plist, bufs[i].data_ptr(), h * w, 1, cnt.data_ptr() if i == sets - 1 else None, streams[i % 2].cuda_stream)
+        torch.cuda.synchronize()
+        assert vrt.rtapi.status(streams[0].cuda_stream) == 0
+    finally:
+        vrt.rtapi.accel_frames_in_flight(ds.accel, 1)
+    for b in bufs[1:]:
+        assert torch.equal(b, bufs[0])
+    assert not torch.equal(bufs[0][0], bufs[0][4])
+    last = bufs[-1].cpu().numpy().view(np.uint32)
+    rays = 0
+    for f in (0, 4):
+        pp = po.shade_params(light_pos=lights[f])
+        for y0, y1 in ((536, 544), (904, 912)):
+            rpx, rhits, _, rn = po.render_ex(sc, w, h, pp, 1, y0, y1)
+            np.testing.assert_array_equal(last[f][y0:y1], rpx[y0:y1])
+            rays += rn
+    assert rays > 100000
+    # rays counted by the last set's launch: 5 frames, primary + one occlusion ray per hit
+    assert 5 * w * h < int(cnt.item()) <= 10 * w * h
+    # single frames, with the optional hit-record output: same pixels
+    s0 = torch.cuda.current_stream().cuda_stream
+    for f in (0, 4):
+        one = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
+        hits = torch.zeros(h * w * 24, dtype=torch.uint8, device=gpu_device)
+        vrt.rtapi.render(ds.accel, w, h, 0, h, plist[f], one.data_ptr(), 1, hits.data_ptr(), None, None, s0)
+        torch.cuda.synchronize()
+        assert torch.equal(one, bufs[0][f])
+
+
 def test_serial_frames_with_learned_tile_order_match_pipelined(vrt, po, gpu_device, atrium):
     """One frame in flight takes the longest-tile-first order from its second frame on; the frame cannot depend on it."""
     sc, ds = atrium

@@ -12,6 +12,10 @@ COLOR_RTOL = 1e-5
 FIXTURES = ["teapot", "torus", "sphere", "cone", "cylinder", "cube", "teapot_x3", "sphere_x6", "tex_mix"]
 
 
+# rays of the sphere_x6 fixture on which the reference expands a TLAS node with a stale base_ptr (rt_traversal.cpp:91-92 after :119):
+# excluded from the comparison with the reference's output, compared with the canonical restatement instead
+STALE_BASE_RAYS_SPHERE_X6 = 43
+
 def _bits(a):
     return np.ascontiguousarray(a).view(np.uint8)
 
@@ -62,6 +66,7 @@ def test_trace_matches_reference_fixture(vrt, po, golden, gpu_device, name):
     ok = np.ones(len(got), bool)
     if name == "sphere_x6":   # reference stale-base quirk, see tests/test_oracle_golden.py
         ok = ~po.stale_base_mask(g, g["rays"])
+        assert int((~ok).sum()) == STALE_BASE_RAYS_SPHERE_X6      # the mask is a fixed set: a regression cannot hide behind a growing one
         want_fixed, _ = po.trace_canonical(g, g["rays"])
         assert np.array_equal(_bits(got), _bits(want_fixed))
     assert np.array_equal(_bits(got[ok]), _bits(g["hits"][ok]))
@@ -73,6 +78,7 @@ def test_any_hit_matches_reference_fixture(vrt, po, golden, gpu_device, name):
     ds = vrt.tracer.DeviceScene(g, gpu_device)
     got = gpu_trace(vrt, ds, g["rays"], mode=vrt.rtapi.MODE_ANY)
     ok = ~po.stale_base_mask(g, g["rays"]) if name == "sphere_x6" else np.ones(len(got), bool)
+    assert int((~ok).sum()) == (STALE_BASE_RAYS_SPHERE_X6 if name == "sphere_x6" else 0)
     assert np.array_equal(_bits(got[ok]), _bits(g["anyhits"][ok]))
 
 

@@ -103,11 +103,11 @@ def test_stale_base_quirk_is_confined_to_deep_tlas(po, golden):
     assert st["stale_base"] == 0
     g = golden("sphere_x6")
     mask = po.stale_base_mask(g, g["rays"])
-    assert mask.any()
+    assert int(mask.sum()) == 43 and len(mask) == 1088        # a fixed set (the GPU tests exclude exactly these rays)
     c, _ = po.trace_canonical(g, g["rays"])
     lost = (g["hits"]["dist"][mask] >= 1e29) & (c["dist"][mask] < 1e29)
     print("sphere_x6: %d rays trip the quirk, reference loses a real hit on %d of them" % (mask.sum(), lost.sum()))
-    assert (c["dist"][mask] <= g["hits"]["dist"][mask]).all()
+    assert (c["dist"][mask] <= g["hits"]["dist"][mask]).all() and int(lost.sum()) == 21
 
 
 def test_mirror_bounce_restatement_properties(vrt, po):
