@@ -369,6 +369,12 @@ int vxrt_trace(vxrt_accel_t* accel, const float* rays, uint64_t n, const float* 
 int vxrt_shade_rays(vxrt_accel_t* accel, const float* rays, const vxrt_hit_t* hits, uint64_t n, const vxrt_shade_params_t* params,
                     float* colors, uint32_t* rgb8, void* stream);
 
+/* Diagnostic (tests): copies the first n_dwords (<= 800) of the control block of frame context `ctx` to `out` after synchronising
+ * `stream`: [0] number of rays the main launch handed to the EXACT launch, [32 + 32 k] queue shard k (k = 0..7) of the main launch,
+ * [288 + 32 k] of the EXACT launch over the deferred list, [544 + 32 k] of the a-priori EXACT launch.  A vxrt_trace call leaves the
+ * block as its launches left it (the next call clears it). */
+int vxrt_debug_read_control(vxrt_accel_t* accel, uint32_t ctx, uint32_t* out, uint32_t n_dwords, void* stream);
+
 /* Status word of the launches on this device since the last call: 0 = ok, bit0 = traversal stack overflow
  * (tree deeper than the 32 levels the reference's own trail supports; the twin: deeper than BVH_STACK_SIZE),
  * bit1 = iteration limit, bit2 = the twin's kernel met an index outside its buffers.  Synchronises `stream`;

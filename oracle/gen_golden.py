@@ -129,6 +129,20 @@ def camera_fixture():
     print("camera_rays", len(out), flush=True)
 
 
+RNG_SEEDS = (0, 1, 61, 12345, 0x9E3779B9, 0xFFFFFFFF, 2073600 * 16 + 7)
+
+
+def rng_fixture():
+    """The reference's WangHash / RandomInt / RandomFloat (common.h:129-147) through oracle/_ref: 256 values per seed."""
+    L = po.ref()
+    out = {}
+    for k, seed in enumerate(RNG_SEEDS):
+        h, i, f = po.rng(seed, 256, L)
+        out["hash%d" % k], out["ints%d" % k], out["floats%d" % k] = h, i, f
+    np.savez_compressed(os.path.join(OUT, "rng.npz"), seeds=np.array(RNG_SEEDS, np.uint64), **out)
+    print("rng", len(RNG_SEEDS), "seeds", flush=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "cube":
@@ -137,7 +151,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "textured":
         make_textured()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "rng":
+        rng_fixture()
+        return
     camera_fixture()
+    rng_fixture()
     make("teapot", [wrap("teapot.obj")], 4096, 11)
     make("torus", [wrap("torus.obj")], 2048, 12)
     make("sphere", [wrap("sphere.obj")], 2048, 13)

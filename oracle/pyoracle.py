@@ -309,6 +309,17 @@ def trace_faithful(scene, rays, tmax=None, any_hit=False):
     return out, st.as_dict()
 
 
+def rng(seed, n, lib=None):
+    """(hash, ints, floats) of orc_rng -- or of the reference's own helpers with lib=ref() (vxref_rng, common.h:129-147)."""
+    L = lib or orc()
+    fn = L.vxref_rng if lib is not None else L.orc_rng
+    fn.restype = None
+    fn.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    h, i, f = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.float32)
+    fn(int(seed) & 0xFFFFFFFF, n, _p(h), _p(i), _p(f))
+    return h, i, f
+
+
 def stale_base_mask(scene, rays):
     """Per-ray flag: the reference expanded a TLAS internal node with a stale (BLAS) base_ptr for
     this ray (rt_traversal.cpp:91-92 after :119; see DESIGN.md 'reference quirks').  Such rays read

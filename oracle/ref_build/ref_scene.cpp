@@ -120,4 +120,16 @@ uint32_t vxref_shade(const float* ray6, float dist, float bx, float by, float bz
   return RGB32FtoRGB8(radiance);
 }
 
+// The reference's RNG helpers (common.h:129-147), host-compiled: hash[i] = WangHash(seed + i); then one xorshift stream seeded
+// with WangHash(seed) (0 -> 1, as every user must do: xorshift has the fixed point 0): ints[i] = RandomInt, and a second stream
+// from the same seed: floats[i] = RandomFloat.
+void vxref_rng(uint32_t seed, uint32_t n, uint32_t* hash, uint32_t* ints, float* floats) {
+  for (uint32_t i = 0; i < n; ++i) hash[i] = WangHash(seed + i);
+  uint32_t s = WangHash(seed);
+  if (s == 0) s = 1;
+  uint32_t t = s;
+  for (uint32_t i = 0; i < n; ++i) ints[i] = RandomInt(&s);
+  for (uint32_t i = 0; i < n; ++i) floats[i] = RandomFloat(&t);
+}
+
 }  // extern "C"

@@ -675,6 +675,17 @@ static uint32_t random_int(uint32_t* s) {          /* common.h:137-143 */
 }
 static float random_float(uint32_t* s) { return random_int(s) * 2.3283064365387e-10f; }   /* common.h:145-147 */
 
+/* the three RNG helpers as the AO / bounce passes use them, exposed so that they can be pinned to the reference's own
+ * (oracle/_ref: vxref_rng) and to tests/golden/rng.npz: same layout as vxref_rng */
+void orc_rng(uint32_t seed, uint32_t n, uint32_t* hash, uint32_t* ints, float* floats) {
+  for (uint32_t i = 0; i < n; ++i) hash[i] = wang_hash(seed + i);
+  uint32_t s = wang_hash(seed);
+  if (s == 0) s = 1;
+  uint32_t t = s;
+  for (uint32_t i = 0; i < n; ++i) ints[i] = random_int(&s);
+  for (uint32_t i = 0; i < n; ++i) floats[i] = random_float(&t);
+}
+
 void orc_ao_ray(uint32_t x, uint32_t y, uint32_t w, uint32_t spp, uint32_t s, uint32_t user_seed,
                 const float I[3], const float N[3], const float view_dir[3], float out6[6]) {
   uint32_t seed = wang_hash((x + y * w) * spp + s + 1u + user_seed * 0x9E3779B9u);

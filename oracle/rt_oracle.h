@@ -136,6 +136,9 @@ int orc_render_ex(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
 
 /* Ambient-occlusion pass (extension; definition in rt_oracle.c).  Only the RNG is the reference's
  * (common.h:129-147); the checker and the HIP kernel share the sampling recipe operation by operation. */
+/* WangHash / RandomInt / RandomFloat of common.h:129-147 as the passes below use them: hash[i] = WangHash(seed + i), ints / floats =
+ * two xorshift streams from WangHash(seed) (0 -> 1) */
+void orc_rng(uint32_t seed, uint32_t n, uint32_t* hash, uint32_t* ints, float* floats);
 void orc_ao_ray(uint32_t x, uint32_t y, uint32_t w, uint32_t spp, uint32_t s, uint32_t user_seed,
                 const float I[3], const float N[3], const float view_dir[3], float out6[6]);
 int orc_render_ao(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,

@@ -535,3 +535,51 @@ def test_diffuse_bounce_pass_matches_oracle(vrt, po, gpu_device):
     np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), rpx)
     _, _, direct = po.render(b, w, h, pp)
     assert (rcol >= direct - 1e-7).all() and (rcol > direct + 1e-3).any()      # the bounce only adds light
+
+
+@pytest.mark.parametrize("n", [1, 7, 63, 64, 65, 2049, 20000])
+def test_exact_launch_with_nothing_deferred_takes_no_queue_position(vrt, po, golden, gpu_device, n):
+    """Guard of round 2's abort (a fault in the EXACT launch of a ray buffer with nothing deferred): with every ray inside the fast
+    domain the main launch defers nothing, and the EXACT launch over the (empty) deferred list must find every queue shard past
+    the end of its job range WITHOUT touching the shard's counter -- its eight counters stay zero, whatever the buffer size
+    (fewer rays than one wavefront included).  The main launch's counters show the test looks at the right block."""
+    g = golden("teapot")
+    ds = vrt.tracer.DeviceScene(g, gpu_device)
+    rs = np.random.RandomState(n)
+    rays = g["rays"][rs.randint(0, len(g["rays"]), size=n)].astype(np.float32).copy()
+    rays[:, 3:] += rs.uniform(1e-4, 2e-4, size=(n, 3)).astype(np.float32)      # no zero direction component: nothing for the EXACT launch
+    inv = 1.0 / rays[:, 3:]
+    assert np.isfinite(inv).all() and (np.abs(inv) <= 2.0 ** 64).all()
+    got = gpu_trace(vrt, ds, rays)
+    want, _ = po.trace_canonical(g, rays)
+    assert np.array_equal(_bits(got), _bits(want))
+    import torch
+    ctl = vrt.rtapi.debug_read_control(ds.accel, 0, 800, torch.cuda.current_stream().cuda_stream)
+    main_q = ctl[32:32 + 256:32]
+    exact_q = ctl[32 + 256:32 + 512:32]
+    assert ctl[0] == 0, "rays deferred to the EXACT launch: %d" % ctl[0]
+    assert int(main_q.sum()) >= n, main_q                  # the main launch did draw its jobs from these counters
+    assert not exact_q.any(), "EXACT launch touched queue counters with nothing to do: %s" % exact_q
+    ds.close()
+
+
+def test_exact_launch_takes_exactly_the_deferred_rays(vrt, po, golden, gpu_device):
+    """The other side of the guard: axis-parallel rays (zero direction components) are ALL deferred; the EXACT launch's counters then
+    cover the deferred list and nothing of the shards past its end."""
+    g = golden("teapot")
+    ds = vrt.tracer.DeviceScene(g, gpu_device)
+    n = 300
+    rays = g["rays"][:n].astype(np.float32).copy()
+    rays[:, 3:] = 0.0
+    rays[np.arange(n), 3 + (np.arange(n) % 3)] = np.where(np.arange(n) % 2 == 0, 1.0, -1.0)
+    got = gpu_trace(vrt, ds, rays)
+    want, _ = po.trace_canonical(g, rays)
+    assert np.array_equal(_bits(got), _bits(want))
+    import torch
+    ctl = vrt.rtapi.debug_read_control(ds.accel, 0, 800, torch.cuda.current_stream().cuda_stream)
+    assert ctl[0] == n
+    exact_q = ctl[32 + 256:32 + 512:32].astype(np.int64)
+    per_shard = ((n + 7) // 8 + 63) & ~63          # the kernel's split of the deferred list over 8 shards
+    used = -(-n // per_shard)
+    assert (exact_q[:used] >= np.minimum(per_shard, n - per_shard * np.arange(used))).all() and not exact_q[used:].any(), exact_q
+    ds.close()

@@ -152,3 +152,14 @@ def test_mirror_bounce_restatement_properties(vrt, po):
     csec = po.shade(b, sec, sh, po.shade_params(light_pos=lp, max_depth=1))[0][0]
     want = (else_arm - bg * refl) + csec * refl
     np.testing.assert_allclose(c2, want, rtol=2e-6, atol=1e-7)
+
+
+def test_rng_matches_reference_fixture(po, golden):
+    """WangHash / RandomInt / RandomFloat of the restatement (what the AO and diffuse-bounce passes draw from) == the reference's own
+    helpers (common.h:129-147, host-compiled in oracle/_ref, tests/golden/rng.npz): 7 seeds x 256 values, bit for bit."""
+    g = golden("rng")
+    for k, seed in enumerate(g["seeds"]):
+        h, i, f = po.rng(int(seed), 256)
+        assert np.array_equal(h, g["hash%d" % k]) and np.array_equal(i, g["ints%d" % k])
+        assert np.array_equal(f.view(np.uint32), g["floats%d" % k].view(np.uint32))
+    assert len(np.unique(g["hash0"])) == 256 and (g["floats3"] >= 0).all() and (g["floats3"] <= 1).all()

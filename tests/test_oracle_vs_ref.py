@@ -70,3 +70,14 @@ def test_obj_ingest_equals_the_reference_mesh_loader(vrt, po, tmp_path):
         assert np.array_equal(ma[k], mb[k]), k
     textured = mb["tex_id"] >= 0
     assert textured.any() and np.array_equal(ma["off"][textured], mb["off"][textured])
+
+
+def test_rng_equals_the_reference_helpers_live(po):
+    """Fresh seeds (not the fixture's): orc_rng == vxref_rng (the reference's WangHash / RandomInt / RandomFloat, common.h:129-147)."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    rs = np.random.RandomState(99)
+    for seed in [int(x) for x in rs.randint(0, 2 ** 32, size=40, dtype=np.uint64)] + [0, 0xFFFFFFFF]:
+        a, b = po.rng(seed, 512), po.rng(seed, 512, po.ref())
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))

@@ -470,6 +470,12 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #ifndef RT_LDS_STACK_RENDER
 #define RT_LDS_STACK_RENDER 6
 #endif
+#ifndef RT_WAVES_RENDER_PACKED
+#define RT_WAVES_RENDER_PACKED 8
+#endif
+#ifndef RT_LDS_STACK_RENDER_PACKED
+#define RT_LDS_STACK_RENDER_PACKED 5
+#endif
 #ifndef LDS_STACK
 #define LDS_STACK 8         // stack levels kept in LDS per lane (4 KiB per wavefront); deeper ones go to scratch
 #endif
@@ -590,10 +596,13 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 // camera tables, or the pixel's primary hit record) on the rare TLAS-level steps.
 // STATS: 0 = the timed kernel; 1 = counting build in the reference's order (ordered occlusion, no leaf helpers: its fetch counts equal
 // the canonical restatement's); 2 = counting build of the traversal the timed kernel actually performs (unordered occlusion, helpers)
-template <int JOB, int STATS, bool LDEXP, bool EXACT>
-__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JOB_TRACE ? RT_WAVES_TRACE : RT_WAVES_RENDER)) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+// PACKED: the instantiation for frames traced in sets that overlap on two streams (bench.py's pipelined mode, batches): 8 wavefronts
+// per SIMD (64 VGPRs, 5 stack levels in LDS) instead of 7 -- +1.6 % there, where many tiles per wavefront hide the few spilled
+// registers, and -8 % on a serial frame, which keeps 7 (profiles/r03_c_flag_variants.txt)
+template <int JOB, int STATS, bool LDEXP, bool EXACT, bool PACKED = false>
+__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JOB_TRACE ? RT_WAVES_TRACE : (PACKED ? RT_WAVES_RENDER_PACKED : RT_WAVES_RENDER))) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
   // stack levels in LDS: what the instantiation's occupancy leaves room for (160 KB per CU)
-  constexpr int LSTK = EXACT ? LDS_STACK : (JOB == JOB_TRACE ? RT_LDS_STACK_TRACE : RT_LDS_STACK_RENDER);
+  constexpr int LSTK = EXACT ? LDS_STACK : (JOB == JOB_TRACE ? RT_LDS_STACK_TRACE : (PACKED ? RT_LDS_STACK_RENDER_PACKED : RT_LDS_STACK_RENDER));
   constexpr int WG_WAVES = EXACT ? 4 : RT_WG_WAVES;
   constexpr bool USE_TOP = RT_TOP_NODES > 0 && !EXACT && !LDEXP;   // (the ldexp decode reads exponents from the reference node by index)
   // V2 node step: only where every slab value is finite (bounded scene -- checked by the accel build, which selects the LDEXP
@@ -828,7 +837,12 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             // a shard past the end of the job range costs no atomic (an EXACT launch with nothing deferred used to pay eight per
             // wavefront to find eight empty shards).  Written as an explicit range test: folded into `s_n == 0` on a select, this
             // compiler dropped the `s_lo < n_jobs` half of the condition and the wavefronts ran past the end of the job list.
-            if (!(s_lo < n_jobs)) { shard = (shard + 1u) % QUEUE_SHARDS; ++tries; continue; }
+            // The test is an asm statement the optimiser cannot look into, and its marker comment is what the build check greps for
+            // in every instantiation's listing (tests/test_build_guards.py: one RTGUARD before the kernel's first queue atomic).
+            uint32_t in_range;
+            asm volatile("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0 ; RTGUARD shard_range" : "=s"(in_range)
+                         : "s"(__builtin_amdgcn_readfirstlane(s_lo)), "s"(__builtin_amdgcn_readfirstlane(n_jobs)) : "scc");   // (both wave-uniform)
+            if (!in_range) { shard = (shard + 1u) % QUEUE_SHARDS; ++tries; continue; }
             const uint32_t s_n = min(per_shard, n_jobs - s_lo);
             uint32_t base = 0;
             if (RT_QUEUE_PREFETCH && !EXACT && JOB != JOB_TRACE && pref_valid) {
@@ -2562,6 +2576,15 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   // free: a persistent grid that fills every CU (LDS) would otherwise keep them waiting until its first workgroups retire, and
   // the frame would end on them (measured: 33 us after the main launch, profiles/r02_d_exact_timeline.txt)
   const uint32_t side_wgs = side_launch ? std::min<uint32_t>(EXACT_GRID, (ap_count + 255u) / 256u) : 0u;
+  // ... on a serial frame.  With sets of frames overlapping on several streams the a-priori launch cannot get those slots anyway --
+  // an EXACT workgroup needs more registers than one retired main workgroup frees, so it only finds room in a tail (measured:
+  // it ends when its own main launch begins to drain, profiles/r03_a_pipeline_timeline.txt) -- and nothing waits for it before
+  // the other stream's tail: the main launch takes the whole machine then, +1 % (serial: -7 %).  VXRT_SIDE_RESERVE=0/1 forces it.
+  static const int side_reserve_env = [] { const char* e = getenv("VXRT_SIDE_RESERVE"); return e ? atoi(e) : -1; }();
+  const bool side_reserve = side_reserve_env >= 0 ? side_reserve_env != 0 : a->n_ctx == 1;
+  // frames packed in overlapping sets: the 8-wavefront instantiation (see rt_persistent_kernel); VXRT_PACKED=0/1 forces it
+  static const int packed_env = [] { const char* e = getenv("VXRT_PACKED"); return e ? atoi(e) : -1; }();
+  const bool packed = packed_env >= 0 ? packed_env != 0 : (a->n_ctx > 1 && n_tiles >= LPT_MIN_TILES);
   hipStream_t side = c->side;
   if (side_launch) {
     if (hipEventRecord(c->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, c->ev_in, 0) != hipSuccess) return -1;
@@ -2575,19 +2598,21 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   // tiles, and the machine stays full.  (A full frame, many tiles per wavefront, keeps the whole grid: measured better.)
   static const int grid_div_env = [] { const char* e = getenv("VXRT_GRID_DIV"); return e ? atoi(e) : 0; }();
 #define MAIN_GRID(K) [&]() -> uint32_t { \
-    uint32_t g = persistent_grid(K, A.total + (uint64_t)side_wgs * RT_WG_THREADS); \
+    const uint32_t side_wgs_r = side_reserve ? side_wgs : 0u; \
+    uint32_t g = persistent_grid(K, A.total + (uint64_t)side_wgs_r * RT_WG_THREADS); \
     const uint32_t cap = persistent_grid(K, ~0ull >> 8); \
     uint32_t div = grid_div_env > 0 ? (uint32_t)grid_div_env : ((grid_div_env == 0 && a->n_ctx > 1 && (uint64_t)A.total < 2ull * 64ull * RT_WG_WAVES * cap) ? a->n_ctx : 1u); \
     if (div > 1u) g = std::min<uint32_t>(g, std::max<uint32_t>(cap / div, 1u)); \
-    return std::max<uint32_t>(1u, g > side_wgs ? g - side_wgs : 1u); }()
-#define LAUNCH_P(J, ST, LD) do { \
+    return std::max<uint32_t>(1u, g > side_wgs_r ? g - side_wgs_r : 1u); }()
+#define LAUNCH_P(J, ST, LD, PK) do { \
     if (side_launch) hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(side_wgs), block, 0, side, sc, p, X0); \
-    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false>), dim3(MAIN_GRID((rt_persistent_kernel<J, ST, LD, false>))), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
+    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false, PK>), dim3(MAIN_GRID((rt_persistent_kernel<J, ST, LD, false, PK>))), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, s, sc, p, X); } while (0)
-#define LAUNCH_PD(J, ST) do { if (sc.exact_decode) LAUNCH_P(J, ST, true); else LAUNCH_P(J, ST, false); } while (0)
-  if (stats == 2)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 2); else LAUNCH_PD(JOB_RENDER, 2); }
-  else if (stats)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 1); else LAUNCH_PD(JOB_RENDER, 1); }
-  else             { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 0); else LAUNCH_PD(JOB_RENDER, 0); }
+#define LAUNCH_PD(J, ST, PK) do { if (sc.exact_decode) LAUNCH_P(J, ST, true, PK); else LAUNCH_P(J, ST, false, PK); } while (0)
+  if (stats == 2)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 2, false); else LAUNCH_PD(JOB_RENDER, 2, false); }
+  else if (stats)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 1, false); else LAUNCH_PD(JOB_RENDER, 1, false); }
+  else if (packed) { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 0, true); else LAUNCH_PD(JOB_RENDER, 0, true); }
+  else             { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 0, false); else LAUNCH_PD(JOB_RENDER, 0, false); }
 #undef LAUNCH_PD
 #undef LAUNCH_P
 #undef MAIN_GRID
@@ -2740,6 +2765,15 @@ int vxrt_shade_rays(vxrt_accel_t* a, const float* rays, const vxrt_hit_t* hits, 
   p.max_depth = 1;
   hipLaunchKernelGGL(rt_shade_rays_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->dev, p, n, rays, (const HitRec*)hits, colors, rgb8);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// diagnostic (tests): the control block of frame context `ctx` as the last call left it -- [0] deferral count, [32 + 32 k] the
+// main launch's queue shard k, [32 + 256 + 32 k] the shards of the EXACT launch over the deferred list, [32 + 512 + 32 k] those of
+// the a-priori EXACT launch.  vxrt_trace leaves the block for the next call to clear, so it can be inspected after a trace.
+int vxrt_debug_read_control(vxrt_accel_t* a, uint32_t ctx, uint32_t* out, uint32_t n_dwords, void* stream) {
+  if (!a || !out || ctx >= MAX_FRAMES_IN_FLIGHT || n_dwords > CTL_DWORDS || !a->ctx[ctx].ctl) return -1;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+  return hipMemcpy(out, a->ctx[ctx].ctl, (size_t)n_dwords * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 int vxrt_status(void* stream, uint32_t* status) {

@@ -117,6 +117,17 @@ def accel_frames_in_flight(accel, n):
         raise RuntimeError("vxrt_accel_frames_in_flight(%r) failed" % (n,))
 
 
+def debug_read_control(accel, ctx=0, n_dwords=800, stream=None):
+    """vxrt_debug_read_control: the control block of frame context `ctx` (numpy u32) as the last call left it."""
+    import numpy as np
+    L = _lib()
+    L.vxrt_debug_read_control.restype = C.c_int
+    L.vxrt_debug_read_control.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    out = np.zeros(n_dwords, np.uint32)
+    check(L.vxrt_debug_read_control(accel, ctx, out.ctypes.data, n_dwords, stream), "vxrt_debug_read_control")
+    return out
+
+
 def accel_bytes(accel):
     return int(_lib().vxrt_accel_bytes(accel))
 
