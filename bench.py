@@ -73,7 +73,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(scene, vrt, w, h, light, budget_cpu_s):
+def cpu_baseline(scene, vrt, w, h, light, budget_cpu_s, random_sample=None):
     """BASELINE.md s2, timed on this box's host cores, on BOUNDED samples of the same workload.  Checker code (oracle/_ref, or
     the C restatement if that library is absent) is the thing timed here for the reported baseline only, never for `value`.
       B2-N  (value)  the reference's own BVHTraverser (sim/simx/rt_traversal.cpp via oracle/_ref) on the frame's camera rays,
@@ -157,8 +157,76 @@ def cpu_baseline(scene, vrt, w, h, light, budget_cpu_s):
                                                        % (n, n // w, w, h, rc["tri"].size // 36, dt1)}
         except Exception as e:   # the baseline leg must not take the bench line down
             out["b1_raycast_render_loop"] = {"error": repr(e)[:200]}
+    # like for like with the GPU run (BASELINE.md s2 "the same synthetic rays as the GPU run"), reference object code, all cores:
+    #   * the frame's own mix -- primary rays of rows spread over the frame AND the occlusion ray of every hit toward the light
+    #     (first accepted candidate = the any-hit query the GPU's shadow phase answers), constructed as shadow_ray does
+    #   * a sample of the second leg's random rays (the device-generated buffer itself, copied back)
+    if kind == "reference":
+        try:
+            f = np.float32
+            rows = np.arange(0, h, 4)
+            pr = np.ascontiguousarray(rays.reshape(h, w, 6)[rows].reshape(-1, 6))
+            t0 = time.perf_counter()
+            chunks = np.array_split(np.arange(len(pr)), cores * 4)
+            with cf.ThreadPoolExecutor(cores) as ex:
+                hits = np.concatenate([x[0] for x in ex.map(lambda c: po.trace_ref(img, pr[c]), chunks)])
+            hit = hits["dist"] < 1e29
+            I = (pr[:, :3] + pr[:, 3:] * hits["dist"].reshape(-1, 1).astype(f)).astype(f)
+            L = (np.array(light, f)[None] - I).astype(f)
+            dist = np.sqrt((L[:, 0] * L[:, 0] + L[:, 1] * L[:, 1]).astype(f) + (L[:, 2] * L[:, 2]).astype(f)).astype(f)
+            Ln = (L * (f(1.0) / dist)[:, None]).astype(f)
+            sr = np.concatenate([(I + (Ln * f(0.001)).astype(f)).astype(f), Ln], 1).astype(f)[hit]
+            schunks = np.array_split(np.arange(len(sr)), cores * 4)
+            with cf.ThreadPoolExecutor(cores) as ex:     # (the reference traverser has no tmax: an any-hit query to infinity, an upper bound of the GPU's bounded one)
+                list(ex.map(lambda c: po.trace_ref(img, sr[c], any_hit=True), schunks))
+            dt2 = time.perf_counter() - t0
+            out["same_rays_primary_plus_shadow"] = {"value": round((len(pr) + len(sr)) / dt2 / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "reference",
+                                                    "sample": "%d primary + %d occlusion rays of %d rows spread over the %dx%d frame, %.1f s wall (ray construction included)" % (len(pr), len(sr), len(rows), w, h, dt2)}
+        except Exception as e:
+            out["same_rays_primary_plus_shadow"] = {"error": repr(e)[:200]}
+        if random_sample is not None and len(random_sample):
+            try:
+                rr = np.ascontiguousarray(random_sample, np.float32)
+                t0 = time.perf_counter()
+                chunks = np.array_split(np.arange(len(rr)), cores * 4)
+                with cf.ThreadPoolExecutor(cores) as ex:
+                    list(ex.map(lambda c: po.trace_ref(img, rr[c]), chunks))
+                dt3 = time.perf_counter() - t0
+                out["same_rays_random"] = {"value": round(len(rr) / dt3 / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "reference",
+                                           "sample": "the first %d of the GPU leg's random rays (seed 12345, origins in the scene box, directions on the sphere), closest hit, %.1f s wall" % (len(rr), dt3)}
+            except Exception as e:
+                out["same_rays_random"] = {"error": repr(e)[:200]}
     out["note"] = "no POCL path exists to time: the reference has no OpenCL ray tracer and POCL is not installed (SURVEY s0.5)"
     return out
+
+
+class ClockProbe:
+    """Shader clock the chip holds around the timed region: a one-wavefront kernel of the measurement library (csrc/calib_kernels.hip,
+    lib/libvxrt_calib.so -- not the product library) reads s_memtime and the constant 100 MHz s_memrealtime around a ~30 us spin.
+    Launched on the timed region's first stream right before its first step and right after its last one: the power management
+    moves the clock over milliseconds, the probe sits within microseconds of the load."""
+
+    def __init__(self, vrt, torch, dev):
+        import ctypes as C
+        self.ok = False
+        try:
+            self.L = C.CDLL(vrt.lib_path("libvxrt_calib.so"))
+            self.L.vxcal_clock_probe.restype = C.c_int
+            self.L.vxcal_clock_probe.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+            self.buf = torch.zeros((4, 4), dtype=torch.int64, device=dev)
+            self.ok = True
+        except Exception as e:     # the probe is optional: without it the nominal clock is used, and the line says so
+            self.err = repr(e)[:120]
+
+    def launch(self, slot, stream_ptr):
+        if self.ok and self.L.vxcal_clock_probe(3000, self.buf[slot].data_ptr(), stream_ptr) != 0:
+            self.ok = False
+
+    def ghz(self, slot):
+        if not self.ok:
+            return None
+        c, t = int(self.buf[slot, 0].item()), int(self.buf[slot, 1].item())
+        return (c / t / 10.0) if t > 0 else None
 
 
 def load_profile_constants():
@@ -379,10 +447,17 @@ def main():
     # the timed ones do (same streams, same frames in flight) and directly before them.
     for i, k in enumerate(groups(a.settle_frames) + groups(a.warmup)):
         step(i, k=k)
+    # every frame rendered before the timed region opens (one for the ray count, two counting builds, the isolated launches,
+    # the clock-settling frames, the W warmup steps): none of them is timed, none of their results is reused
+    frames_before = 1 + (2 if world == 1 else 0) + len(iso) + a.settle_frames + a.warmup
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
+    probe = ClockProbe(vrt, torch, dev) if rank == 0 else None
+    if probe:
+        probe.launch(0, sptr)          # (untimed: behind the warmup steps, before the region's opening synchronisation)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i, k in enumerate(timed_groups):
         step(i, evs[i], k=k)
@@ -391,6 +466,8 @@ def main():
         stream.wait_stream(st_)
     end_ev = torch.cuda.Event(enable_timing=True)
     end_ev.record(stream)
+    if probe:
+        probe.launch(1, sptr)          # (behind the end event: not part of the span it closes; its ~30 us are inside the host-timed region)
     t_issued = time.perf_counter() - t0     # host time to issue the K steps (diagnostic: a host-bound run has t_issued ~ elapsed)
     torch.cuda.synchronize()
     if grouped:
@@ -417,6 +494,7 @@ def main():
         print("step starts (ms):", " ".join("%.3f" % evs[0][0].elapsed_time(e0) for e0, _ in evs), "end %.3f" % span_ms, "host %.3f" % (elapsed * 1e3), "issued %.3f" % (t_issued * 1e3), file=sys.stderr)
 
     extras = {}
+    random_sample = None
     if a.random_rays:
         # north_star's second figure: synthetic random rays against the fixed BVH, ray buffer (24 B/ray) in HBM ->
         # hit records (24 B/ray); every rank traces its own N rays (seed 12345 + rank), no collective
@@ -429,6 +507,7 @@ def main():
         d = d / d.norm(dim=1, keepdim=True)
         rays = torch.cat([o, d], 1).contiguous()
         del o, d
+        random_sample = rays[:60000].cpu().numpy() if rank == 0 else None     # (for the CPU baseline's like-for-like leg)
         hits = torch.zeros(n * 24, dtype=torch.uint8, device=dev)
         rstats = rtapi.trace_stats(ds.accel, rays.data_ptr(), n, hits.data_ptr(), rtapi.MODE_CLOSEST, None, sptr) if rank == 0 else None
         reps = 5
@@ -483,31 +562,54 @@ def main():
             "dtype": "f32",
             "data": "synthetic (procedural 'Sponza-class' atrium, seed 3; no Sponza/bunny asset exists offline)",
             "config": {"workload": "configs[2]: Sponza-class %d tris, %dx%d, primary + 1 shadow ray per hit%s" % (scene.n_tris, W, H, "" if shadow else " (shadow disabled)"),
-                       "rays_per_step": rays_all, "rays_per_step_rank0": rays_rank, "frames_in_flight": nfl, "frames_per_launch_group": B, "clock_settle_frames_untimed": a.settle_frames, "parallelism": par,
+                       "rays_per_step": rays_all, "rays_per_step_rank0": rays_rank, "frames_in_flight": nfl, "frames_per_launch_group": B, "clock_settle_frames_untimed": a.settle_frames, "frames_rendered_before_the_timed_region": frames_before, "parallelism": par,
                        "world_size": dist_world, "rank_devices": rank_devices, "dist_backend": (a.dist_backend if grouped else None),
                        "bvh_nodes": scene.n_bvh_nodes, "bvh_depth": scene.info.get("max_depth")},
         }
         prof = load_profile_constants()
         # one step = the launches of vxrt_render: persistent traversal kernel (dominant, > 93 % of the step), the EXACT launches
         # for the rays with NaN-capable slabs, and the shading pass; priced together
-        roof = {"bound": "valu", "achieved": None, "peak": round(SIMDS * CLOCK_GHZ, 1), "unit": "Gcycle/s (VALU issue cycles summed over the 1024 SIMDs)", "frac": None, "traffic": None,
+        clk = [probe.ghz(0), probe.ghz(1)] if probe else [None, None]
+        clock_held = (sum(clk) / 2.0) if all(clk) else None
+        clock = clock_held or CLOCK_GHZ
+        # ONE denominator: wave64 VALU instructions per second against what 1,024 SIMDs can issue at the clock held in the timed
+        # region, at the guide's 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: "issues each VALU instruction over 2
+        # cycles").  The same fraction at the 2.2 cycles this chip measured for dense independent streams (tools/calibrate_valu.py)
+        # and at the nominal 2.4 GHz are given next to it, labelled.
+        roof = {"bound": "valu", "achieved": None, "peak": round(SIMDS * clock / 2.0, 1), "unit": "G wave64 VALU instructions/s", "frac": None, "traffic": None,
+                "peak_is": "1024 SIMDs x clock held in the timed region / 2 cycles per wave64 VALU instruction (guide constant)",
+                "clock_ghz_held": round(clock_held, 4) if clock_held else None,
+                "clock_probe_ghz_before_after": [round(c, 4) if c else None for c in clk],
+                "clock_source": "one-wavefront s_memtime / s_memrealtime probe right before the first and right after the last timed step (lib/libvxrt_calib.so)" if clock_held
+                                else "nominal %.1f GHz (probe library not available)" % CLOCK_GHZ,
                 "kernel": "rt_persistent_kernel<JOB_RENDER%s> (+ EXACT launches + rt_shade_kernel)" % ("_SHADOW" if shadow else ""),
                 "kernel_ms": round(kern_ms, 4), "kernel_ms_overlapped": round(ovl_ms, 4), "kernel_ms_isolated": round(iso_ms, 4),
+                "kernel_ms_is": "GPU-clock span of the timed region (HIP events: first step's start -> an event behind every stream) / steps",
                 "frames_per_launch": B, "launch_set_ms_overlapped": round(ovl_ms * a.steps / max(1, len(evs)), 4),
                 "frames_in_flight": nfl,
                 "why_valu": "the scene is cache-resident (measured HBM traffic = a few % of the HBM peak) and relieving the memory path measured neutral (LDS-staged "
                             "top of the tree: 39 % of node steps from LDS, -17 % vector-memory instructions, +0 %: profiles/r02_b_lds_top_counters.txt); what moves the time "
-                            "is the number of VALU instructions.  Roof: one wave64 VALU instruction per 2.2 SIMD cycles (measured, tools/calibrate_valu.py: 1,100 G/s "
-                            "over 1,024 SIMDs, for add/mul/fma/mov streams and for their 1:1 mixes with the cmp/cndmask/min/max/cvt class that alone sustains one per 4.1)"}
+                            "is the number of VALU instructions"}
         if prof and world == 1 and W == 1920 and H == 1080 and a.level == 8 and shadow:
-            # profile constants of THIS workload (deterministic instruction counts per frame), source named in the file
-            cyc = prof["valu_simd_cycles_per_frame"]            # sum over instruction classes of count x measured cycles
-            ach = cyc / (kern_ms * 1e-3) / 1e9
-            roof.update({"achieved": round(ach, 1), "frac": round(ach / (SIMDS * CLOCK_GHZ), 4),
-                         "frac_isolated": round(cyc / (iso_ms * 1e-3) / 1e9 / (SIMDS * CLOCK_GHZ), 4),
-                         "valu_simd_cycles_per_frame": cyc, "valu_instr_per_frame": prof.get("valu_instr_per_frame"),
-                         "valu_Ginstr_s": round(prof.get("valu_instr_per_frame", 0) / (kern_ms * 1e-3) / 1e9, 1), "valu_peak_Ginstr_s_measured": prof.get("valu_peak_Ginstr_s_measured"),
-                         "valu_source": prof.get("source"), "valu_pricing": prof.get("pricing")})
+            # profile constants of THIS workload (instruction counts per frame are a property of the frame and the code), source named in the file
+            n_valu = prof["valu_instr_per_frame"]
+            ach = n_valu / (kern_ms * 1e-3) / 1e9
+            mk = prof.get("main_kernel", {})
+            roof.update({"achieved": round(ach, 1), "frac": round(ach / (SIMDS * clock / 2.0), 4),
+                         "frac_isolated": round(n_valu / (iso_ms * 1e-3) / 1e9 / (SIMDS * clock / 2.0), 4),
+                         "valu_instr_per_frame": n_valu, "valu_source": prof.get("source"),
+                         "same_numerator_other_denominators": {
+                             "frac_at_2.2_cycles_per_instruction_measured_on_this_chip": round(ach / (SIMDS * clock / 2.2), 4),
+                             "frac_at_nominal_2.4_GHz_and_2_cycles": round(ach / (SIMDS * CLOCK_GHZ / 2.0), 4),
+                             "frac_at_nominal_2.4_GHz_and_2.2_cycles": round(ach / (SIMDS * CLOCK_GHZ / 2.2), 4)}})
+            if mk.get("SQ_ACTIVE_INST_VALU") and mk.get("SQ_WAVE_CYCLES"):
+                roof["main_kernel_counters"] = {
+                    "lane_utilisation": round(mk["SQ_THREAD_CYCLES_VALU"] / (64.0 * mk["SQ_ACTIVE_INST_VALU"]), 4),
+                    "lane_utilisation_is": "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)",
+                    "wait_any_of_wave_cycles": round(mk["SQ_WAIT_ANY"] / mk["SQ_WAVE_CYCLES"], 4),
+                    "wait_inst_any_of_wave_cycles": round(mk["SQ_WAIT_INST_ANY"] / mk["SQ_WAVE_CYCLES"], 4),
+                    "salu_per_valu": round(mk["SQ_INSTS_SALU"] / mk["SQ_INSTS_VALU"], 4) if mk.get("SQ_INSTS_VALU") else None,
+                    "source": prof.get("source")}
             roof["traffic"] = prof.get("hbm_bytes_per_frame")
             roof["traffic_source"] = prof.get("hbm_source")
         if algo:
@@ -525,7 +627,7 @@ def main():
             roof["counts_timed_traversal"] = algo_timed
         out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, vrt, W, H, LIGHT, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(scene, vrt, W, H, LIGHT, a.cpu_seconds, random_sample)
         if extras:
             out["extras"] = extras
         sys.stdout.flush()

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from test_gpu_parity import gpu_render, gpu_trace, _bits
-from test_scene_builder import brute_force, check_tree
+from test_scene_builder import brute_force, check_tree, check_tree_fast
 
 pytestmark = pytest.mark.gpu
 
@@ -155,6 +155,10 @@ def test_one_million_triangles(vrt, po, gpu_device):
     same = hits["dist"] == rhits["dist"]
     assert same.mean() > 0.9995 and (px[same] == rpx[same]).mean() > 0.9995
     sc = ds.to_host()
+    # exact check of the tree itself at the size where the bottom-up box pass has cross-XCD contention (a stale sibling box would
+    # give a box that is too small: hits dropped silently, and the oracle below walks the SAME tree): every vertex inside the
+    # decoded boxes of all its ancestors, every triangle in exactly one leaf
+    assert check_tree_fast(sc) == info.max_depth
     y0, y1 = 536, 544
     opp = po.shade_params()
     opp.light_pos[:] = (300.0, 480.0, 60.0)

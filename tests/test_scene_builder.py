@@ -42,11 +42,58 @@ def check_tree(sc):
     return maxd
 
 
+def check_tree_fast(sc, root=0):
+    """check_tree for trees of millions of nodes: the same properties, breadth-first with numpy over whole levels -- every
+    triangle in exactly one leaf, every vertex inside the decoded boxes of ALL its ancestors (the intersection of the chain),
+    internal nodes with >= 2 children in the first slots, children after their parent.  Returns the depth."""
+    nodes = sc["bvh"].view(NODE)
+    tri = sc["tri"].view(np.float32).reshape(-1, 3, 3)
+    seen = np.zeros(len(tri), np.int32)
+    idx = np.array([root], np.int64)
+    lo = np.full((1, 3), -np.inf, np.float32)
+    hi = np.full((1, 3), np.inf, np.float32)
+    depth = 0
+    while len(idx):
+        n = nodes[idx]
+        assert (n["imask"] == 0).all()
+        leaf = n["ld"] != 0
+        if leaf.any():
+            lf, ld = n["lf"][leaf].astype(np.int64), n["ld"][leaf].astype(np.int64)
+            assert (lf + ld <= len(tri)).all()
+            owner = np.repeat(np.arange(len(lf)), ld)                       # leaf of every listed triangle
+            t = np.repeat(lf - np.concatenate([[0], np.cumsum(ld)[:-1]]), ld) + np.arange(int(ld.sum()))
+            np.add.at(seen, t, 1)
+            llo, lhi = lo[leaf][owner], hi[leaf][owner]
+            v = tri[t]                                                       # [k, 3 vertices, 3]
+            assert (v >= llo[:, None, :]).all() and (v <= lhi[:, None, :]).all(), "a vertex outside a decoded box of its ancestors"
+        inner = ~leaf
+        if not inner.any():
+            break
+        ni, nn = idx[inner], n[inner]
+        valid = nn["ch"][:, :, 0] != 0                                       # [m, 4]
+        cnt = valid.sum(1)
+        assert (cnt >= 2).all() and (valid == (np.arange(4)[None, :] < cnt[:, None])).all(), "children not in the first slots"
+        s = np.ldexp(np.float32(1), nn["e"].astype(np.int32)).astype(np.float32)          # [m, 3]
+        q = nn["ch"][:, :, 1:].astype(np.float32)                                           # [m, 4, 6]
+        clo = nn["o"][:, None, :] + q[:, :, :3] * s[:, None, :]
+        chi = nn["o"][:, None, :] + q[:, :, 3:] * s[:, None, :]
+        assert (chi >= clo)[valid].all()
+        clo = np.maximum(clo, lo[inner][:, None, :])
+        chi = np.minimum(chi, hi[inner][:, None, :])
+        child = nn["lf"].astype(np.int64)[:, None] + np.arange(4)[None, :]
+        assert (child[valid] > np.repeat(ni, cnt)).all() and (child[valid] < len(nodes)).all(), "children must come after their parent"
+        idx, lo, hi = child[valid], clo[valid], chi[valid]
+        depth += 1
+    assert (seen == 1).all(), "triangles in no leaf: %d, in several: %d" % (int((seen == 0).sum()), int((seen > 1).sum()))
+    return depth
+
+
 @pytest.mark.parametrize("args", [("cornell", 0, 0, 1), ("blob", 3, 0, 2), ("atrium", 4, 0, 3), ("hairball", 60, 20, 7)])
 def test_builder_invariants(vrt, args):
     sc = vrt.scene.procedural(*args)
     d = check_tree(sc)
     assert d == sc.info["max_depth"] and d < 32        # the reference's trail supports 32 levels
+    assert check_tree_fast(sc) == d
     assert sc.info["n_tris"] == sc.n_tris
     tl = sc["tlas"].view(NODE)
     assert len(tl) == 1 and tl[0]["imask"] == 1 and tl[0]["ld"] == 0     # single mesh: TLAS root is the instance leaf (bvh.cpp:325-328)
@@ -56,6 +103,7 @@ def test_atrium_level8_is_the_1m_triangle_scene(vrt):
     sc = vrt.scene.procedural("atrium", 8, 0, 3)
     assert sc.n_tris == 1048576
     assert sc.info["max_depth"] < 32
+    assert check_tree_fast(sc) == sc.info["max_depth"]      # the exact containment check at the size the benchmark runs
     assert sc.n_mats == 16 and sc["tex"].size == 8 * 256 * 256 * 4
 
 

@@ -23,9 +23,9 @@ def main():
         tag, flags = arg.split("=", 1)
         d = os.path.join(out_root, tag)
         os.makedirs(d, exist_ok=True)
-        for f in ("libvortex.so", "libvxrt_scene.so"):
+        for f in ("libvortex.so", "libvxrt_scene.so", "libvxrt_calib.so"):
             shutil.copy2(os.path.join(bld.LIB, f), os.path.join(d, f))
-        src = [os.path.join(bld.CSRC, f) for f in ("rt_kernels.hip", "rc_kernels.hip", "vx_backend.hip", "calib_kernels.hip", "bvh_builder.hip")]
+        src = [os.path.join(bld.CSRC, f) for f in bld.PRODUCT_HIP_SOURCES]
         cmd = [bld.HIPCC] + bld.HIP_FLAGS + flags.split() + ["-shared", "-o", os.path.join(d, "libvortex-hip.so")] + src
         open(os.path.join(d, "FLAGS"), "w").write(flags + "\n")
         procs.append((tag, subprocess.Popen(cmd)))

@@ -7,6 +7,8 @@ mkdir -p "$OUT"
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT";; esac
 cd /tmp && export TMPDIR=/tmp
+# the instantiation the default (pipelined) bench times, without the serial frame's tile-cost clocks: counters of THAT code
+export VXRT_PACKED=1 VXRT_LPT=0
 i=0
 for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" \
            "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD" \

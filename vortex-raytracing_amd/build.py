@@ -1,6 +1,7 @@
 """Build every native artefact of the package in-tree (hipcc cross-compiles gfx950 without a GPU).
 
   lib/libvortex-hip.so   HIP kernels + vx_dev_init backend + vxrt_* direct API   (hipcc, gfx950)
+  lib/libvxrt_calib.so   measurement only: VALU calibration loops + clock probe  (hipcc, gfx950; not part of the product library)
   lib/libvortex.so       vx_* host API dispatcher (stand-in for the reference's runtime/stub)
   lib/libvxrt_scene.so   BVH4 builder / quantiser / procedural scenes            (g++)
   lib/rt_host            C++ host program mirroring tests/regression/raytracing/main.cpp
@@ -28,6 +29,8 @@ ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 HIP_FLAGS += os.environ.get("VXRT_EXTRA_HIPFLAGS", "").split()   # experiments only (e.g. -DLDS_STACK=8)
 CXX_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall"]
+
+PRODUCT_HIP_SOURCES = ("rt_kernels.hip", "rc_kernels.hip", "vx_backend.hip", "bvh_builder.hip")
 
 # fixed VMAs of the four images of the RTU test (tests/regression/raytracing/Makefile:104-107)
 SELECTORS = {
@@ -70,9 +73,15 @@ def build(force=False, verbose=True):
         raise RuntimeError("hipcc not found at %s: the HIP path cannot be built" % HIPCC)
 
     hip_so = os.path.join(LIB, "libvortex-hip.so")
-    hip_src = [os.path.join(CSRC, f) for f in ("rt_kernels.hip", "rc_kernels.hip", "vx_backend.hip", "calib_kernels.hip", "bvh_builder.hip")]
+    hip_src = [os.path.join(CSRC, f) for f in PRODUCT_HIP_SOURCES]
     if force or _newer(hip_so, hip_src + hdrs):
         _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", hip_so] + hip_src)
+
+    # measurement only (VALU calibration loops, clock probe): its own library, not part of the product
+    cal_so = os.path.join(LIB, "libvxrt_calib.so")
+    cal_src = [os.path.join(CSRC, "calib_kernels.hip")]
+    if force or _newer(cal_so, cal_src):
+        _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", cal_so] + cal_src)
 
     stub_so = os.path.join(LIB, "libvortex.so")
     stub_src = [os.path.join(CSRC, "vx_stub.cpp")]

@@ -201,7 +201,11 @@ __global__ __launch_bounds__(256) void bb_tree_kernel(const uint64_t* __restrict
 // (__threadfence) costs an L2 write-back + invalidate per use on this chip (the XCDs' L2s are not coherent with each other):
 // 6 ms for a million triangles.  The boxes are therefore exchanged with relaxed agent-scope atomics -- stores that write through
 // to the coherence point, loads that read there -- and the only ordering needed, "box complete before the counter moves", is the
-// wavefront waiting for its own stores (s_waitcnt) before it issues the counter's atomic.
+// wavefront waiting for its own stores (s_waitcnt) before it issues the counter's atomic.  Both sides of that ordering are spelled
+// out for the COMPILER as well: the wait is an asm statement with a memory clobber (no memory operation moves across it), and
+// the second arrival reads its sibling's box behind another one (relaxed atomics to different addresses may otherwise be
+// reordered).  The hardware part -- stores acknowledged at the coherence point before vmcnt reaches 0, loads issued in order
+// behind the returned atomic -- is what tests/test_gpu_bvh_builder.py checks exactly on the 1M-triangle tree (check_tree_fast).
 __device__ __forceinline__ float coherent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -219,8 +223,9 @@ __global__ __launch_bounds__(256) void bb_fit_kernel(const float* __restrict__ t
     if (n == 1) return;
     const uint32_t p = id == 0 ? 0xffffffffu : parent[id];
     if (p == 0xffffffffu) return;                     // the root's box is written
-    __builtin_amdgcn_s_waitcnt(0);                    // this wavefront's stores have completed
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wavefront's stores have completed; nothing is moved across
     if (__hip_atomic_fetch_add(flag + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;   // the sibling subtree is not finished: its last thread continues
+    asm volatile("" ::: "memory");                                // the sibling's box is read AFTER the counter said it is complete
     const uint32_t l = rec[p].left, r = rec[p].right;   // (written by the previous launch)
     const BNode* s = rec + (l == id ? r : l);
     b.lx = fminf(b.lx, coherent_load(&s->lx)); b.ly = fminf(b.ly, coherent_load(&s->ly)); b.lz = fminf(b.lz, coherent_load(&s->lz));

@@ -3,7 +3,8 @@
 // and the 100 MHz wall clock (s_memrealtime) around its loop, so the cycles one wave64 instruction occupies its SIMD follow
 // from counts and clocks alone -- no assumption about the frequency the chip holds under this load.  Run under the same
 // rocprofv3 --pmc pass as the traversal kernel, it also shows what SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES read
-// for a VALU pipe whose utilisation is known.  No reference counterpart; measurement infrastructure of the product library.
+// for a VALU pipe whose utilisation is known.  No reference counterpart.  MEASUREMENT ONLY: built into lib/libvxrt_calib.so, which
+// tools/calibrate_valu.py and bench.py's clock probe load; the product library (libvortex-hip.so) does not contain it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -127,6 +128,21 @@ __global__ __launch_bounds__(256) void vxcal_kernel(float* __restrict__ out, uns
   }
 }
 
+__global__ __launch_bounds__(64) void vxcal_clock_probe_kernel(uint32_t ticks, unsigned long long* __restrict__ out) {
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  unsigned long long r1 = r0;
+  float x = 1.0f;
+  for (uint32_t i = 0; i < 4000000u && r1 - r0 < ticks; ++i) {     // (bounded: ~4 M iterations at most)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x));
+    r1 = wall_clock64();
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  r1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+  if (x == 123.456f) out[2] = 1;   // (keeps the chain alive)
+}
+
 extern "C" {
 // blocks of 256 threads (4 wavefronts, one per SIMD of a CU); vector instructions per wavefront = CAL_CHAINS * CAL_UNROLL * n_iter.
 // clocks: device u64[2 * 4 * blocks] = per wavefront {shader cycles, 100 MHz ticks} around the loop.
@@ -194,4 +210,14 @@ int vxcal_valu_loop(int op, uint32_t blocks, uint32_t n_iter, float* out, unsign
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 uint32_t vxcal_instr_per_iter(void) { return CAL_CHAINS * CAL_UNROLL; }
+
+// Clock probe: ONE wavefront reads the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime), spins for `ticks`
+// of the latter (a bounded loop: it also ends after max_iter iterations) and reads both again.  out[0] = shader cycles, out[1] =
+// 100 MHz ticks: shader clock in GHz = out[0] / out[1] / 10.  Launched right before and right after a timed region, on the stream
+// that carries it, it says what clock the chip held there (the power management reacts over milliseconds, the probe takes ~30 us).
+int vxcal_clock_probe(uint32_t ticks, unsigned long long* out, void* stream) {
+  if (!out || ticks == 0 || ticks > 100000u) return -1;
+  hipLaunchKernelGGL(vxcal_clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 }

