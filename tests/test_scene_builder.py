@@ -334,3 +334,23 @@ def test_obj_mtl_with_map_kd_feeds_the_texture_buffer(vrt, po, tmp_path):
     assert (hits["dist"] < 1e29).mean() > 0.1
     lit = col[hits["dist"] < 1e29]
     assert len(np.unique(lit.round(4), axis=0)) > 10      # many distinct texel colours, not one flat material
+
+
+@pytest.mark.parametrize("name", ["teapot", "torus", "sphere", "cone", "cylinder"])
+def test_tree_quality_anchored_to_the_reference_builder(vrt, po, golden, name):
+    """The committed fixtures hold the tree the REFERENCE's builder made of its own assets (bvh.cpp:30-264 through oracle/_ref).  On the
+    same triangles and the fixture's rays, the package's SAH tree must not cost more algorithmic bytes per ray (52 B per node fetch,
+    36 B per triangle test) than the reference's: it spends more triangle tests (leaves of up to 4) to save node
+    fetches.  tools/tree_quality.py prints the same comparison at the benchmark's scale (profiles/r03_d_tree_quality.txt)."""
+    g = golden(name)
+    tri = g["tri"].view(np.float32).reshape(-1, 9)
+    ours = vrt.scene.from_triangles([tri])
+    a, sa = po.trace_canonical(g, g["rays"])
+    b, sb = po.trace_canonical(ours, g["rays"])
+    assert np.array_equal(a["dist"], b["dist"])
+    ref_bytes = 52 * sa["node_reads"] + 36 * sa["tri_reads"]
+    our_bytes = 52 * sb["node_reads"] + 36 * sb["tri_reads"]
+    print("%s: reference tree %.1f nodes + %.2f tris per ray = %d B; ours %.1f + %.2f = %d B" % (
+        name, sa["node_reads"] / len(a), sa["tri_reads"] / len(a), ref_bytes // len(a), sb["node_reads"] / len(b), sb["tri_reads"] / len(b), our_bytes // len(b)))
+    assert our_bytes <= 1.02 * ref_bytes
+    assert sb["node_reads"] < sa["node_reads"]

@@ -415,6 +415,12 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #ifndef RT_TRACE_LEAF_MIN
 #define RT_TRACE_LEAF_MIN 24   // incoherent rays: +3.5 % at 16, another 1 % at 24
 #endif
+#ifndef RT_TRI_LDS
+#define RT_TRI_LDS 0        // > 0: triangles of the leaf most lanes of the wavefront hold are staged through LDS (north_star: "triangle vertices staged
+#endif                      // through LDS"): leaves of up to RT_TRI_LDS triangles, when at least RT_TRI_LDS_MIN lanes hold the same one.  Measured, off: DESIGN.md s5
+#ifndef RT_TRI_LDS_MIN
+#define RT_TRI_LDS_MIN 8
+#endif
 #ifndef RT_UNORDERED_OCCLUSION
 #define RT_UNORDERED_OCCLUSION 1
 #endif
@@ -643,6 +649,8 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   // top of the tree staged in LDS (north_star: "BVH nodes staged through LDS"): the first levels are what every ray of every
   // tile walks, and a ds_read_b128 does not queue behind the CU's vector-memory pipeline
   __shared__ uint4 s_top[USE_TOP ? 4 : 1][USE_TOP ? RT_TOP_NODES : 1];
+  constexpr bool TRI_LDS = RT_TRI_LDS > 0 && !EXACT && JOB != JOB_TRACE;
+  __shared__ float4 s_tri[TRI_LDS ? WG_WAVES : 1][TRI_LDS ? 3 * RT_TRI_LDS : 1];
   const uint32_t n_top = USE_TOP ? min(sc.n_top, (uint32_t)RT_TOP_NODES) : 0u;
   if (USE_TOP && n_top) {
     for (uint32_t i = threadIdx.x; i < 4u * n_top; i += (uint32_t)(64 * WG_WAVES)) s_top[i / n_top][i % n_top] = sc.top_img[(size_t)(i / n_top) * RT_TOP_NODES + (i % n_top)];
@@ -1116,6 +1124,20 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
         // ---- BLAS leaf (:123-161): triangles in index order, strict '<' ----
         if (STATS && A.wave_log) { ++wl_leaf_x; wl_leaf_l += (unsigned)__popcll(leafm); }
         {
+          // triangles through LDS (RT_TRI_LDS): the lanes of a tile reach the same leaves, and every one of them loads the leaf's
+          // triangles for itself.  The leaf of the first leaf lane is loaded ONCE, by 3 lanes per triangle, and handed to the lanes
+          // that hold it by broadcast reads; the others load theirs as before.
+          bool tri_from_lds = false;
+          if (TRI_LDS) {
+            const uint32_t L0 = __shfl(cur, __ffsll((long long)leafm) - 1);
+            const uint32_t c0 = (L0 >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
+            const unsigned long long same = __ballot(cur == L0);
+            if (c0 != 0u && c0 <= (uint32_t)RT_TRI_LDS && (uint32_t)__popcll(same) >= (uint32_t)RT_TRI_LDS_MIN) {   // (wave-uniform)
+              if (lane < 3u * c0) s_tri[threadIdx.x >> 6][lane] = sc.tri_w[(size_t)(L0 & LEAF_FIRST_MASK) * 3 + lane];
+              tri_from_lds = cur == L0;
+              if (STATS && A.wave_log) wl_no23 += (unsigned)__popcll(same);
+            }
+          }
           if (is_leaf_desc(cur)) {
             if (STATS) fx.node++;
             uint32_t leftFirst = cur & LEAF_FIRST_MASK, triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
@@ -1157,6 +1179,14 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             for (uint32_t i = 0; i < triCount; ++i) {
               const uint32_t triIdx = leftFirst + i;
               float4 t0, t1, t2;
+              if (TRI_LDS && tri_from_lds) {
+                // (typed LDS pointer: through a plain pointer the compiler would merge this arm and the global one into flat loads)
+                typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(3))) const volatile f32x4_t lds_f32x4_t;
+                lds_f32x4_t* lp = (lds_f32x4_t*)&s_tri[threadIdx.x >> 6][0] + 3u * i;
+                const f32x4_t a0 = lp[0], a1 = lp[1], a2 = lp[2];
+                t0 = make_float4(a0.x, a0.y, a0.z, a0.w); t1 = make_float4(a1.x, a1.y, a1.z, a1.w); t2 = make_float4(a2.x, a2.y, a2.z, a2.w);
+              } else
               if (PREFETCH) {
                 t0 = n0; t1 = n1; t2 = n2;
                 if (i + 1u < triCount) { const float4* tn = sc.tri_w + (size_t)(triIdx + 1u) * 3; n0 = tn[0]; n1 = tn[1]; n2 = tn[2]; }
