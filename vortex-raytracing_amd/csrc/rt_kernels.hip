@@ -385,6 +385,46 @@ __device__ __forceinline__ void generate_ray(float u, float v,
   dx = vx * inv; dy = vy * inv; dz = vz * inv;
 }
 
+__device__ __forceinline__ uint32_t wang_hash(uint32_t s) {   // common.h:129-135
+  s = (s ^ 61u) ^ (s >> 16);
+  s *= 9u; s = s ^ (s >> 4);
+  s *= 0x27d4eb2du;
+  s = s ^ (s >> 15);
+  return s;
+}
+__device__ __forceinline__ float random_float(uint32_t& s) {   // common.h:137-147
+  s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+  return (float)s * 2.3283064365387e-10f;
+}
+
+// The occlusion / bounce ray of sample `smp` of pixel (x, y) leaving the hit point I with shading normal N (view direction vd), as
+// oracle/rt_oracle.c:orc_ao_ray defines it, operation by operation: o = I + N' * 1e-3, d = cosine-weighted about the normal N'
+// that faces the viewer (rejection-sampled disk, Duff et al. basis; only IEEE add / mul / div / sqrt).
+__device__ __forceinline__ void ao_sample_ray(uint32_t x, uint32_t y, uint32_t W, uint32_t spp, uint32_t smp, uint32_t user_seed,
+                                              float Ix, float Iy, float Iz, float nx, float ny, float nz, float vdx, float vdy, float vdz, float* o6) {
+  uint32_t seed = wang_hash((x + y * W) * spp + smp + 1u + user_seed * 0x9E3779B9u);
+  if (seed == 0u) seed = 1u;
+  float u = 0.0f, v = 0.0f, r2 = 0.0f;
+  bool ok = false;
+  for (int k = 0; k < 8 && !ok; ++k) {
+    const float a = 2.0f * random_float(seed) - 1.0f;
+    const float b = 2.0f * random_float(seed) - 1.0f;
+    const float q = a * a + b * b;
+    if (q < 1.0f) { u = a; v = b; r2 = q; ok = true; }
+  }
+  const float z = sqrtf(1.0f - r2);
+  if (nx * vdx + ny * vdy + nz * vdz > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+  const float sign = nz >= 0.0f ? 1.0f : -1.0f;
+  const float a = -1.0f / (sign + nz);
+  const float b = nx * ny * a;
+  const float tx = 1.0f + sign * nx * nx * a, ty = sign * b, tz = -sign * nx;
+  const float bx = b, by = sign + ny * ny * a, bz = -ny;
+  o6[0] = Ix + nx * 0.001f; o6[1] = Iy + ny * 0.001f; o6[2] = Iz + nz * 0.001f;
+  o6[3] = tx * u + bx * v + nx * z;
+  o6[4] = ty * u + by * v + ny * z;
+  o6[5] = tz * u + bz * v + nz * z;
+}
+
 #ifndef RT_TRI_PREFETCH
 #define RT_TRI_PREFETCH 1
 #endif
@@ -499,7 +539,22 @@ __device__ __forceinline__ void generate_ray(float u, float v,
 #define RT_TOP_MAX 1024
 static_assert(RT_TOP_NODES <= RT_TOP_MAX, "top-of-tree image");
 
-enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2 };
+enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2, JOB_RENDER_GI = 3 };
+// JOB_RENDER_GI: the whole "one diffuse bounce" frame (BASELINE configs[2] as worded; recipe: oracle/rt_oracle.c:orc_render_gi) in ONE
+// persistent launch -- a lane traces its pixel's primary ray, shades the hit (closest.cpp's else arm), draws the pixel's bounce ray
+// (ao_sample_ray, sample 0 of 1), traces it for its closest hit in the same lane, shades that hit and writes the pixel:
+// colour = Lambert(primary) + albedo(primary) * Lambert(bounce hit | background).  Before, the frame was a primary launch, a pass that
+// listed the hit pixels, a ray-generation pass, a 2 M-ray trace launch (a short launch with a long tail: 0.61 of the frame's 1.17 ms),
+// an accumulation pass and a final pass.
+#ifndef RT_WAVES_GI
+#define RT_WAVES_GI 6
+#endif
+#ifndef RT_LDS_STACK_GI
+#define RT_LDS_STACK_GI 8
+#endif
+#ifndef RT_GI_DEAD_MAX
+#define RT_GI_DEAD_MAX 64    // (lanes refilled one by one: 16 -> 1.50 ms, 32 -> 1.45, 8 -> 1.72 against 1.18 with whole tiles: profiles/r03_f_gi_fused_ab.txt)
+#endif
 
 // -DRT_ISA_MARKS: comment-only markers in the listing (hipcc -S) that delimit the regions of the traversal loop for
 // tools/isa_regions.py; never set for a build that is run
@@ -547,6 +602,8 @@ struct PersistArgs {
   // batch of frames in one launch (vxrt_render_interleaved_batch): the window's tiles repeat `frame_tiles` apart, frame f = tile /
   // frame_tiles is shaded and lit with pbatch[f]; nullptr = one frame
   const ShadeParams* pbatch; uint32_t frame_tiles;
+  // JOB_RENDER_GI: the frame itself (pixel (x, y) at dst[x + y * W]), optional f32 colours, seed of the bounce rays
+  uint32_t* dst; float* colors; uint32_t gi_seed;
 };
 
 // Domain of the fast (non-EXACT) traversal: every component of 1/d finite, non-zero and at most 2^64 in magnitude, every origin
@@ -606,16 +663,17 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 // per SIMD (64 VGPRs, 5 stack levels in LDS) instead of 7 -- +1.6 % there, where many tiles per wavefront hide the few spilled
 // registers, and -8 % on a serial frame, which keeps 7 (profiles/r03_c_flag_variants.txt)
 template <int JOB, int STATS, bool LDEXP, bool EXACT, bool PACKED = false>
-__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JOB_TRACE ? RT_WAVES_TRACE : (PACKED ? RT_WAVES_RENDER_PACKED : RT_WAVES_RENDER))) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JOB_TRACE ? RT_WAVES_TRACE : (JOB == JOB_RENDER_GI ? RT_WAVES_GI : (PACKED ? RT_WAVES_RENDER_PACKED : RT_WAVES_RENDER)))) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
   // stack levels in LDS: what the instantiation's occupancy leaves room for (160 KB per CU)
-  constexpr int LSTK = EXACT ? LDS_STACK : (JOB == JOB_TRACE ? RT_LDS_STACK_TRACE : (PACKED ? RT_LDS_STACK_RENDER_PACKED : RT_LDS_STACK_RENDER));
+  constexpr int LSTK = EXACT ? LDS_STACK : (JOB == JOB_TRACE ? RT_LDS_STACK_TRACE : (JOB == JOB_RENDER_GI ? RT_LDS_STACK_GI : (PACKED ? RT_LDS_STACK_RENDER_PACKED : RT_LDS_STACK_RENDER)));
   constexpr int WG_WAVES = EXACT ? 4 : RT_WG_WAVES;
   constexpr bool USE_TOP = RT_TOP_NODES > 0 && !EXACT && !LDEXP;   // (the ldexp decode reads exponents from the reference node by index)
   // V2 node step: only where every slab value is finite (bounded scene -- checked by the accel build, which selects the LDEXP
   // instantiation otherwise -- and rays inside the bounds checked in start_ray / enter_instance), so that the sign of a float
   // difference IS the comparison
   constexpr bool V2 = RT_NODE_V2 && !EXACT && !LDEXP;
-  constexpr uint32_t DEAD_MAX = JOB == JOB_TRACE ? RT_TRACE_DEAD_MAX : RT_DEAD_MAX;
+  // (JOB_RENDER_GI: the bounce rays of a tile are incoherent -- a lane whose pixel is finished takes the next pixel, as ray buffers do)
+  constexpr uint32_t DEAD_MAX = JOB == JOB_TRACE ? RT_TRACE_DEAD_MAX : (JOB == JOB_RENDER_GI ? RT_GI_DEAD_MAX : RT_DEAD_MAX);
   // render-with-shadow jobs: retire finished primary rays (their lanes continue with the occlusion ray
   // of the same pixel - same traversal code, so no phase mixing) before the whole tile is done
   constexpr uint32_t FINISH_MIN = JOB == JOB_RENDER_SHADOW ? RT_SHADOW_FINISH_MIN : 65u;
@@ -663,6 +721,8 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   float arx = 0, ary = 0, arz = 0, aix = 0, aiy = 0, aiz = 0;   // active ray: origin, 1/direction
   float hitd = 0, path_m = 0, tos_m = 0;
   uint32_t cur = DESC_IDLE, tos_d = DESC_DONE, job = 0, flags = 0;
+  // JOB_RENDER_GI: colour and albedo of the pixel's primary hit and the pixel's bounce ray (world space), kept while that ray is traced
+  float g_col[3] = {0.f, 0.f, 0.f}, g_alb[3] = {0.f, 0.f, 0.f}, g_ray[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int sp = 0;                     // V2: entries on the stack; else: entries below the register top (LDS, then scratch)
   // V2 keeps the stack as two planes in the same LDS block (descriptors, then path maxima): rank-addressed scatter writes need no
   // register pairs, and there is no register-cached top to shuffle
@@ -703,6 +763,9 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
       uint32_t x, y;
       pixel_of(job, x, y);
       generate_ray(A.utab[x], A.vtab[y], ox, oy, oz, dx, dy, dz);
+      if (JOB == JOB_RENDER_GI && (flags & F_SHADOW)) {   // bounce phase: the ray drawn when the primary ray finished
+        ox = g_ray[0]; oy = g_ray[1]; oz = g_ray[2]; dx = g_ray[3]; dy = g_ray[4]; dz = g_ray[5];
+      }
       if (JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW)) {
         const float pd = __uint_as_float(CTX(5));   // distance of this pixel's primary hit
         float sox, soy, soz, sdx, sdy, sdz, sdist;
@@ -717,7 +780,10 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   // main launch only: hand this lane's ray (in its current phase) over to the EXACT launch
   auto defer = [&](bool counted) {
     const uint32_t slot = atomicAdd(A.defer_count, 1u);
-    if (slot < A.defer_cap) A.defer_list[slot] = job | ((flags & F_SHADOW) ? 0x80000000u : 0u);
+    // (JOB_RENDER_GI: a bounce ray outside the fast domain sends the whole PIXEL to the EXACT launch, which traces its primary ray again
+    // -- same hit by construction -- and goes on from there; the primary ray this launch counted is taken back)
+    if (JOB == JOB_RENDER_GI && (flags & F_SHADOW)) nrays--;
+    if (slot < A.defer_cap) A.defer_list[slot] = job | ((flags & F_SHADOW) && JOB != JOB_RENDER_GI ? 0x80000000u : 0u);
     if (JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW)) {
       // the EXACT launch resumes this pixel's occlusion ray from the primary hit record in memory
       HitRec h;
@@ -1239,6 +1305,47 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
         }
         A.hits[job] = h;
         cur = DESC_IDLE;
+      } else if (JOB == JOB_RENDER_GI) {
+        // one diffuse bounce, in the lane (see JOB_RENDER_GI above).  Every step is the code of the pass it replaces:
+        // rt_ao_prepare_kernel (colour / albedo / hit point / normal of the primary hit), rt_ao_rays_kernel (the bounce ray),
+        // rt_gi_accumulate_kernel + rt_gi_final_kernel (shade the bounce hit, colour += albedo * that, pack).
+        uint32_t x, y;
+        pixel_of(job, x, y);
+        const size_t e = (size_t)x + (size_t)y * A.W;
+        bool write = false;
+        float cr = 0.f, cg = 0.f, cb = 0.f;
+        if (found) {
+          h.dist = hitd; h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;
+          h.blasIdx = CTX(6); h.triIdx = CTX(7);
+        }
+        if (!(flags & F_SHADOW)) {
+          float ox, oy, oz, dx, dy, dz;
+          generate_ray(A.utab[x], A.vtab[y], ox, oy, oz, dx, dy, dz);
+          if (!found) {
+            cr = p.bg[0]; cg = p.bg[1]; cb = p.bg[2];   // miss.cpp:9-14; no bounce
+            write = true;
+          } else {
+            float r, g, b, refl, Ix, Iy, Iz, Nx, Ny, Nz, a3[3];
+            shade_terms<false>(sc, p, ox, oy, oz, dx, dy, dz, h, false, r, g, b, refl, Ix, Iy, Iz, Nx, Ny, Nz, nullptr, a3);
+            float thr = 1.0f;
+            thr *= refl;
+            g_col[0] = r + p.bg[0] * thr; g_col[1] = g + p.bg[1] * thr; g_col[2] = b + p.bg[2] * thr;
+            g_alb[0] = a3[0]; g_alb[1] = a3[1]; g_alb[2] = a3[2];
+            ao_sample_ray(x, y, A.W, 1u, 0u, A.gi_seed, Ix, Iy, Iz, Nx, Ny, Nz, dx, dy, dz, g_ray);
+            flags = F_SHADOW;       // (second phase of the pixel)
+            start_ray(g_ray[0], g_ray[1], g_ray[2], g_ray[3], g_ray[4], g_ray[5], RT_LARGE_FLOAT, false);
+          }
+        } else {
+          float r, g, b;
+          shade_eval<false>(sc, p, g_ray[0], g_ray[1], g_ray[2], g_ray[3], g_ray[4], g_ray[5], h, found, false, r, g, b);
+          cr = g_col[0] + g_alb[0] * r; cg = g_col[1] + g_alb[1] * g; cb = g_col[2] + g_alb[2] * b;
+          write = true;
+        }
+        if (write) {
+          A.dst[e] = pack_rgb8(cr, cg, cb);
+          if (A.colors) { A.colors[3 * e] = cr; A.colors[3 * e + 1] = cg; A.colors[3 * e + 2] = cb; }
+          cur = DESC_IDLE;
+        }
       } else if (!(flags & F_SHADOW)) {
         // deferred shading: finishing a ray costs one store, not a chain of dependent loads
         if (STATS && found) nhit++;
@@ -1526,18 +1633,6 @@ __global__ __launch_bounds__(256) void rt_bounce_unwind_kernel(uint32_t n, const
 // mirrored here operation by operation -- RNG of common.h:129-147, rejection-sampled disk, Duff basis:
 // only IEEE add/mul/div/sqrt, so host and device produce the same rays).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wang_hash(uint32_t s) {   // common.h:129-135
-  s = (s ^ 61u) ^ (s >> 16);
-  s *= 9u; s = s ^ (s >> 4);
-  s *= 0x27d4eb2du;
-  s = s ^ (s >> 15);
-  return s;
-}
-__device__ __forceinline__ float random_float(uint32_t& s) {   // common.h:137-147
-  s ^= s << 13; s ^= s >> 17; s ^= s << 5;
-  return (float)s * 2.3283064365387e-10f;
-}
-
 // per pixel of rows [y0,y1): Lambert colour of the primary hit (else arm of closest.cpp), hit point and
 // shading normal for the occlusion rays; geo[t] = (I, hit?), nrm[t] = (N, 0), col[t] = (rgb, 0), cnt[t] = 0;
 // pixels with a hit are appended to list[] (count in hdr[0]; the order is arbitrary, nothing depends on it)
@@ -1615,29 +1710,11 @@ __global__ __launch_bounds__(256) void rt_ao_rays_kernel(uint64_t cap, uint32_t 
   const uint32_t x = t % W, y = y0 + t / W;
   float ox, oy, oz, vdx, vdy, vdz;
   generate_ray(utab[x], vtab[y], ox, oy, oz, vdx, vdy, vdz);
-  uint32_t seed = wang_hash((x + y * W) * spp + smp + 1u + user_seed * 0x9E3779B9u);
-  if (seed == 0u) seed = 1u;
-  float u = 0.0f, v = 0.0f, r2 = 0.0f;
-  bool ok = false;
-  for (int k = 0; k < 8 && !ok; ++k) {
-    const float a = 2.0f * random_float(seed) - 1.0f;
-    const float b = 2.0f * random_float(seed) - 1.0f;
-    const float q = a * a + b * b;
-    if (q < 1.0f) { u = a; v = b; r2 = q; ok = true; }
-  }
-  const float z = sqrtf(1.0f - r2);
   const float4 gN = nrm[t];
-  float nx = gN.x, ny = gN.y, nz = gN.z;
-  if (nx * vdx + ny * vdy + nz * vdz > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
-  const float sign = nz >= 0.0f ? 1.0f : -1.0f;
-  const float a = -1.0f / (sign + nz);
-  const float b = nx * ny * a;
-  const float tx = 1.0f + sign * nx * nx * a, ty = sign * b, tz = -sign * nx;
-  const float bx = b, by = sign + ny * ny * a, bz = -ny;
-  o[0] = gI.x + nx * 0.001f; o[1] = gI.y + ny * 0.001f; o[2] = gI.z + nz * 0.001f;
-  o[3] = tx * u + bx * v + nx * z;
-  o[4] = ty * u + by * v + ny * z;
-  o[5] = tz * u + bz * v + nz * z;
+  float r6[6];
+  ao_sample_ray(x, y, W, spp, smp, user_seed, gI.x, gI.y, gI.z, gN.x, gN.y, gN.z, vdx, vdy, vdz, r6);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o[k] = r6[k];
   tmax[i] = radius;
 }
 
@@ -2647,6 +2724,16 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false, PK>), dim3(MAIN_GRID((rt_persistent_kernel<J, ST, LD, false, PK>))), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, s, sc, p, X); } while (0)
 #define LAUNCH_PD(J, ST, PK) do { if (sc.exact_decode) LAUNCH_P(J, ST, true, PK); else LAUNCH_P(J, ST, false, PK); } while (0)
+  // one diffuse bounce: the whole frame in the persistent launches (JOB_RENDER_GI); VXRT_GI_FUSED=0 keeps the multi-pass form (same
+  // pixels: tests/test_gpu_configs.py compares them; A/B knob)
+  static const bool gi_fused_on = [] { const char* e = getenv("VXRT_GI_FUSED"); return !(e && e[0] == '0'); }();
+  const bool gi_fused = gi_fused_on && ao && ao->reserved == VXRT_AO_MODE_DIFFUSE_BOUNCE && !stats && !shadow && !unoccluded;
+  if (gi_fused) {
+    A.dst = dst; A.colors = colors; A.gi_seed = ao->seed;
+    X.dst = dst; X.colors = colors; X.gi_seed = ao->seed;
+    X0.dst = dst; X0.colors = colors; X0.gi_seed = ao->seed;
+    LAUNCH_PD(JOB_RENDER_GI, 0, false);
+  } else
   if (stats == 2)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 2, false); else LAUNCH_PD(JOB_RENDER, 2, false); }
   else if (stats)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 1, false); else LAUNCH_PD(JOB_RENDER, 1, false); }
   else if (packed) { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 0, true); else LAUNCH_PD(JOB_RENDER, 0, true); }
@@ -2659,6 +2746,11 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   if (lpt && !lpt_sort) c->lpt_valid = false;
   if (side_launch) {
     if (hipEventRecord(c->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, c->ev_side, 0) != hipSuccess) return fail();
+  }
+  if (gi_fused) {
+    // nothing follows: the pixels are written.  The control block stays as the launches left it; the context's next call clears it.
+    if (hipGetLastError() != hipSuccess) return fail();
+    return release_ctx(c, s);
   }
   if (ao) {
     if (render_ao_tail(a, c, p, width, y0, y1, ao, A.utab, A.vtab, dst, colors, unoccluded, counters, s) != 0) return fail();
