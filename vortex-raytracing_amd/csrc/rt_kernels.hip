@@ -547,10 +547,10 @@ enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2, JOB_RENDER_GI = 3 }
 // listed the hit pixels, a ray-generation pass, a 2 M-ray trace launch (a short launch with a long tail: 0.61 of the frame's 1.17 ms),
 // an accumulation pass and a final pass.
 #ifndef RT_WAVES_GI
-#define RT_WAVES_GI 6
+#define RT_WAVES_GI 7
 #endif
 #ifndef RT_LDS_STACK_GI
-#define RT_LDS_STACK_GI 8
+#define RT_LDS_STACK_GI 6
 #endif
 #ifndef RT_GI_DEAD_MAX
 #define RT_GI_DEAD_MAX 64    // (lanes refilled one by one: 16 -> 1.50 ms, 32 -> 1.45, 8 -> 1.72 against 1.18 with whole tiles: profiles/r03_f_gi_fused_ab.txt)
