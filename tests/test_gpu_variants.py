@@ -1,0 +1,35 @@
+"""GPU: the two LDS-staging variants north_star prescribes -- the top of the tree (-DRT_TOP_NODES) and the triangles of the leaf most
+lanes hold (-DRT_TRI_LDS) staged through LDS -- lost their A/B (profiles/r02_b_lds_top_counters.txt, profiles/r03_e_tri_lds.txt) and are
+compiled out of the shipped library.  So that the code behind the flags cannot rot, this test builds a library with BOTH switched on
+(hipcc, ~40 s) and runs the reference-fixture parity tests and a frame against the oracle on it, in a child process that loads the
+variant through VXRT_LIB_DIR."""
+import importlib
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FLAGS = ["-DRT_TOP_NODES=84", "-DRT_LDS_STACK_RENDER=5", "-DRT_LDS_STACK_RENDER_PACKED=4", "-DRT_TRI_LDS=4", "-DRT_TRI_LDS_MIN=2"]
+
+
+def test_lds_staging_variants_stay_bit_equal(vrt, gpu_device):
+    bld = importlib.import_module("vortex-raytracing_amd.build")
+    if not os.path.exists(bld.HIPCC):
+        pytest.skip("hipcc not installed on this box")
+    d = os.path.join(bld.HERE, "lib_ab", "lds_staging")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, "libvortex-hip.so")
+    src = [os.path.join(bld.CSRC, f) for f in bld.PRODUCT_HIP_SOURCES]
+    if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in src):
+        subprocess.run([bld.HIPCC] + bld.HIP_FLAGS + FLAGS + ["-shared", "-o", so] + src, check=True, timeout=900)
+    for f in ("libvortex.so", "libvxrt_scene.so"):
+        shutil.copy2(os.path.join(bld.LIB, f), os.path.join(d, f))
+    env = dict(os.environ, VXRT_LIB_DIR=d, VXRT_DEBUG="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-k",
+                        "reference_fixture or render_matches_oracle or shadow_rays_extension"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
+    assert " passed" in r.stdout and "top-of-tree nodes staged" in (r.stdout + r.stderr)     # the variant library is the one that ran

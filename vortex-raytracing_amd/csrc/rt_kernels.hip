@@ -470,24 +470,6 @@ __device__ __forceinline__ void ao_sample_ray(uint32_t x, uint32_t y, uint32_t W
 #ifndef RT_TRACE_DEAD_MAX
 #define RT_TRACE_DEAD_MAX 16   // ray-buffer jobs (incoherent rays): refill early
 #endif
-#ifndef RT_QUEUE_PREFETCH
-#define RT_QUEUE_PREFETCH 0   // 1: a wavefront reserves its next tile while it traces the current one (hides the queue atomic's round trip)
-#endif
-#ifndef RT_WAVE_PRIO
-#define RT_WAVE_PRIO 0
-#endif
-#ifndef RT_PERTURB_VALU
-#define RT_PERTURB_VALU 0
-#endif
-#ifndef RT_PERTURB_SLEEP
-#define RT_PERTURB_SLEEP 0
-#endif
-#ifndef RT_PUSH_FAST
-#define RT_PUSH_FAST 0      // 1: wave-uniform LDS-only push path of the node step (fewer branches; measured +0.2 %: not worth the code)
-#endif
-#ifndef RT_TRI_STEP
-#define RT_TRI_STEP 0       // 1: inlined leaves are tested one triangle per loop iteration
-#endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 64         // jobs reserved per global atomic (one 8x8 tile)
 #endif
@@ -525,10 +507,6 @@ __device__ __forceinline__ void ao_sample_ray(uint32_t x, uint32_t y, uint32_t W
 #ifndef LDS_STACK
 #define LDS_STACK 8         // stack levels kept in LDS per lane (4 KiB per wavefront); deeper ones go to scratch
 #endif
-#ifndef RT_NODE_V2
-#define RT_NODE_V2 0        // 1: alternative node step (children ranked by float subtraction + sign shift and scattered to the LDS stack by
-#endif                      // rank instead of a compare/select sorting network + register-cached stack top).  Bit-equal results (all GPU
-                            // tests pass with it); measured 2.5 % SLOWER (profiles/r02_c_node_v2.txt), so off: DESIGN.md s5
 #ifndef RT_WG_WAVES
 #define RT_WG_WAVES 4       // wavefronts per workgroup of the persistent kernels (the staged top of the tree is shared by them)
 #endif
@@ -617,22 +595,6 @@ __device__ __forceinline__ bool ray_in_fast_domain(float ox, float oy, float oz,
          fabsf(ox) <= RT_FAST_POS_MAX && fabsf(oy) <= RT_FAST_POS_MAX && fabsf(oz) <= RT_FAST_POS_MAX;
 }
 
-// V2 node step, slab test of child K on sign-selected plane words (nw = near x, y, z; fw = far x, y, z; one byte per child):
-// the arithmetic of child_box's fast form, returning both interval ends.
-template <int K>
-__device__ __forceinline__ void child_slab(const uint32_t* nw, const uint32_t* fw, float px, float py, float pz, float sx, float sy, float sz,
-                                           float rox, float roy, float roz, float rix, float riy, float riz, float& tmin, float& tmax) {
-  const float ax = __fmaf_rn(qbyte<K>(nw[0]), sx, px), ay = __fmaf_rn(qbyte<K>(nw[1]), sy, py), az = __fmaf_rn(qbyte<K>(nw[2]), sz, pz);
-  const float bx = __fmaf_rn(qbyte<K>(fw[0]), sx, px), by = __fmaf_rn(qbyte<K>(fw[1]), sy, py), bz = __fmaf_rn(qbyte<K>(fw[2]), sz, pz);
-  const float tx1 = (ax - rox) * rix, tx2 = (bx - rox) * rix;
-  const float ty1 = (ay - roy) * riy, ty2 = (by - roy) * riy;
-  const float tz1 = (az - roz) * riz, tz2 = (bz - roz) * riz;
-  tmin = fmaxf(fmaxf(tx1, ty1), tz1);
-  tmax = fminf(fminf(tx2, ty2), tz2);
-}
-// -1 if a < b else 0, for finite a, b (and a or b = +inf, not both): the sign of the float difference -- two full-rate VALU
-// instructions (v_sub_f32, v_ashrrev_i32) where a compare + select takes two half-rate ones (profiles/r02_valu_calibration.txt)
-__device__ __forceinline__ int lt_mask(float a, float b) { return __float_as_int(a - b) >> 31; }
 // max of two values neither of which is a NaN: one v_max_f32 (fmaxf adds a canonicalising v_max_f32 x, x for a signalling NaN the
 // compiler cannot rule out)
 __device__ __forceinline__ float vmax_nonan(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -647,7 +609,6 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 #define F_ANYHIT 2u
 #define F_SHADOW 8u      // render job is in its occlusion-ray phase
 #define F_WORLD 16u      // the active ray registers hold the world-space ray (TLAS level)
-#define F_INLEAF 64u     // RT_TRI_STEP, counting builds: `cur` is the rest of a leaf already entered
 #define F_RESUMED 32u    // EXACT launch: occlusion ray handed over by the main launch (its primary hit record is in memory)
 
 // Register budget is the lever here (profiles/r01_c_*: at 4 waves/SIMD the VALU pipe idles 58 % of
@@ -668,29 +629,11 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   constexpr int LSTK = EXACT ? LDS_STACK : (JOB == JOB_TRACE ? RT_LDS_STACK_TRACE : (JOB == JOB_RENDER_GI ? RT_LDS_STACK_GI : (PACKED ? RT_LDS_STACK_RENDER_PACKED : RT_LDS_STACK_RENDER)));
   constexpr int WG_WAVES = EXACT ? 4 : RT_WG_WAVES;
   constexpr bool USE_TOP = RT_TOP_NODES > 0 && !EXACT && !LDEXP;   // (the ldexp decode reads exponents from the reference node by index)
-  // V2 node step: only where every slab value is finite (bounded scene -- checked by the accel build, which selects the LDEXP
-  // instantiation otherwise -- and rays inside the bounds checked in start_ray / enter_instance), so that the sign of a float
-  // difference IS the comparison
-  constexpr bool V2 = RT_NODE_V2 && !EXACT && !LDEXP;
-  // (JOB_RENDER_GI: the bounce rays of a tile are incoherent -- a lane whose pixel is finished takes the next pixel, as ray buffers do)
   constexpr uint32_t DEAD_MAX = JOB == JOB_TRACE ? RT_TRACE_DEAD_MAX : (JOB == JOB_RENDER_GI ? RT_GI_DEAD_MAX : RT_DEAD_MAX);
   // render-with-shadow jobs: retire finished primary rays (their lanes continue with the occlusion ray
   // of the same pixel - same traversal code, so no phase mixing) before the whole tile is done
   constexpr uint32_t FINISH_MIN = JOB == JOB_RENDER_SHADOW ? RT_SHADOW_FINISH_MIN : 65u;
   const uint32_t lane = threadIdx.x & 63u;
-#if RT_WAVE_PRIO > 0
-  // distinct issue priorities for the wavefronts that share a SIMD (one from each of the CU's resident workgroups, which the dispatcher
-  // hands out 256 apart): with equal priorities the wavefronts of a SIMD fall into step -- all computing, then all waiting
-  if (!EXACT) {
-    const uint32_t pr = RT_WAVE_PRIO == 1 ? (blockIdx.x >> 8) & 3u : (RT_WAVE_PRIO == 2 ? blockIdx.x & 3u : ((blockIdx.x >> 8) & 1u) * 3u);
-    switch (pr) {   // (s_setprio takes an immediate)
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      case 3: __builtin_amdgcn_s_setprio(3); break;
-      default: __builtin_amdgcn_s_setprio(0); break;
-    }
-  }
-#endif
   // EXACT launch: the jobs are the entries of the deferral list the main launch left behind
   const uint32_t n_jobs = EXACT ? min(*A.defer_count, A.defer_cap) : (A.total_dev ? min(*A.total_dev, A.total) : A.total);
   const uint32_t per_shard = (EXACT || A.total_dev) ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
@@ -723,18 +666,13 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   uint32_t cur = DESC_IDLE, tos_d = DESC_DONE, job = 0, flags = 0;
   // JOB_RENDER_GI: colour and albedo of the pixel's primary hit and the pixel's bounce ray (world space), kept while that ray is traced
   float g_col[3] = {0.f, 0.f, 0.f}, g_alb[3] = {0.f, 0.f, 0.f}, g_ray[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int sp = 0;                     // V2: entries on the stack; else: entries below the register top (LDS, then scratch)
-  // V2 keeps the stack as two planes in the same LDS block (descriptors, then path maxima): rank-addressed scatter writes need no
-  // register pairs, and there is no register-cached top to shuffle
-  uint32_t* const stk_d = (uint32_t*)&s_stk[threadIdx.x >> 6][0][0] + lane;
-  float* const stk_m = (float*)stk_d + LSTK * 64;
+  int sp = 0;                     // entries below the register top (LDS, then scratch)
   uint32_t ovf_d[RT_STACK_ENTRIES];
   float ovf_m[RT_STACK_ENTRIES];
   // wave-uniform job-queue state
   bool queue_empty = false;
   uint32_t shard = blockIdx.x % QUEUE_SHARDS;   // blocks b and b+8 share an XCD (observed dispatch order; speed only)
   uint32_t tries = 0, loc_next = 0, loc_end = 0;
-  uint32_t pref_base = 0; bool pref_valid = false;   // RT_QUEUE_PREFETCH: queue position reserved ahead (lane 0), for the current shard
   uint32_t loc_off = 0;           // job id = queue position + loc_off (tile order indirection of render jobs)
   uint32_t lpt_tile = 0xFFFFFFFFu; unsigned long long lpt_t0 = 0;   // tile being timed for A.tile_cost
   Fetches fx;
@@ -842,12 +780,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   // (the scratch part of the stack through volatile pointers: the compiler must not speculate its loads into the common path)
   volatile uint32_t* const vovf_d = ovf_d;
   volatile float* const vovf_m = ovf_m;
-  auto stk_write = [&](int slot, uint32_t d, float m) {   // V2, general form
-    if (slot < LSTK) { stk_d[slot * 64] = d; stk_m[slot * 64] = m; }
-    else { vovf_d[slot - LSTK] = d; vovf_m[slot - LSTK] = m; }
-  };
   auto push = [&](uint32_t d, float m) {
-    if (V2) { stk_write(sp, d, m); ++sp; return; }
     if (tos_d != DESC_DONE) {
       if (sp < LSTK) lstk[sp * 64] = make_uint2(tos_d, __float_as_uint(tos_m));
       else { ovf_d[sp - LSTK] = tos_d; ovf_m[sp - LSTK] = tos_m; }
@@ -855,33 +788,10 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     }
     tos_d = d; tos_m = m;
   };
-  auto push_lds = [&](uint32_t d, float m) {   // caller: sp < LSTK for this lane
-    if (tos_d != DESC_DONE) { lstk[sp * 64] = make_uint2(tos_d, __float_as_uint(tos_m)); ++sp; }
-    tos_d = d; tos_m = m;
-  };
   // next pending work item of this lane (m < hit.dist: the reference's re-filtering),
   // or DESC_DONE when its stack is exhausted.  The refill of the register top from LDS is not waited for.
   auto pop_next = [&]() {
     cur = DESC_DONE;
-    if (V2) {
-      if (!__any(sp > LSTK)) {   // wave-uniform: every entry any lane can pop is in LDS (the common case by far)
-        while (sp > 0) {
-          --sp;
-          const uint32_t d = stk_d[sp * 64];
-          const float m = stk_m[sp * 64];
-          if (m < hitd) { cur = d; path_m = m; break; }
-        }
-        return;
-      }
-      while (sp > 0) {
-        --sp;
-        uint32_t d; float m;
-        if (sp < LSTK) { d = stk_d[sp * 64]; m = stk_m[sp * 64]; }
-        else { d = vovf_d[sp - LSTK]; m = vovf_m[sp - LSTK]; }
-        if (m < hitd) { cur = d; path_m = m; break; }
-      }
-      return;
-    }
     while (tos_d != DESC_DONE) {
       const uint32_t d = tos_d;
       const float m = tos_m;
@@ -919,20 +829,10 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             if (!in_range) { shard = (shard + 1u) % QUEUE_SHARDS; ++tries; continue; }
             const uint32_t s_n = min(per_shard, n_jobs - s_lo);
             uint32_t base = 0;
-            if (RT_QUEUE_PREFETCH && !EXACT && JOB != JOB_TRACE && pref_valid) {
-              base = pref_base;          // reserved while the previous tile was being traced: its round trip is long over
-              pref_valid = false;
-            } else {
-              if (lane == 0) base = atomicAdd(A.queue + shard * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
-            }
+            if (lane == 0) base = atomicAdd(A.queue + shard * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
             base = __shfl(base, 0);
             if (base < s_n) {
               loc_next = s_lo + base; loc_end = s_lo + min(base + (uint32_t)RT_CHUNK, s_n);
-              if (RT_QUEUE_PREFETCH && !EXACT && JOB != JOB_TRACE) {
-                // reserve this wavefront's NEXT tile of the shard now; the returned position is first read at the next fetch
-                if (lane == 0) pref_base = atomicAdd(A.queue + shard * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
-                pref_valid = true;
-              }
               if (JOB != JOB_TRACE && !EXACT && (A.tile_order || A.tile_cost)) {   // one chunk = one 8x8 tile
                 const uint32_t pos = loc_next >> 6;
                 const uint32_t tile = A.tile_order ? A.tile_order[pos] : pos;
@@ -947,7 +847,6 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             }
             shard = (shard + 1u) % QUEUE_SHARDS;
             ++tries;
-            pref_valid = false;   // (a reservation past the shard's end was consumed above; the next shard starts without one)
           }
           if (tries >= QUEUE_SHARDS) queue_empty = true;
         }
@@ -1030,91 +929,9 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           const uint4* np = sc.nodes_c + (size_t)ni * CNODE_VEC4;
           q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
         }
-#if RT_PERTURB_VALU > 0
-        // perturbation experiment (tools/ab_quick.sh): extra independent full-rate VALU work per node step
-        { float pa = arx, pb = ary;
-#pragma unroll
-          for (int k = 0; k < RT_PERTURB_VALU / 2; ++k) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(pa) : "v"(aix)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(pb) : "v"(aiy)); }
-          asm volatile("" :: "v"(pa), "v"(pb)); }
-#endif
         const uint32_t* ref_node = nullptr;
         if (LDEXP) ref_node = top ? sc.ref_tlas + (size_t)ni * RT_NODE_DWORDS : sc.ref_bvh + (size_t)(ni - sc.n_tlas) * RT_NODE_DWORDS;
         if (STATS) fx.node++;
-        if (V2) {
-          // ---- V2 node step.  Same values as eval_children's fast form, then:
-          //  * D_k = entry distance of child k, +inf if it is not to be visited (rt_traversal.cpp:60,71 and :338)
-          //  * r_k = how many children are visited before child k: near to far, equal distance -> higher index first (the order
-          //    of the far-to-near std::sort of :76-78 read from the back).  From the sign of the six pairwise differences.
-          //  * all children to visit go to the stack at sp + (n - 1 - r_k), the nearest on top, and the top is popped.
-          const float px = __uint_as_float(q0.x), py = __uint_as_float(q0.y), pz = __uint_as_float(q0.z);
-          const float sx = __uint_as_float(q0.w), sy = __uint_as_float(q3.z), sz = __uint_as_float(q3.w);
-          // near / far plane words by the sign of 1/d: swap lo and hi where the mask is all ones (xor swap, full-rate VALU)
-          const uint32_t mx = (uint32_t)(__float_as_int(aix) >> 31), my = (uint32_t)(__float_as_int(aiy) >> 31), mz = (uint32_t)(__float_as_int(aiz) >> 31);
-          const uint32_t dxw = (q1.x ^ q1.w) & mx, dyw = (q1.y ^ q2.x) & my, dzw = (q1.z ^ q2.y) & mz;
-          const uint32_t nw[3] = {q1.x ^ dxw, q1.y ^ dyw, q1.z ^ dzw};
-          const uint32_t fw[3] = {q1.w ^ dxw, q2.x ^ dyw, q2.y ^ dzw};
-          const uint32_t desc[4] = {q2.z, q2.w, q3.x, q3.y};
-          float tn[4], tf[4];
-          child_slab<0>(nw, fw, px, py, pz, sx, sy, sz, arx, ary, arz, aix, aiy, aiz, tn[0], tf[0]);
-          child_slab<1>(nw, fw, px, py, pz, sx, sy, sz, arx, ary, arz, aix, aiy, aiz, tn[1], tf[1]);
-          child_slab<2>(nw, fw, px, py, pz, sx, sy, sz, arx, ary, arz, aix, aiy, aiz, tn[2], tf[2]);
-          child_slab<3>(nw, fw, px, py, pz, sx, sy, sz, arx, ary, arz, aix, aiy, aiz, tn[3], tf[3]);
-          bool ok[4];
-          float D[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            ok[k] = !(tf[k] < tn[k] || tf[k] <= 0) && tn[k] < hitd && desc[k] != DESC_NONE;   // :327-338, :71, :60
-            D[k] = ok[k] ? tn[k] : __builtin_inff();
-          }
-          const int n = (int)ok[0] + (int)ok[1] + (int)ok[2] + (int)ok[3];
-          int r0, r1, r2, r3;
-          if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && STATS != 1 && __all((flags & F_ANYHIT) != 0u)) {
-            // occlusion rays of a frame only feed a boolean: any order reaches the same set of triangles, so children are taken in
-            // slot order (vxrt_trace's MODE_ANY, which returns the reference's FIRST accepted candidate, keeps the distance order)
-            r0 = 0; r1 = (int)ok[0]; r2 = r1 + (int)ok[1]; r3 = r2 + (int)ok[2];
-          } else {
-            // m_ij = -1 if child i is visited before child j (D_i < D_j), else 0 (D_j <= D_i: j first), i < j
-            const int m01 = lt_mask(D[0], D[1]), m02 = lt_mask(D[0], D[2]), m03 = lt_mask(D[0], D[3]);
-            const int m12 = lt_mask(D[1], D[2]), m13 = lt_mask(D[1], D[3]), m23 = lt_mask(D[2], D[3]);
-            r0 = 3 + m01 + m02 + m03;
-            r1 = 2 - m01 + m12 + m13;
-            r2 = 1 - m02 - m12 + m23;
-            r3 = 0 - m03 - m13 - m23;
-          }
-          if (!__any(sp + 4 > LSTK)) {
-            // common case, wave-uniform: four free LDS slots above every lane's stack.  ALL four children are written, without
-            // predication, to the distinct slots sp + ((n - 1 - r_k) & 3): a child to visit (r_k < n) lands at sp + (n - 1 - r_k), far
-            // ones first and the nearest on top; the others (r_k >= n) land above the new top, where nothing is live
-            const int tn = n - 1;
-            uint32_t* const wd = stk_d + sp * 64;
-            float* const wm = stk_m + sp * 64;
-            const int o0 = (tn - r0) & 3, o1 = (tn - r1) & 3, o2 = (tn - r2) & 3, o3 = (tn - r3) & 3;
-            wd[o0 * 64] = desc[0]; wm[o0 * 64] = vmax_nonan(path_m, D[0]);
-            wd[o1 * 64] = desc[1]; wm[o1 * 64] = vmax_nonan(path_m, D[1]);
-            wd[o2 * 64] = desc[2]; wm[o2 * 64] = vmax_nonan(path_m, D[2]);
-            wd[o3 * 64] = desc[3]; wm[o3 * 64] = vmax_nonan(path_m, D[3]);
-            if (n != 0) {
-              // the top is the nearest child, its m = max(path_m, D) < hit.dist by construction: continue with it
-              cur = wd[tn * 64]; path_m = wm[tn * 64];
-              sp += tn;
-            } else {
-              pop_next();
-            }
-          } else {
-            if (n != 0) {
-              if (sp + n > LSTK + RT_STACK_ENTRIES) atomicOr(A.status, STATUS_STACK_OVERFLOW);
-              else {
-                const int t = sp + n - 1;
-                if (ok[0]) stk_write(t - r0, desc[0], fmaxf(path_m, D[0]));
-                if (ok[1]) stk_write(t - r1, desc[1], fmaxf(path_m, D[1]));
-                if (ok[2]) stk_write(t - r2, desc[2], fmaxf(path_m, D[2]));
-                if (ok[3]) stk_write(t - r3, desc[3], fmaxf(path_m, D[3]));
-                sp += n;
-              }
-            }
-            pop_next();
-          }
-        } else {
         Cand c[4];
         eval_children<EXACT, LDEXP>(q0, q1, q2, q3, ref_node, arx, ary, arz, aix, aiy, aiz, hitd, c);
         if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && STATS != 1 && __all((flags & F_ANYHIT) != 0u)) {   // STATS keeps the reference's order, hence its fetch counts
@@ -1139,19 +956,6 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           order_children(c);   // valid children first (d < inf), nearest in c[0]
           // (path_m and the candidates' distances are never NaN -- a filtered child carries +inf -- so the maxima need no
           // canonicalising v_max x, x in front of them)
-          if (RT_PUSH_FAST && !V2 && !__any(sp + 3 > LSTK)) {
-            // wave-uniform common case: the three possible pushes of every lane stay inside the LDS part of its stack, so a push
-            // is "spill the register top to its LDS slot, take the new top" without the LDS / scratch split and its exec juggling
-            if (c[0].d < __builtin_inff()) {
-              if (c[3].d < __builtin_inff()) push_lds(c[3].desc, vmax_nonan(path_m, c[3].d));
-              if (c[2].d < __builtin_inff()) push_lds(c[2].desc, vmax_nonan(path_m, c[2].d));
-              if (c[1].d < __builtin_inff()) push_lds(c[1].desc, vmax_nonan(path_m, c[1].d));
-              cur = c[0].desc;
-              path_m = vmax_nonan(path_m, c[0].d);
-            } else {
-              pop_next();
-            }
-          } else
           if (c[0].d < __builtin_inff()) {
             bool more = true;
             if (sp + 4 > LSTK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
@@ -1165,14 +969,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             pop_next();
           }
         }
-        }   // !V2
       }
-#if RT_PERTURB_SLEEP > 0
-      // perturbation experiment: extra latency per loop iteration (64 clocks per unit) that uses no issue slot and overlaps no load:
-      // after the node step's results are in registers, before the next fetch is issued
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
-      __builtin_amdgcn_s_sleep(RT_PERTURB_SLEEP);
-#endif
       if (STATS && A.wave_log) { const unsigned long long t1 = __builtin_readcyclecounter(); wl_tn += t1 - wl_t0; wl_t0 = t1; }
       RT_MARK("inst");
       if (__any(is_inst_desc(cur))) {
@@ -1207,30 +1004,6 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           if (is_leaf_desc(cur)) {
             if (STATS) fx.node++;
             uint32_t leftFirst = cur & LEAF_FIRST_MASK, triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
-            if (RT_TRI_STEP && triCount != 0u) {
-              // one triangle per loop iteration: the lanes of a wavefront hold leaves of different sizes, and a loop over each
-              // lane's triangles runs as long as the largest one while the node lanes wait; stepping keeps `cur` = the rest of the
-              // leaf (first + 1, count - 1), so the next triangle is tested beside the other lanes' next node step
-              if (STATS && (flags & F_INLEAF)) fx.node--;   // (counted when the leaf was entered)
-              const float cdx = __uint_as_float(CTX(0)), cdy = __uint_as_float(CTX(1)), cdz = __uint_as_float(CTX(2));
-              const float4* tp = sc.tri_w + (size_t)leftFirst * 3;
-              const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-              if (STATS) fx.tri++;
-              float bx, by, bz;
-              const float d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
-              bool more = triCount > 1u, stop1 = false;
-              if (d < hitd) {
-                hitd = d;
-                flags |= F_FOUND;
-                if (!(JOB == JOB_RENDER_SHADOW && (flags & F_SHADOW))) { CTX(3) = __float_as_uint(bx); CTX(4) = __float_as_uint(by); CTX(6) = CTX(8); CTX(7) = leftFirst; }
-                if (flags & F_ANYHIT) { stop1 = true; more = false; }
-                else if (!(path_m < hitd)) more = false;   // (rule 3)
-              }
-              if (STATS) flags = more ? (flags | F_INLEAF) : (flags & ~F_INLEAF);
-              if (more) cur += 1u - (1u << LEAF_FIRST_BITS);
-              else if (stop1) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
-              else pop_next();
-            } else {
             if (triCount == 0u) {   // leaf with more than 15 triangles: range kept in the reference node
               const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS;
               leftFirst = rn[4]; triCount = rn[5];
@@ -1276,7 +1049,6 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             }
             if (stop) { sp = 0; tos_d = DESC_DONE; cur = DESC_DONE; }
             else pop_next();
-            }   // !RT_TRI_STEP
           }
         }
       }
@@ -1307,8 +1079,8 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
         cur = DESC_IDLE;
       } else if (JOB == JOB_RENDER_GI) {
         // one diffuse bounce, in the lane (see JOB_RENDER_GI above).  Every step is the code of the pass it replaces:
-        // rt_ao_prepare_kernel (colour / albedo / hit point / normal of the primary hit), rt_ao_rays_kernel (the bounce ray),
-        // rt_gi_accumulate_kernel + rt_gi_final_kernel (shade the bounce hit, colour += albedo * that, pack).
+        // rt_ao_prepare_kernel (colour / albedo / hit point / normal of the primary hit), rt_ao_rays_kernel (the bounce ray) and, for the rest,
+        // what the multi-pass form did after its trace launch: shade the bounce hit, colour += albedo * that, pack (orc_render_gi).
         uint32_t x, y;
         pixel_of(job, x, y);
         const size_t e = (size_t)x + (size_t)y * A.W;
@@ -1804,41 +1576,6 @@ __global__ __launch_bounds__(256) void rt_bin_scatter_kernel(uint64_t cap, const
   order[atomicAdd(&hist[keys[i]], 1u)] = (uint32_t)i;
 }
 
-// One diffuse bounce (extension for BASELINE config 3; recipe in oracle/rt_oracle.c:orc_render_gi): the bounce rays are
-// the AO rays of sample 0 with spp = 1 and no tmax, traced for their closest hit.  Listed pixel i: colour += albedo *
-// (Lambert colour of the bounce hit | background).
-__global__ __launch_bounds__(256) void rt_gi_accumulate_kernel(SceneDev sc, ShadeParams p, uint64_t cap, const uint32_t* __restrict__ list,
-    const uint32_t* __restrict__ hdr, const float* __restrict__ rays, const HitRec* __restrict__ bhits, const float4* __restrict__ alb,
-    float4* __restrict__ col) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (i >= hdr[1] || i >= cap) return;
-  const uint32_t t = list[i];
-  const float* rp = rays + (size_t)i * 6;
-  const HitRec h = bhits[i];
-  float r, g, b;
-  shade_eval<false>(sc, p, rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], h, h.dist != RT_LARGE_FLOAT, false, r, g, b);
-  const float4 a = alb[t];
-  float4 c = col[t];
-  c.x = c.x + a.x * r; c.y = c.y + a.y * g; c.z = c.z + a.z * b;
-  col[t] = c;
-}
-
-__global__ __launch_bounds__(256) void rt_gi_final_kernel(uint64_t n, uint32_t W, uint32_t y0, const float4* __restrict__ geo, const float4* __restrict__ col,
-    uint32_t* __restrict__ dst, float* __restrict__ colors_out, unsigned long long* rays_traced) {
-  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  bool hit = false;
-  if (t < n) {
-    const uint32_t x = (uint32_t)(t % W), y = y0 + (uint32_t)(t / W);
-    const size_t e = (size_t)x + (size_t)y * W;
-    const float4 c = col[t];
-    hit = geo[t].w != 0.f;
-    dst[e] = pack_rgb8(c.x, c.y, c.z);
-    if (colors_out) { colors_out[3 * e] = c.x; colors_out[3 * e + 1] = c.y; colors_out[3 * e + 2] = c.z; }
-  }
-  const unsigned long long m = __ballot(hit);
-  if (rays_traced && (threadIdx.x & 63u) == 0u && m) atomicAdd(rays_traced, (unsigned long long)__popcll(m));
-}
-
 struct ShadeBatch { ShadeParams p[VXRT_MAX_BATCH]; };
 __global__ void set_batch_params_kernel(ShadeBatch b, uint32_t n, ShadeParams* __restrict__ dst) {
   if (threadIdx.x < n) dst[threadIdx.x] = b.p[threadIdx.x];
@@ -2111,7 +1848,7 @@ struct FrameCtx {
   // tile cost of the last frame and the order derived from it (render jobs, see lpt_order_kernel)
   uint32_t* tile_cost = nullptr; uint32_t* tile_order = nullptr; uint32_t lpt_cap = 0; uint32_t lpt_key[6] = {0, 0, 0, 0, 0, 0}; bool lpt_valid = false;
   // ambient-occlusion pass (allocated on first use), one entry per pixel of the window
-  float4* ao_geo = nullptr; float4* ao_nrm = nullptr; float4* ao_col = nullptr; float4* ao_alb = nullptr; uint32_t* ao_cnt = nullptr;
+  float4* ao_geo = nullptr; float4* ao_nrm = nullptr; float4* ao_col = nullptr; uint32_t* ao_cnt = nullptr;
   uint32_t* ao_list = nullptr; uint32_t* ao_hdr = nullptr;   // pixels with a hit; [0] their number, [1] rays of the current batch
   float* ao_rays = nullptr; float* ao_tmax = nullptr; HitRec* ao_hits = nullptr; uint64_t ao_cap = 0, ao_ray_cap = 0;
   uint32_t* bin_hist = nullptr; uint32_t* bin_keys = nullptr; uint32_t* bin_order = nullptr; uint64_t bin_cap = 0, bin_ray_cap = 0;   // secondary-ray binning
@@ -2149,7 +1886,7 @@ static void accel_free(vxrt_accel* a) {
   for (uint32_t k = 0; k <= VXRT_MAX_BATCH; ++k) (void)hipFree(a->batch_order[k]);
   for (FrameCtx& c : a->ctx) {
     (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount); (void)hipFree(c.tile_cost); (void)hipFree(c.tile_order);
-    (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_alb); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits); (void)hipFree(c.ao_list); (void)hipFree(c.ao_hdr);
+    (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits); (void)hipFree(c.ao_list); (void)hipFree(c.ao_hdr);
     (void)hipFree(c.bin_hist); (void)hipFree(c.bin_keys); (void)hipFree(c.bin_order);
     for (FrameCtx::Level& l : c.lv) {
       (void)hipFree(l.rays); (void)hipFree(l.hits); (void)hipFree(l.parent); (void)hipFree(l.term); (void)hipFree(l.col);
@@ -2457,8 +2194,8 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
                           uint32_t* unoccluded, unsigned long long* rays_traced, hipStream_t s) {
   const SceneDev& sc = a->dev;
   const uint64_t n = (uint64_t)width * (y1 - y0);
-  const bool gi = ao->reserved == VXRT_AO_MODE_DIFFUSE_BOUNCE;   // one closest-hit bounce ray instead of spp occlusion rays
-  if (n > 0x7fffffffull || ao->spp == 0 || (gi && ao->spp != 1)) return -1;
+  if (ao->reserved == VXRT_AO_MODE_DIFFUSE_BOUNCE) return -1;    // (the diffuse-bounce frame is JOB_RENDER_GI: it has no tail)
+  if (n > 0x7fffffffull || ao->spp == 0) return -1;
   uint32_t ns = (uint32_t)std::min<uint64_t>(ao->spp, std::max<uint64_t>(1, AO_BATCH_RAYS / n));   // samples per batch
   const uint64_t ray_cap = n * ns;
   if (ray_cap > 0x7fffffffull) return -1;
@@ -2466,7 +2203,6 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const uint64_t have = c->ao_cap, rhave = c->ao_ray_cap;
     bool ok = grow_buf((void**)&c->ao_geo, have, n, 16) && grow_buf((void**)&c->ao_nrm, have, n, 16) && grow_buf((void**)&c->ao_col, have, n, 16) &&
-              grow_buf((void**)&c->ao_alb, have, n, 16) &&
               grow_buf((void**)&c->ao_cnt, have, n, 4) && grow_buf((void**)&c->ao_list, have, n, 4) && grow_buf((void**)&c->ao_hdr, c->ao_hdr ? 1 : 0, 1, 8) &&
               grow_buf((void**)&c->ao_rays, rhave, ray_cap, 24) && grow_buf((void**)&c->ao_tmax, rhave, ray_cap, 4) &&
               grow_buf((void**)&c->ao_hits, rhave, ray_cap, sizeof(HitRec));
@@ -2499,18 +2235,9 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
   };
   if (hipMemsetAsync(c->ao_hdr, 0, 8, s) != hipSuccess) return -1;
   hipLaunchKernelGGL(rt_ao_prepare_kernel, dim3((uint32_t)((n + 256u * AO_PREP_CHUNKS - 1u) / (256u * AO_PREP_CHUNKS))), block, 0, s, sc, p, n, width, y0, utab, vtab, (const HitRec*)c->hitbuf,
-                     c->ao_geo, c->ao_nrm, c->ao_col, c->ao_cnt, c->ao_list, c->ao_hdr, c->ctl, gi ? c->ao_alb : (float4*)nullptr);
+                     c->ao_geo, c->ao_nrm, c->ao_col, c->ao_cnt, c->ao_list, c->ao_hdr, c->ctl, (float4*)nullptr);
   if (hipGetLastError() != hipSuccess) return -1;
   c->ctl_dirty = false;
-  if (gi) {
-    hipLaunchKernelGGL(rt_ao_rays_kernel, rgrid, block, 0, s, ray_cap, width, y0, utab, vtab, (const float4*)c->ao_geo, (const float4*)c->ao_nrm,
-                       (const uint32_t*)c->ao_list, c->ao_hdr, 1u, 0u, 1u, ao->seed, RT_LARGE_FLOAT, c->ao_rays, c->ao_tmax);
-    if (trace_on_ctx(a, c, c->ao_rays, n, nullptr, c->ao_hits, VXRT_MODE_CLOSEST, s, c->ao_hdr + 1, nullptr, bin_rays(1u)) != 0) return -1;
-    hipLaunchKernelGGL(rt_gi_accumulate_kernel, rgrid, block, 0, s, sc, p, ray_cap, (const uint32_t*)c->ao_list, (const uint32_t*)c->ao_hdr,
-                       (const float*)c->ao_rays, (const HitRec*)c->ao_hits, (const float4*)c->ao_alb, c->ao_col);
-    hipLaunchKernelGGL(rt_gi_final_kernel, grid, block, 0, s, n, width, y0, (const float4*)c->ao_geo, (const float4*)c->ao_col, dst, colors, rays_traced);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-  }
   for (uint32_t s0 = 0; s0 < ao->spp; s0 += ns) {
     const uint32_t k = std::min(ns, ao->spp - s0);
     hipLaunchKernelGGL(rt_ao_rays_kernel, rgrid, block, 0, s, ray_cap, width, y0, utab, vtab, (const float4*)c->ao_geo, (const float4*)c->ao_nrm,
@@ -2724,10 +2451,10 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false, PK>), dim3(MAIN_GRID((rt_persistent_kernel<J, ST, LD, false, PK>))), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, s, sc, p, X); } while (0)
 #define LAUNCH_PD(J, ST, PK) do { if (sc.exact_decode) LAUNCH_P(J, ST, true, PK); else LAUNCH_P(J, ST, false, PK); } while (0)
-  // one diffuse bounce: the whole frame in the persistent launches (JOB_RENDER_GI); VXRT_GI_FUSED=0 keeps the multi-pass form (same
-  // pixels: tests/test_gpu_configs.py compares them; A/B knob)
-  static const bool gi_fused_on = [] { const char* e = getenv("VXRT_GI_FUSED"); return !(e && e[0] == '0'); }();
-  const bool gi_fused = gi_fused_on && ao && ao->reserved == VXRT_AO_MODE_DIFFUSE_BOUNCE && !stats && !shadow && !unoccluded;
+  // one diffuse bounce: the whole frame in the persistent launches (JOB_RENDER_GI).  (The multi-pass form it replaced -- list the hit
+  // pixels, generate the rays, a 2 M-ray trace launch, accumulate, final -- took the same 1.18 ms: profiles/r03_f_gi_fused_ab.txt)
+  const bool gi_fused = ao && ao->reserved == VXRT_AO_MODE_DIFFUSE_BOUNCE;
+  if (gi_fused && (stats || shadow || unoccluded)) return fail();
   if (gi_fused) {
     A.dst = dst; A.colors = colors; A.gi_seed = ao->seed;
     X.dst = dst; X.colors = colors; X.gi_seed = ao->seed;
