@@ -29,7 +29,7 @@ def test_lds_staging_variants_stay_bit_equal(vrt, gpu_device):
     for f in ("libvortex.so", "libvxrt_scene.so"):
         shutil.copy2(os.path.join(bld.LIB, f), os.path.join(d, f))
     env = dict(os.environ, VXRT_LIB_DIR=d, VXRT_DEBUG="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-k",
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-s", "-k",
                         "reference_fixture or render_matches_oracle or shadow_rays_extension"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
     assert " passed" in r.stdout and "top-of-tree nodes staged" in (r.stdout + r.stderr)     # the variant library is the one that ran
