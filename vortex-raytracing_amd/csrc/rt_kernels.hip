@@ -1188,8 +1188,11 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
 // thread scanning the 2048 counters (profiles/r02_d_exact_timeline.txt).
 // Measured and rejected: one global order dealt round robin to the shards (-4 %: loses the band -> XCD locality) and
 // bands cut at equal cost instead of equal size (-7 %: the measured cost of a tile includes the contention on its SIMD).
+// `base_order` (optional): the static order the queue positions have without learning (the band-major order of a batch of frames); the
+// tiles of queue positions [lo, hi) are then base_order[lo..hi), and it is those that are sorted into order[lo..hi).
 __device__ void lpt_order_block(uint32_t shard, const uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
-                                uint32_t n_tiles, uint32_t tiles_per_shard, uint32_t* hist /* LDS, 2048 + 8 words */) {
+                                uint32_t n_tiles, uint32_t tiles_per_shard, uint32_t* hist /* LDS, 2048 + 8 words */,
+                                const uint32_t* __restrict__ base_order = nullptr) {
   const uint32_t lo = shard * tiles_per_shard;
   const uint32_t hi = min(lo + tiles_per_shard, n_tiles);
   if (lo >= hi) return;   // (block-uniform)
@@ -1200,7 +1203,7 @@ __device__ void lpt_order_block(uint32_t shard, const uint32_t* __restrict__ cos
     const uint32_t e = 31u - (uint32_t)__clz((int)c);       // 6..31
     return ((e - 5u) << 6) | ((c >> (e - 6u)) & 63u);       // 64 .. 1727
   };
-  for (uint32_t t = lo + threadIdx.x; t < hi; t += 256u) atomicAdd(&hist[2047u - cls(cost[t])], 1u);   // descending
+  for (uint32_t t = lo + threadIdx.x; t < hi; t += 256u) atomicAdd(&hist[2047u - cls(cost[base_order ? base_order[t] : t])], 1u);   // descending
   __syncthreads();
   // exclusive scan of the 2048 counters: 8 consecutive counters per thread, wavefront scan, then the four wavefront totals
   uint32_t v[8], sum = 0;
@@ -1216,7 +1219,10 @@ __device__ void lpt_order_block(uint32_t shard, const uint32_t* __restrict__ cos
 #pragma unroll
   for (int k = 0; k < 8; ++k) { hist[threadIdx.x * 8u + k] = base; base += v[k]; }
   __syncthreads();
-  for (uint32_t t = lo + threadIdx.x; t < hi; t += 256u) order[lo + atomicAdd(&hist[2047u - cls(cost[t])], 1u)] = t;
+  for (uint32_t t = lo + threadIdx.x; t < hi; t += 256u) {
+    const uint32_t tile = base_order ? base_order[t] : t;
+    order[lo + atomicAdd(&hist[2047u - cls(cost[tile])], 1u)] = tile;
+  }
 }
 
 // Deferred shading pass: one thread per pixel of rows [y0,y1), x fastest, so hit records are read
@@ -1229,10 +1235,11 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
                                                       unsigned long long* counters, uint32_t* __restrict__ ctl_reset,
                                                       uint32_t lpt_blocks, const uint32_t* __restrict__ lpt_cost, uint32_t* __restrict__ lpt_order,
                                                       uint32_t lpt_tiles, uint32_t lpt_per_shard,
-                                                      uint32_t batch = 1, const ShadeParams* __restrict__ pbatch = nullptr, uint64_t dst_frame_stride = 0) {
+                                                      uint32_t batch = 1, const ShadeParams* __restrict__ pbatch = nullptr, uint64_t dst_frame_stride = 0,
+                                                      const uint32_t* __restrict__ lpt_base = nullptr) {
   // the first lpt_blocks workgroups sort the frame's tiles by cost for the context's next frame (see lpt_order_block)
   __shared__ uint32_t s_hist[2048 + 8];
-  if (blockIdx.x < lpt_blocks) { lpt_order_block(blockIdx.x, lpt_cost, lpt_order, lpt_tiles, lpt_per_shard, s_hist); return; }
+  if (blockIdx.x < lpt_blocks) { lpt_order_block(blockIdx.x, lpt_cost, lpt_order, lpt_tiles, lpt_per_shard, s_hist, lpt_base); return; }
   const uint32_t blk = blockIdx.x - lpt_blocks;
   // last kernel of a frame: every user of the frame's control block (queue counters, deferral count)
   // has finished, so zero it here for the context's next frame instead of paying fill launches per frame
@@ -1790,6 +1797,7 @@ static uint32_t* status_word() {
 }
 
 #define LPT_MIN_TILES 20000u
+#define LPT_BATCH_MAX_TILES 100000u
 #ifndef EXACT_GRID
 #define EXACT_GRID 128   // workgroups of the EXACT launch (it sees a fraction of a percent of the rays)
 #endif
@@ -1846,7 +1854,9 @@ struct FrameCtx {
   std::vector<Level> lv;
   uint32_t* bcount = nullptr;  // device: rays appended to the level being built
   // tile cost of the last frame and the order derived from it (render jobs, see lpt_order_kernel)
-  uint32_t* tile_cost = nullptr; uint32_t* tile_order = nullptr; uint32_t lpt_cap = 0; uint32_t lpt_key[6] = {0, 0, 0, 0, 0, 0}; bool lpt_valid = false;
+  // one slot per batch size (slot 1 = single frames): a frame loop that alternates batch sizes keeps what it learned for each
+  struct Lpt { uint32_t* cost = nullptr; uint32_t* order = nullptr; uint32_t cap = 0; uint32_t key[6] = {0, 0, 0, 0, 0, 0}; bool valid = false; };
+  Lpt lpt[VXRT_MAX_BATCH + 1];
   // ambient-occlusion pass (allocated on first use), one entry per pixel of the window
   float4* ao_geo = nullptr; float4* ao_nrm = nullptr; float4* ao_col = nullptr; uint32_t* ao_cnt = nullptr;
   uint32_t* ao_list = nullptr; uint32_t* ao_hdr = nullptr;   // pixels with a hit; [0] their number, [1] rays of the current batch
@@ -1885,7 +1895,8 @@ static void accel_free(vxrt_accel* a) {
   (void)hipFree(a->uvtab); (void)hipFree(a->apriori);
   for (uint32_t k = 0; k <= VXRT_MAX_BATCH; ++k) (void)hipFree(a->batch_order[k]);
   for (FrameCtx& c : a->ctx) {
-    (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount); (void)hipFree(c.tile_cost); (void)hipFree(c.tile_order);
+    (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount);
+    for (FrameCtx::Lpt& l : c.lpt) { (void)hipFree(l.cost); (void)hipFree(l.order); }
     (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits); (void)hipFree(c.ao_list); (void)hipFree(c.ao_hdr);
     (void)hipFree(c.bin_hist); (void)hipFree(c.bin_keys); (void)hipFree(c.bin_order);
     for (FrameCtx::Level& l : c.lv) {
@@ -2365,19 +2376,31 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   // and only for frames of more than LPT_MIN_TILES tiles: below, the sort launch costs more than the shorter tail saves
   // (1024x1024, 86 % background: -5 %; 1920x1080: +9 %; 3840x2160: +4 %; the sort on a side stream instead: worse, the
   // two extra event hops cost more than the kernel)
-  const bool lpt = lpt_on && (!stats || wave_log) && a->n_ctx == 1 && batch == 1 && n_tiles >= LPT_MIN_TILES;   // (with frames in flight: no difference, measured)
+  // Single frames in flight on several streams: no difference, measured (round 2).  BATCHES of frames: a rank's share of a frame split
+  // over GPUs makes short launches -- at 8 ranks a 20-step run is two launches of ~5 tiles per wavefront, whose tails nothing
+  // fills -- and the batches of a frame loop repeat: the order is learned from the context's previous batch of the same size
+  // (VXRT_LPT_BATCH=0 disables; profiles/r03_h_lpt_batch.txt).
+  static const bool lpt_batch_on = [] { const char* e = getenv("VXRT_LPT_BATCH"); return !(e && e[0] == '0'); }();
+  // ... for batches of at most LPT_BATCH_MAX_TILES tiles (about a dozen per resident wavefront): measured on one box, driver-sized
+  // runs, rank 0's pipeline of 8 / 4 / 2 ranks (40.8 K / 81.6 K / 162 K tiles per batch): +5.5 % / +2 % / 0; one GPU's batches of
+  // five whole frames (162 K tiles, sets overlapping on two streams): -5 % -- sorted by cost, a band's tiles are no longer
+  // traced next to their screen neighbours, and there the tails are filled anyway.
+  const bool lpt = lpt_on && (!stats || wave_log) && n_tiles >= LPT_MIN_TILES &&
+                   (batch == 1 ? a->n_ctx == 1 : (lpt_batch_on && n_tiles <= LPT_BATCH_MAX_TILES));
+  FrameCtx::Lpt& L = c->lpt[batch];
   if (lpt) {
-    if (c->lpt_cap < n_tiles) {
+    if (L.cap < n_tiles) {
       if (hipStreamSynchronize(s) != hipSuccess) return fail();
-      (void)hipFree(c->tile_cost); (void)hipFree(c->tile_order);
-      c->tile_cost = c->tile_order = nullptr; c->lpt_cap = 0; c->lpt_valid = false;
-      if (hipMalloc((void**)&c->tile_cost, (size_t)n_tiles * 4) != hipSuccess || hipMalloc((void**)&c->tile_order, (size_t)n_tiles * 4) != hipSuccess) return fail();
-      c->lpt_cap = n_tiles;
+      (void)hipFree(L.cost); (void)hipFree(L.order);
+      L.cost = L.order = nullptr; L.cap = 0; L.valid = false;
+      if (hipMalloc((void**)&L.cost, (size_t)n_tiles * 4) != hipSuccess || hipMalloc((void**)&L.order, (size_t)n_tiles * 4) != hipSuccess) return fail();
+      L.cap = n_tiles;
     }
-    const uint32_t key[6] = {width, height, y0, y1, (uint32_t)shadow | (stride << 1), ao ? 1u : 0u};
-    if (memcmp(key, c->lpt_key, sizeof key) != 0) { c->lpt_valid = false; memcpy(c->lpt_key, key, sizeof key); }
-    A.tile_cost = c->tile_cost;
-    A.tile_order = c->lpt_valid ? c->tile_order : nullptr;
+    const uint32_t key[6] = {width, height, y0, y1, (uint32_t)shadow | (stride << 1), (ao ? 1u : 0u) | (batch << 1)};
+    if (memcmp(key, L.key, sizeof key) != 0) { L.valid = false; memcpy(L.key, key, sizeof key); }
+    A.tile_cost = L.cost;
+    if (L.valid) A.tile_order = L.order;          // else: the static order (identity, or the batch's band-major order set above)
+    else if (batch == 1) A.tile_order = nullptr;
   }
   // a-priori EXACT list (camera rays with u == 0 or v == 0), rebuilt only when the window changes.  The list of a batch is the
   // frames' lists one after the other, so a list built for F frames serves every batch <= F: the launch takes a prefix.
@@ -2470,7 +2493,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
 #undef MAIN_GRID
   // (the tile sort for the next frame rides in the shading launch; the AO / bounce tails have no such launch and skip it)
   const bool lpt_sort = lpt && !ao && !(p.max_depth > 1 && a->max_reflectivity > 0.0f);
-  if (lpt && !lpt_sort) c->lpt_valid = false;
+  if (lpt && !lpt_sort) L.valid = false;
   if (side_launch) {
     if (hipEventRecord(c->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, c->ev_side, 0) != hipSuccess) return fail();
   }
@@ -2492,11 +2515,12 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   const uint32_t lpt_blocks = lpt_sort ? QUEUE_SHARDS : 0u;
   dim3 sgrid((uint32_t)((npx + 255) / 256) + lpt_blocks);
   if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl,
-                                lpt_blocks, (const uint32_t*)c->tile_cost, c->tile_order, n_tiles, A.per_shard >> 6);
+                                lpt_blocks, (const uint32_t*)L.cost, L.order, n_tiles, A.per_shard >> 6);
   else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl,
-                                lpt_blocks, (const uint32_t*)c->tile_cost, c->tile_order, n_tiles, A.per_shard >> 6, batch, (const ShadeParams*)c->pbatch, dst_frame_stride);
+                                lpt_blocks, (const uint32_t*)L.cost, L.order, n_tiles, A.per_shard >> 6, batch, (const ShadeParams*)c->pbatch, dst_frame_stride,
+                                batch > 1 ? (const uint32_t*)a->batch_order[batch] : (const uint32_t*)nullptr);
   if (hipGetLastError() != hipSuccess) return fail();
-  if (lpt_sort) c->lpt_valid = true;
+  if (lpt_sort) L.valid = true;
   c->ctl_dirty = false;
   return release_ctx(c, s);
 }
