@@ -101,6 +101,12 @@ int vx_dev_init(callbacks_t* callbacks);
  * renders the 8-row tile rows phase, phase + n, phase + 2n, ... of the frame with phase = ROW_BEGIN / 8 (< n): the split of one
  * frame over n GPUs that balances them (see vxrt_render_interleaved). */
 #define VX_DCR_HIP_ROW_STRIDE 0x7F3
+/* Backend extension: 1 = REFERENCE-QUIRKS traversal for the RTU test's frames (default 0 = the canonical algorithm).  The frame's
+ * camera rays are then traced by vxrt_trace_reference_quirks on a flat image of the device's address space -- every allocation at
+ * its address, as the simulator's RAM holds it -- with the RTX DCR values as base pointers, so that the stale base_ptr of
+ * rt_traversal.cpp:91-92 reads here what it reads there.  Slow (one thread per ray, the address space copied when an allocation
+ * changed); closest-hit frames only (no shadow-ray extension, no row stride). */
+#define VX_DCR_HIP_REFERENCE_QUIRKS 0x7F4
 
 /* CSRs answered by mpm_query (read by vx_dump_perf at vx_dev_close: stub/perf.cpp:195-227). */
 #define VX_CSR_MPM_BASE 0xB00
@@ -368,6 +374,22 @@ int vxrt_trace(vxrt_accel_t* accel, const float* rays, uint64_t n, const float* 
  * them.  The records must come from this accel (their blasIdx / triIdx are followed unchecked). */
 int vxrt_shade_rays(vxrt_accel_t* accel, const float* rays, const vxrt_hit_t* hits, uint64_t n, const vxrt_shade_params_t* params,
                     float* colors, uint32_t* rgb8, void* stream);
+
+/* Camera rays of rows [y0, y1) of the RTU test's frame (kernel.cpp:28-39) as a ray buffer: 6 floats per ray, ray of pixel (x, y) at
+ * index x + (y - y0) * width. */
+int vxrt_camera_rays(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, float* rays, void* stream);
+
+/* Opt-in REFERENCE-QUIRKS traversal.  vxrt_trace / vxrt_render implement the canonical algorithm: the reference RTU's result
+ * wherever the RTU addresses its own data.  With a TLAS deeper than one level it does not: children of a TLAS internal node popped
+ * from the short stack are addressed relative to the last BLAS's base_ptr (sim/simx/rt_traversal.cpp:91-92 after :119-120), it reads
+ * unrelated memory and loses hits that exist.  What it returns then depends on the memory layout, so this entry point works on what
+ * the simulator works on: ONE flat memory image addressed with 32-bit offsets (its RAM) and the four base pointers of the RTX DCRs
+ * 0x6..0x9, and restates BVHTraverser::traverse literally (trail[32], 5-entry short stack, restart, re-descent after every
+ * accepted candidate, libstdc++ min/max).  One thread per ray; a compatibility mode, not a fast path.  Reads outside the image
+ * return zeros; a path deeper than 32 levels sets status bit 0 (undefined behaviour in the reference).
+ * mode: VXRT_MODE_CLOSEST = fixed point of the accept loop, VXRT_MODE_ANY = first accepted candidate.  tmax (optional) as vxrt_trace. */
+int vxrt_trace_reference_quirks(const void* image, uint64_t image_size, uint32_t tlas_off, uint32_t blas_off, uint32_t bvh_off, uint32_t tri_off,
+                                const float* rays, uint64_t n, const float* tmax, vxrt_hit_t* hits, int mode, void* stream);
 
 /* Diagnostic (tests): copies the first n_dwords (<= 800) of the control block of frame context `ctx` to `out` after synchronising
  * `stream`: [0] number of rays the main launch handed to the EXACT launch, [32 + 32 k] queue shard k (k = 0..7) of the main launch,

@@ -154,3 +154,54 @@ def test_runs_do_not_rebuild_or_reallocate(vrt, gpu_device):
     tr.run()
     assert tr.dev.hip_stat(0) == 2 and tr.dev.hip_stat(1) == mallocs
     tr.close()
+
+
+def test_reference_quirks_dcr_renders_what_the_rtu_would_on_this_address_space(vrt, po, gpu_device):
+    """DCR 0x7F4 = 1 through the vx_* boundary: the frame is traced by the literal restatement of the reference RTU (stale base_ptr
+    of rt_traversal.cpp:91-92 included) on a flat image of the device's address space, with the RTX DCR values as base pointers.
+    Expected pixels: the oracle's faithful restatement on the SAME address space (every buffer at the address vx_mem_address
+    reported), shaded by the oracle.  The scene has 12 instances -- a TLAS deeper than one level -- in the camera's view, so the
+    quirk is live: the frame differs from the canonical one (DCR 0x7F4 = 0, the default), which equals the canonical oracle."""
+    rng = np.random.default_rng(5)
+    base = vrt.scene.procedural("blob", 2, 0, 1)["tri"].view(np.float32).reshape(-1, 9)
+    base = (base - base.reshape(-1, 3).mean(0).tolist() * 3) * np.float32(0.25)
+    xf = []
+    for i in range(12):
+        m = np.eye(4, dtype=np.float32)
+        m[:3, 3] = (260.0 + 45.0 * (i % 3) + 130.0 * (i // 6), 100.0 + 40.0 * ((i // 3) % 2), 60.0 * (i % 3 - 1))
+        xf.append(m)
+    sc = vrt.scene.from_triangles([base] * 12, xf)
+    assert sc.n_tlas_nodes > 5                      # internal TLAS nodes below the root
+    w, h = 160, 96
+    tr = vrt.tracer.Tracer(w, h)
+    tr.init(sc)
+    tr.setup()
+    canon = tr.run()
+    want_canon, _, _ = po.render(sc, w, h)
+    assert np.array_equal(canon, want_canon)
+    tr.dev.dcr_write(0x7F4, 1)
+    quirk = tr.run()
+    tr.dev.dcr_write(0x7F4, 0)
+    again = tr.run()
+    assert np.array_equal(again, canon)             # the mode is a switch, nothing sticks
+    # the address space as the backend laid it out
+    addr = {k: b.address for k, b in tr.bufs.items()}
+    top = max(addr[k] + int(sc[k].size) for k in ("tri", "triEx", "triIdx", "tlas", "blas", "bvh", "mat", "tex"))
+    assert top < 2 ** 32
+    mem = np.zeros(top + 64, np.uint8)
+    for k in ("tri", "triEx", "triIdx", "tlas", "blas", "bvh", "mat", "tex"):
+        b = np.ascontiguousarray(sc[k], np.uint8).reshape(-1)
+        mem[addr[k]: addr[k] + b.size] = b
+
+    class Img:   # what pyoracle.Image is, on the device's layout
+        pass
+    img = Img()
+    img.mem, img.off = mem, {k: addr[k] for k in ("tlas", "blas", "bvh", "tri")}
+    img.__class__ = type("Image", (po.Image,), {})
+    rays = po.camera_rays(w, h)
+    hits, st = po.trace_faithful(img, rays)
+    _, want_quirk = po.shade(sc, rays, hits)
+    assert np.array_equal(quirk, want_quirk.reshape(h, w))
+    tr.close()
+    print("quirk mode: %d rays took the stale base_ptr, %d of %d pixels differ from the canonical frame" % (st["stale_base"], int((quirk != canon).sum()), w * h))
+    assert st["stale_base"] > 0 and (quirk != canon).any()

@@ -583,3 +583,33 @@ def test_exact_launch_takes_exactly_the_deferred_rays(vrt, po, golden, gpu_devic
     used = -(-n // per_shard)
     assert (exact_q[:used] >= np.minimum(per_shard, n - per_shard * np.arange(used))).all() and not exact_q[used:].any(), exact_q
     ds.close()
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_reference_quirks_mode_equals_the_reference_on_every_ray(vrt, po, golden, gpu_device, name):
+    """vxrt_trace_reference_quirks: the RTU's traversal restated literally on a flat memory image -- trail, short stack, restart,
+    re-descent, and the stale base_ptr of rt_traversal.cpp:91-92.  EVERY ray of every fixture equals what the reference's own
+    traverser returned (closest hit and first accepted candidate), UNMASKED: including the 43 rays of sphere_x6 on which the
+    reference reads unrelated nodes and the canonical kernels (the default) deliberately differ."""
+    import torch
+    g = golden(name)
+    img = po.Image(g)
+    mem = torch.from_numpy(img.mem).to(gpu_device)
+    rays = torch.from_numpy(np.ascontiguousarray(g["rays"], np.float32)).to(gpu_device)
+    n = len(g["rays"])
+    offs = (img.off["tlas"], img.off["blas"], img.off["bvh"], img.off["tri"])
+    s = torch.cuda.current_stream().cuda_stream
+    for mode, key in ((vrt.rtapi.MODE_CLOSEST, "hits"), (vrt.rtapi.MODE_ANY, "anyhits")):
+        out = torch.zeros(n * 24, dtype=torch.uint8, device=gpu_device)
+        vrt.rtapi.trace_reference_quirks(mem.data_ptr(), mem.numel(), offs, rays.data_ptr(), n, out.data_ptr(), mode, None, s)
+        assert vrt.rtapi.status(s) == 0
+        got = _hits_np(out)[:n]
+        assert np.array_equal(_bits(got), _bits(g[key])), "%s / %s: %d rays differ" % (name, key, int((_bits(got).reshape(n, -1) != _bits(g[key]).reshape(n, -1)).any(1).sum()))
+    if name == "sphere_x6":
+        # ... and there the default (canonical) kernels do differ, on exactly the masked rays
+        ds = vrt.tracer.DeviceScene(g, gpu_device)
+        canon = gpu_trace(vrt, ds, g["rays"])
+        differ = (_bits(canon).reshape(n, -1) != _bits(g["hits"]).reshape(n, -1)).any(1)
+        mask = po.stale_base_mask(g, g["rays"])
+        assert differ.any() and not (differ & ~mask).any()
+        ds.close()

@@ -5,6 +5,7 @@ EXACT launch (side stream), of the deferred-list EXACT launch and of the shading
 start, plus the gap from the end of the frame's last traversal kernel to the shading pass.
 usage: tools/exact_timeline.py <kernel_trace.csv> [frames to skip]"""
 import csv
+import re
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -13,7 +14,8 @@ ev = []
 for r in rows:
     n = r["Kernel_Name"]
     if "rt_persistent_kernel<1, 0" in n or "rt_shade_kernel<false>" in n or "lpt_order_kernel" in n:
-        kind = "shade" if "rt_shade" in n else ("lpt" if "lpt_order" in n else ("exact" if ", true>" in n else "main"))
+        m = re.search(r"rt_persistent_kernel<1, 0, (true|false), (true|false)", n)      # <JOB, STATS, LDEXP, EXACT, PACKED>
+        kind = "shade" if "rt_shade" in n else ("lpt" if "lpt_order" in n else ("exact" if (m and m.group(2) == "true") else "main"))
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind, r.get("Queue_Id", "") + "/" + r.get("Stream_Id", "")))
 ev.sort()
 main_q = next(q for _, _, k, q in ev if k == "main")

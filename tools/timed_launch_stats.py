@@ -10,7 +10,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 groups = int(sys.argv[2])
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-main = [r for r in rows if "rt_persistent_kernel<1, 0, false, false>" in r["Kernel_Name"] or "rt_persistent_kernel<0, 0, false, false>" in r["Kernel_Name"]]
+import re
+# main launch of a frame job: rt_persistent_kernel<JOB 0|1, STATS 0, LDEXP, EXACT false, PACKED any>
+main = [r for r in rows if re.search(r"rt_persistent_kernel<[01], 0, (true|false), false(, (true|false))?>", r["Kernel_Name"])]
 shade = [r for r in rows if "rt_shade_kernel<false>" in r["Kernel_Name"]]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 m, s = main[-groups:], shade[-groups:]

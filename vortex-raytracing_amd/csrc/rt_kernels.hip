@@ -1583,6 +1583,159 @@ __global__ __launch_bounds__(256) void rt_bin_scatter_kernel(uint64_t cap, const
   order[atomicAdd(&hist[keys[i]], 1u)] = (uint32_t)i;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Reference-quirks traversal (opt-in; vxrt_trace_reference_quirks).  The kernels above implement the CANONICAL algorithm (DESIGN.md
+// s3), which returns what the reference's RTU returns wherever the reference addresses its own data.  The RTU does not always:
+// children of a TLAS internal node that is popped from the short stack are addressed relative to the LAST BLAS's base_ptr
+// (rt_traversal.cpp:91-92 after :119-120), so with a TLAS deeper than one level it reads unrelated memory and loses real hits.
+// What it then returns depends on what lies at those addresses, i.e. on the memory layout -- so this mode works as the
+// simulator does: on ONE flat memory image addressed with 32-bit offsets (the simulated RAM) and the four base pointers of the
+// RTX DCRs, and it restates BVHTraverser::traverse literally: trail[32], the 5-entry short stack that forgets its oldest entry,
+// the restart from the root when the stack is dry, a full re-descent after every accepted candidate (rt_unit.cpp:199-202),
+// libstdc++ min/max in the slab test, the per-test edge subtractions.  One thread per ray: this is a compatibility mode, not a
+// fast path.  Reads outside the image return zeros.  rt_traversal.cpp:80-86 spins 2^32 times without effect when
+// trail[level] == 4 and no child passes: closed form here.  Depth > 32 overruns trail[] in the reference: status bit, ray ends.
+// ---------------------------------------------------------------------------------------------
+struct QuirkImage { const uint8_t* mem; uint64_t size; uint32_t tlas_ptr, blas_ptr, bvh_ptr, tri_ptr; };
+
+__device__ __forceinline__ void q_read(const QuirkImage& im, uint32_t* dst, uint32_t addr, uint32_t dwords) {
+  if ((uint64_t)addr + 4ull * dwords > im.size || (addr & 3u)) { for (uint32_t i = 0; i < dwords; ++i) dst[i] = 0u; return; }
+  const uint32_t* p = (const uint32_t*)(im.mem + addr);
+  for (uint32_t i = 0; i < dwords; ++i) dst[i] = p[i];
+}
+
+__global__ __launch_bounds__(64) void rt_quirks_trace_kernel(QuirkImage im, const float* __restrict__ rays, const float* __restrict__ tmax, uint64_t n,
+                                                            HitRec* __restrict__ out, int any_hit_first, uint32_t* status) {
+  const uint64_t r = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+  if (r >= n) return;
+  const float* rp = rays + r * 6;
+  const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
+  HitRec hit; hit.dist = tmax ? tmax[r] : RT_LARGE_FLOAT; hit.bx = 0; hit.by = 0; hit.bz = 0; hit.blasIdx = 0; hit.triIdx = 0;
+  if (hit.dist > RT_LARGE_FLOAT) hit.dist = RT_LARGE_FLOAT;
+  uint8_t trail[RT_MAX_TRAIL];
+  for (int i = 0; i < RT_MAX_TRAIL; ++i) trail[i] = 0;
+  // ShortStack<TraversalStackEntry, 5> (types.h:1808-1840)
+  uint32_t ss_ptr[5]; uint8_t ss_last[5]; uint32_t ss_head = 0, ss_count = 0;
+  auto ss_push = [&](uint32_t ptr, uint8_t last) {
+    if (ss_count < 5u) ss_count++;            // (a full stack overwrites its oldest entry: head wraps onto it)
+    ss_ptr[ss_head] = ptr; ss_last[ss_head] = last;
+    ss_head = (ss_head + 1u) % 5u;
+  };
+  bool accepted = false;
+  for (uint32_t guard = 0; guard < (1u << 20); ++guard) {   // one pass of traverse() per accepted candidate
+    uint32_t level = 0, base_ptr = im.tlas_ptr, node_ptr = im.tlas_ptr, blasIdx = 0;
+    float cx = ox, cy = oy, cz = oz, cdx = dx, cdy = dy, cdz = dz;   // cur_ray
+    bool finished = false, pending = false;
+    float pending_dist = 0.f;
+    // findNextParentLevel + pop (rt_traversal.cpp:171-213); true = traversal over
+    auto pop = [&]() -> bool {
+      int parent = -1;
+      for (int i = (int)level - 1; i >= 0; --i) if (i < RT_MAX_TRAIL && trail[i] != 4) { parent = i; break; }
+      if (parent < 0) return true;
+      trail[parent]++;
+      for (int i = parent + 1; i < RT_MAX_TRAIL; ++i) trail[i] = 0;
+      if (ss_count == 0u) { base_ptr = im.tlas_ptr; node_ptr = im.tlas_ptr; level = 0; }
+      else {
+        ss_head = ss_head == 0u ? 4u : ss_head - 1u;
+        ss_count--;
+        node_ptr = ss_ptr[ss_head];
+        if (ss_last[ss_head]) trail[parent] = 4;
+        level = (uint32_t)parent + 1u;
+      }
+      return false;
+    };
+    for (uint32_t it = 0; it < ITER_LIMIT && !finished && !pending; ++it) {
+      uint32_t w[RT_NODE_DWORDS];
+      q_read(im, w, node_ptr, RT_NODE_DWORDS);
+      const uint32_t imask = w[3] >> 24, leftFirst = w[4], leafData = w[5];
+      const bool top = imask == 1u;
+      const bool leaf = top ? (leafData != 0xffffffffu) : (leafData != 0u);
+      if (!leaf) {
+        const float px = __uint_as_float(w[0]), py = __uint_as_float(w[1]), pz = __uint_as_float(w[2]);
+        const int ex = (int)(int8_t)(w[3] & 0xff), ey = (int)(int8_t)((w[3] >> 8) & 0xff), ez = (int)(int8_t)((w[3] >> 16) & 0xff);
+        const uint8_t* cb = (const uint8_t*)w + 24;
+        float dist[4]; uint32_t child[4]; int cnt = 0;
+        const float rox = top ? ox : cx, roy = top ? oy : cy, roz = top ? oz : cz;
+        const float rdx = top ? dx : cdx, rdy = top ? dy : cdy, rdz = top ? dz : cdz;
+        const float ix = 1.0f / rdx, iy = 1.0f / rdy, iz = 1.0f / rdz;
+        for (int k = 0; k < 4; ++k) {
+          const uint8_t* c = cb + 7 * k;
+          if (c[0] == 0) continue;
+          const float d = ray_box<true>(rox, roy, roz, ix, iy, iz,
+                                        px + ldexpf((float)c[1], ex), py + ldexpf((float)c[2], ey), pz + ldexpf((float)c[3], ez),
+                                        px + ldexpf((float)c[4], ex), py + ldexpf((float)c[5], ey), pz + ldexpf((float)c[6], ez));
+          if (d < hit.dist) {
+            // std::sort(a.dist > b.dist) on <= 4 elements = insertion sort: stable, farthest first (:76-78)
+            int j = cnt;
+            while (j > 0 && d > dist[j - 1]) { dist[j] = dist[j - 1]; child[j] = child[j - 1]; --j; }
+            dist[j] = d; child[j] = (uint32_t)k;
+            cnt++;
+          }
+        }
+        if (level >= RT_MAX_TRAIL) { atomicOr(status, STATUS_STACK_OVERFLOW); finished = true; break; }
+        const uint32_t kdrop = trail[level];
+        const uint32_t drop = kdrop == 4u ? (uint32_t)cnt - 1u : kdrop;     // wraps when cnt == 0 (:81)
+        if (drop >= (uint32_t)cnt) cnt = 0; else cnt -= (int)drop;
+        if (cnt == 0) finished = pop();
+        else {
+          const uint32_t nearest = child[cnt - 1];
+          cnt--;
+          node_ptr = base_ptr + (leftFirst + nearest) * RT_NODE_BYTES;          // base_ptr may be STALE here: the quirk
+          if (cnt == 0) trail[level] = 4;
+          else for (int q = 0; q < cnt; ++q) ss_push(base_ptr + (leftFirst + child[q]) * RT_NODE_BYTES, q == 0 ? 1 : 0);
+          level++;
+        }
+      } else if (top) {
+        blasIdx = leafData;
+        uint32_t bw[13];
+        q_read(im, bw, im.blas_ptr + blasIdx * RT_BLAS_STRIDE, 13);
+        const float m00 = __uint_as_float(bw[1]), m01 = __uint_as_float(bw[2]), m02 = __uint_as_float(bw[3]), m03 = __uint_as_float(bw[4]);
+        const float m10 = __uint_as_float(bw[5]), m11 = __uint_as_float(bw[6]), m12 = __uint_as_float(bw[7]), m13 = __uint_as_float(bw[8]);
+        const float m20 = __uint_as_float(bw[9]), m21 = __uint_as_float(bw[10]), m22 = __uint_as_float(bw[11]), m23 = __uint_as_float(bw[12]);
+        cx = m00 * ox + m01 * oy + m02 * oz + m03; cy = m10 * ox + m11 * oy + m12 * oz + m13; cz = m20 * ox + m21 * oy + m22 * oz + m23;
+        cdx = m00 * dx + m01 * dy + m02 * dz; cdy = m10 * dx + m11 * dy + m12 * dz; cdz = m20 * dx + m21 * dy + m22 * dz;
+        base_ptr = im.bvh_ptr + bw[0] * RT_NODE_BYTES;
+        node_ptr = base_ptr;
+      } else {
+        for (uint32_t i = 0; i < leafData && !pending; ++i) {
+          const uint32_t triIdx = leftFirst + i;
+          uint32_t tw[9];
+          q_read(im, tw, im.tri_ptr + triIdx * RT_TRI_BYTES, 9);
+          const float v0x = __uint_as_float(tw[0]), v0y = __uint_as_float(tw[1]), v0z = __uint_as_float(tw[2]);
+          const float4 t0 = make_float4(v0x, v0y, v0z, __uint_as_float(tw[3]) - v0x);
+          const float4 t1 = make_float4(__uint_as_float(tw[4]) - v0y, __uint_as_float(tw[5]) - v0z, __uint_as_float(tw[6]) - v0x, __uint_as_float(tw[7]) - v0y);
+          const float4 t2 = make_float4(__uint_as_float(tw[8]) - v0z, 0.f, 0.f, 0.f);
+          float bx, by, bz;
+          const float d = ray_tri(cx, cy, cz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
+          if (d < hit.dist) {
+            pending_dist = d; hit.bx = bx; hit.by = by; hit.bz = bz; hit.blasIdx = blasIdx; hit.triIdx = triIdx;
+            ss_count = 0; ss_head = 0;     // :150-153 (an emptied stack pops nothing: head position is irrelevant)
+            pending = true;
+          }
+        }
+        if (!pending) finished = pop();
+      }
+    }
+    if (!pending) break;                       // traversal completed (or the iteration backstop)
+    hit.dist = pending_dist;                   // rt_unit.cpp:199-202 COMMIT_ACCEPT, then traverse again from the root with the kept trail
+    accepted = true;
+    if (any_hit_first) break;
+  }
+  if (!accepted) { hit.dist = RT_LARGE_FLOAT; hit.bx = 0; hit.by = 0; hit.bz = 0; hit.blasIdx = 0; hit.triIdx = 0; }
+  out[r] = hit;
+}
+
+// camera rays of rows [y0, y1) as a ray buffer (kernel.cpp:28-39; u, v in double as there -- IEEE division, so the same bits as the
+// host-built tables of the frame kernels): ray (x, y) at index x + (y - y0) * W
+__global__ __launch_bounds__(256) void rt_camera_rays_kernel(uint32_t W, uint32_t H, uint32_t y0, uint64_t n, float* __restrict__ rays) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t x = (uint32_t)(i % W), y = y0 + (uint32_t)(i / W);
+  const float u = (float)(((double)x * 2.0 - (double)W) / (double)H), v = (float)(((double)y * 2.0 - (double)H) / (double)H);
+  float* o = rays + i * 6;
+  generate_ray(u, v, o[0], o[1], o[2], o[3], o[4], o[5]);
+}
+
 struct ShadeBatch { ShadeParams p[VXRT_MAX_BATCH]; };
 __global__ void set_batch_params_kernel(ShadeBatch b, uint32_t n, ShadeParams* __restrict__ dst) {
   if (threadIdx.x < n) dst[threadIdx.x] = b.p[threadIdx.x];
@@ -2628,6 +2781,34 @@ int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax
   if (!c) return -1;
   if (trace_on_ctx(a, c, rays, n, tmax, (HitRec*)hits, mode, s) != 0) return -1;
   return release_ctx(c, s);
+}
+
+// Opt-in compatibility mode: the reference RTU's traversal restated literally, quirks included, on a flat memory image (see
+// rt_quirks_trace_kernel).  image: device memory of image_size bytes; the four offsets are what the RTX DCRs 0x6..0x9 hold in the
+// simulator (32-bit addresses into its RAM).  hits: n records; a miss has dist 1e30.  mode: VXRT_MODE_CLOSEST = the fixed point of
+// the accept loop, VXRT_MODE_ANY = the first accepted candidate.
+int vxrt_trace_reference_quirks(const void* image, uint64_t image_size, uint32_t tlas_off, uint32_t blas_off, uint32_t bvh_off, uint32_t tri_off,
+                                const float* rays, uint64_t n, const float* tmax, vxrt_hit_t* hits, int mode, void* stream) {
+  if (!image || image_size < 64 || (n && (!rays || !hits))) return -1;
+  if (mode != VXRT_MODE_CLOSEST && mode != VXRT_MODE_ANY) return -1;
+  if (n == 0) return 0;
+  if (n > 0x7fffffffull) return -1;
+  uint32_t* st = status_word();
+  if (!st) return -1;
+  QuirkImage im{(const uint8_t*)image, image_size, tlas_off, blas_off, bvh_off, tri_off};
+  hipLaunchKernelGGL(rt_quirks_trace_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, im, rays, tmax, n, (HitRec*)hits,
+                     mode == VXRT_MODE_ANY ? 1 : 0, st);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Camera rays of rows [y0, y1) of a W x H frame as a ray buffer (6 floats per ray, ray (x, y) at x + (y - y0) * W): what the frame
+// kernels trace, for callers that trace them through vxrt_trace / vxrt_trace_reference_quirks and shade with vxrt_shade_rays.
+int vxrt_camera_rays(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, float* rays, void* stream) {
+  if (!rays || width == 0 || height == 0 || y0 > y1 || y1 > height) return -1;
+  const uint64_t n = (uint64_t)width * (y1 - y0);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(rt_camera_rays_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, width, height, y0, n, rays);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int vxrt_shade_rays(vxrt_accel_t* a, const float* rays, const vxrt_hit_t* hits, uint64_t n, const vxrt_shade_params_t* params,

@@ -11,6 +11,7 @@
 #define RT_NODE_DWORDS 13
 #define RT_BLAS_STRIDE 160         // rt_traversal.cpp:112 (hard-coded `* 160`)
 #define RT_TRI_BYTES 36
+#define RT_MAX_TRAIL 32            // TraversalTrail levels (rt_traversal.h: trail[32]); deeper = undefined behaviour in the reference
 #define RT_TRIEX_BYTES 64
 #define RT_MAT_BYTES 88
 #define RT_MAX_LEVELS 32           // MAX_TRAIL_LEVEL (rt_traversal.h:8): deeper trees are UB in the reference

@@ -81,6 +81,8 @@ struct vx_device {
   vxrt_accel_t* accel = nullptr;
   vxrc_accel_t* rc_accel = nullptr;   // layout of the raycast twin's scene, rebuilt when one of its buffers is re-uploaded
   uint64_t rc_key[16] = {0};
+  // reference-quirks mode (DCR 0x7F4): flat image of the address space, camera rays and hit records of the frame
+  void* q_image = nullptr; uint64_t q_image_size = 0, q_image_ver = ~0ull; void* q_rays = nullptr; void* q_hits = nullptr; uint64_t q_rays_cap = 0;
   uint64_t accel_key[14] = {0};
 
   int init() {
@@ -95,7 +97,7 @@ struct vx_device {
     if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
     if (hipEventCreate(&ev_begin) != hipSuccess || hipEventCreate(&ev_end) != hipSuccess) return -1;
     if (hipMalloc((void**)&d_rays, sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (hipHostMalloc((void**)&h_back, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return -1;
+    if (hipHostMalloc((void**)&h_back, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return -1;
     h_back[0] = h_back[1] = 0;
     return 0;
   }
@@ -108,6 +110,9 @@ struct vx_device {
     for (auto& kv : allocs) if (kv.second.dptr && !kv.second.pooled) (void)hipFree(kv.second.dptr);
     for (void* sl : slabs) (void)hipFree(sl);
     if (d_rays) (void)hipFree(d_rays);
+    if (q_image) (void)hipFree(q_image);
+    if (q_rays) (void)hipFree(q_rays);
+    if (q_hits) (void)hipFree(q_hits);
     if (h_back) (void)hipHostFree(h_back);
     if (ev_begin) (void)hipEventDestroy(ev_begin);
     if (ev_end) (void)hipEventDestroy(ev_end);
@@ -378,9 +383,54 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
     std::memcpy(accel_key, key, sizeof key);
   }
 
+  uint32_t* dstp = (uint32_t*)((char*)r_dst.a->dptr + r_dst.off);
+  uint32_t quirks = 0;
+  dcr(VX_DCR_HIP_REFERENCE_QUIRKS, &quirks);
+  if (quirks) {
+    // reference-quirks mode: the frame's camera rays through the literal restatement of the RTU on a flat image of the address space
+    if (shadow || row_stride > 1 || ka.max_depth > 1) { VXLOG("start: reference-quirks mode renders closest-hit frames only (no shadow extension, row stride or mirror bounce)"); return -1; }
+    uint64_t hi = 0, ver = 0;
+    for (auto& kv : allocs) if (!kv.second.reserved && kv.first < 0x80000000ull) { hi = std::max(hi, kv.second.va + kv.second.span); ver = ver * 1315423911ull + kv.second.version + kv.first; }
+    if (hi == 0 || hi > 0xFFFFFFFFull) { VXLOG("start: reference-quirks mode needs the scene below 4 GiB of device address space"); return -1; }
+    if (q_image_size < hi) {
+      if (q_image) (void)hipFree(q_image);
+      q_image = nullptr; q_image_size = 0; q_image_ver = ~0ull;
+      if (hipMalloc(&q_image, hi) != hipSuccess) return -1;
+      q_image_size = hi;
+    }
+    if (q_image_ver != ver) {
+      if (hipMemsetAsync(q_image, 0, q_image_size, stream) != hipSuccess) return -1;
+      for (auto& kv : allocs) {
+        const Alloc& al = kv.second;
+        if (al.reserved || kv.first >= 0x80000000ull || !al.dptr) continue;
+        if (hipMemcpyAsync((char*)q_image + al.va, al.dptr, al.size, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
+      }
+      q_image_ver = ver;
+    }
+    const uint64_t nr = (uint64_t)ka.dst_width * (y1 - y0);
+    if (q_rays_cap < nr) {
+      if (q_rays) (void)hipFree(q_rays);
+      if (q_hits) (void)hipFree(q_hits);
+      q_rays = q_hits = nullptr; q_rays_cap = 0;
+      if (hipMalloc(&q_rays, nr * 24) != hipSuccess || hipMalloc(&q_hits, nr * 24) != hipSuccess) return -1;
+      q_rays_cap = nr;
+    }
+    if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
+    if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
+    int rc = vxrt_camera_rays(ka.dst_width, ka.dst_height, y0, y1, (float*)q_rays, stream);
+    // (the DCRs hold 32-bit device addresses: offsets into the image, as they are addresses into the simulator's RAM)
+    if (rc == 0) rc = vxrt_trace_reference_quirks(q_image, q_image_size, d_tlas, d_blas, d_bvh, d_tri, (const float*)q_rays, nr, nullptr, (vxrt_hit_t*)q_hits, VXRT_MODE_CLOSEST, stream);
+    if (rc == 0) rc = vxrt_shade_rays(accel, (const float*)q_rays, (const vxrt_hit_t*)q_hits, nr, &sp, nullptr, dstp + (size_t)y0 * ka.dst_width, stream);
+    h_back[2] = nr;   // (pinned; the stream reads it after this call returns)
+    if (rc == 0 && hipMemcpyAsync(d_rays, &h_back[2], sizeof(unsigned long long), hipMemcpyHostToDevice, stream) != hipSuccess) rc = -1;
+    if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
+    if (rc != 0) { VXLOG("start: reference-quirks launch rejected"); return -1; }
+    if (enqueue_readback() != 0) return -1;
+    run_pending = true;
+    return 0;
+  }
   if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
   if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
-  uint32_t* dstp = (uint32_t*)((char*)r_dst.a->dptr + r_dst.off);
   int rc = row_stride > 1 ? vxrt_render_interleaved(accel, ka.dst_width, ka.dst_height, y0 / 8u, row_stride, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream)
                           : vxrt_render(accel, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream);
   if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;

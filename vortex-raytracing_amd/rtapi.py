@@ -117,6 +117,17 @@ def accel_frames_in_flight(accel, n):
         raise RuntimeError("vxrt_accel_frames_in_flight(%r) failed" % (n,))
 
 
+def trace_reference_quirks(image_ptr, image_size, offsets, rays_ptr, n, hits_ptr, mode=MODE_CLOSEST, tmax_ptr=None, stream=None):
+    """vxrt_trace_reference_quirks: the RTU's traversal restated literally (stale base_ptr included) on a flat memory image;
+    offsets = (tlas, blas, bvh, tri) byte offsets into the image, i.e. the values of the RTX DCRs 0x6..0x9."""
+    L = _lib()
+    L.vxrt_trace_reference_quirks.restype = C.c_int
+    L.vxrt_trace_reference_quirks.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    check(L.vxrt_trace_reference_quirks(image_ptr, image_size, offsets[0], offsets[1], offsets[2], offsets[3], rays_ptr, n, tmax_ptr, hits_ptr, mode, stream),
+          "vxrt_trace_reference_quirks")
+
+
 def debug_read_control(accel, ctx=0, n_dwords=800, stream=None):
     """vxrt_debug_read_control: the control block of frame context `ctx` (numpy u32) as the last call left it."""
     import numpy as np
