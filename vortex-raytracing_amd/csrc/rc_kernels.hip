@@ -34,14 +34,15 @@
 #define RC_EPSILON 1e-6f
 #define RC_STACK 64             // BVH_STACK_SIZE of the reference (deeper = undefined behaviour there, status bit here)
 #ifndef RC_LDS_STACK
-#define RC_LDS_STACK 12         // stack entries kept in LDS per lane; deeper ones in scratch (12 + 6 wavefronts per SIMD: +2 % over 16 + 5)
+#define RC_LDS_STACK 8          // stack entries kept in LDS per lane; deeper ones in scratch (8 + 7 wavefronts per SIMD: +1 % over 12 + 6, +3 % over 16 + 5)
 #endif
 #ifndef RC_WAVES
-#define RC_WAVES 6              // wavefronts per SIMD the kernel is compiled for
+#define RC_WAVES 7              // wavefronts per SIMD the kernel is compiled for
 #endif
 #define RC_STATUS_STACK 1u      // same bits as the RTU path's status word
 #define RC_STATUS_ITER 2u
 #define RC_STATUS_BAD_SCENE 4u
+#define RC_STATUS_SLOW_BOXES 16u  // build-time only: a reachable box is not lo <= hi, finite and within 2^60: the scene keeps the libstdc++ min/max slab form
 #define RC_TLAS_ITER_LIMIT (1u << 20)   // the TLAS is taken as uploaded (not re-laid out), so its walk is bounded
 #define RC_QUEUE_SHARDS 8u
 #define RC_QUEUE_STRIDE 32u
@@ -73,6 +74,7 @@ struct RcDev {
   const float4* tri_w;                     // wide triangles in triIdx order: (v0, e1.x) (e1.yz, e2.xy) (e2.z, triIdx, -, -)
   const uint32_t* blas_root;               // per instance record: descriptor of its BVH root
   uint32_t n_tri_idx;
+  uint32_t fast_boxes;                     // 1: every box of the compact nodes is lo <= hi, finite, within 2^60 (checked by the build): the sign-selected slab form is exact for rays in the fast domain
 };
 
 struct RcParams {
@@ -162,6 +164,13 @@ __global__ void rc_accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t
   const uint32_t l = base + w[3], r = l + 1;
   const uint32_t* lw = ref + (size_t)l * 8;
   const uint32_t* rw = ref + (size_t)r * 8;
+  // the fast slab form (rc_persistent_kernel) takes the plane on the side the ray comes from as the near one: exact only for lo <= hi,
+  // and NaN-free only for bounded planes
+  for (int k = 0; k < 3; ++k) {
+    const float l0 = __uint_as_float(lw[k]), l1 = __uint_as_float(lw[4 + k]), r0 = __uint_as_float(rw[k]), r1 = __uint_as_float(rw[4 + k]);
+    if (!(l0 <= l1) || !(r0 <= r1) || !(fabsf(l0) <= 0x1p+60f) || !(fabsf(l1) <= 0x1p+60f) || !(fabsf(r0) <= 0x1p+60f) || !(fabsf(r1) <= 0x1p+60f))
+      atomicOr(status, RC_STATUS_SLOW_BOXES);
+  }
   uint4* o = out + (size_t)i * 4;
   o[0] = make_uint4(lw[0], lw[1], lw[2], lw[4]);                 // L.min.xyz, L.max.x
   o[1] = make_uint4(lw[5], lw[6], rw[0], rw[1]);                 // L.max.yz, R.min.xy
@@ -217,6 +226,7 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
   // active object-space ray and traversal state in registers
   float rox = 0, roy = 0, roz = 0, rix = 0, riy = 0, riz = 0, hitd = 0;
   uint32_t cur = RC_CUR_IDLE, cur_blas = 0, sp = 0, tsp = 0, titer = 0;
+  bool lfast = false;                // the lane's object-space ray is in the fast domain (and the scene's boxes allow the fast slab form)
   // pixel / path state
   uint32_t px = 0, py = 0, smp = 0, bounce = 0;
   float cr = 0, cg = 0, cb = 0, rr = 0, rg = 0, rb = 0, thr = 1.0f;
@@ -288,10 +298,34 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
         // ---- BVH internal node (render.h:99-121): both children's boxes in one 64-byte record ----
         const uint4* np = sc.nodes_c + (size_t)cur * 4;
         const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-        const float dLeft = ray_box(rox, roy, roz, rix, riy, riz, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z),
-                                    __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
-        const float dRight = ray_box(rox, roy, roz, rix, riy, riz, __uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x),
-                                     __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w));
+        float dLeft, dRight;
+        if (__all(!rc_is_node(cur) || lfast)) {
+          // Fast slab form (wave-uniform choice; the other form is always valid).  For a box with lo <= hi and a ray whose slab
+          // products cannot be NaN or overflow, (lo - o) * (1/d) and (hi - o) * (1/d) are ordered by the sign of 1/d alone, so the
+          // std::min / std::max of each pair (geometry.h:1445-1458) IS the product with the plane on the near / far side: six
+          // selects per box replace twelve compare + select pairs, and the chains collapse into v_max3 / v_min3.  Same values
+          // (a +0 / -0 difference cannot reach a comparison's outcome), so the same decisions and the same hit.
+          const bool nx = rix < 0.0f, ny = riy < 0.0f, nz = riz < 0.0f;
+          const float lx0 = __uint_as_float(q0.x), ly0 = __uint_as_float(q0.y), lz0 = __uint_as_float(q0.z);
+          const float lx1 = __uint_as_float(q0.w), ly1 = __uint_as_float(q1.x), lz1 = __uint_as_float(q1.y);
+          const float rx0 = __uint_as_float(q1.z), ry0 = __uint_as_float(q1.w), rz0 = __uint_as_float(q2.x);
+          const float rx1 = __uint_as_float(q2.y), ry1 = __uint_as_float(q2.z), rz1 = __uint_as_float(q2.w);
+          {
+            const float tn = fmaxf(fmaxf(((nx ? lx1 : lx0) - rox) * rix, ((ny ? ly1 : ly0) - roy) * riy), ((nz ? lz1 : lz0) - roz) * riz);
+            const float tf = fminf(fminf(((nx ? lx0 : lx1) - rox) * rix, ((ny ? ly0 : ly1) - roy) * riy), ((nz ? lz0 : lz1) - roz) * riz);
+            dLeft = (tf < tn || tf <= 0) ? RC_LARGE_FLOAT : tn;
+          }
+          {
+            const float tn = fmaxf(fmaxf(((nx ? rx1 : rx0) - rox) * rix, ((ny ? ry1 : ry0) - roy) * riy), ((nz ? rz1 : rz0) - roz) * riz);
+            const float tf = fminf(fminf(((nx ? rx0 : rx1) - rox) * rix, ((ny ? ry0 : ry1) - roy) * riy), ((nz ? rz0 : rz1) - roz) * riz);
+            dRight = (tf < tn || tf <= 0) ? RC_LARGE_FLOAT : tn;
+          }
+        } else {
+          dLeft = ray_box(rox, roy, roz, rix, riy, riz, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z),
+                          __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+          dRight = ray_box(rox, roy, roz, rix, riy, riz, __uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x),
+                           __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w));
+        }
         uint32_t left = q3.x, right = q3.y;
         const bool hitLeft = (dLeft != RC_LARGE_FLOAT) && (dLeft < hitd);
         const bool hitRight = (dRight != RC_LARGE_FLOAT) && (dRight < hitd);
@@ -349,6 +383,9 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
                   roy = M[4] * ox + M[5] * oy + M[6] * oz + M[7] * 1.0f;
                   roz = M[8] * ox + M[9] * oy + M[10] * oz + M[11] * 1.0f;
                   rix = 1.0f / bdx; riy = 1.0f / bdy; riz = 1.0f / bdz;
+                  // fast domain of the slab test (as on the RTU path): 1/d finite, non-zero, at most 2^64; origin at most 2^60
+                  lfast = sc.fast_boxes != 0u && fabsf(rix) <= 0x1p+64f && fabsf(riy) <= 0x1p+64f && fabsf(riz) <= 0x1p+64f && rix != 0.0f && riy != 0.0f && riz != 0.0f &&
+                          fabsf(rox) <= 0x1p+60f && fabsf(roy) <= 0x1p+60f && fabsf(roz) <= 0x1p+60f;
                   CTX(6) = __float_as_uint(bdx); CTX(7) = __float_as_uint(bdy); CTX(8) = __float_as_uint(bdz);
                   cur_blas = blasIdx;
                   sp = 0;
@@ -471,6 +508,7 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
 struct vxrc_accel {
   vxrc_scene_t ref{};
   void* nodes_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr; uint32_t* ctl = nullptr;
+  uint32_t fast_boxes = 0;   // see RcDev
 };
 
 extern "C" int vxrc_accel_destroy(vxrc_accel_t* a) {
@@ -528,7 +566,8 @@ extern "C" int vxrc_accel_build(const vxrc_scene_t* s, void* stream, vxrc_accel_
          hipMemcpy(&hstatus, d_status, 4, hipMemcpyDeviceToHost) == hipSuccess;
   }
   (void)hipFree(d_ranges); (void)hipFree(d_status);
-  if (!ok || hstatus != 0) { vxrc_accel_destroy(a); return -1; }
+  if (!ok || (hstatus & ~RC_STATUS_SLOW_BOXES) != 0) { vxrc_accel_destroy(a); return -1; }
+  a->fast_boxes = (hstatus & RC_STATUS_SLOW_BOXES) ? 0u : 1u;
   *out = a;
   return 0;
 }
@@ -551,6 +590,7 @@ extern "C" int vxrc_render_accel(vxrc_accel_t* a, uint32_t width, uint32_t heigh
   d.tlas_root = s->tlas_root;
   d.nodes_c = (const uint4*)a->nodes_c; d.tri_w = (const float4*)a->tri_w; d.blas_root = (const uint32_t*)a->blas_root;
   d.n_tri_idx = s->n_tri_idx;
+  d.fast_boxes = a->fast_boxes;
   RcParams p{};
   for (int i = 0; i < 3; ++i) {
     p.cpos[i] = prm->camera_pos[i]; p.cfwd[i] = prm->camera_forward[i]; p.cright[i] = prm->camera_right[i]; p.cup[i] = prm->camera_up[i];
