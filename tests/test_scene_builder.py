@@ -341,7 +341,7 @@ def test_tree_quality_anchored_to_the_reference_builder(vrt, po, golden, name):
     """The committed fixtures hold the tree the REFERENCE's builder made of its own assets (bvh.cpp:30-264 through oracle/_ref).  On the
     same triangles and the fixture's rays, the package's SAH tree must not cost more algorithmic bytes per ray (52 B per node fetch,
     36 B per triangle test) than the reference's: it spends more triangle tests (leaves of up to 4) to save node
-    fetches.  tools/tree_quality.py prints the same comparison at the benchmark's scale (profiles/r03_d_tree_quality.txt)."""
+    fetches.  tests/tree_quality.py prints the same comparison at the benchmark's scale (profiles/r03_d_tree_quality.txt)."""
     g = golden(name)
     tri = g["tri"].view(np.float32).reshape(-1, 9)
     ours = vrt.scene.from_triangles([tri])

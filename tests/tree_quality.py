@@ -5,7 +5,7 @@ used here only to produce the tree that is measured): for the same triangles, th
   * node / triangle fetches per ray and algorithmic bytes per ray (52 B per node, 36 B per triangle: SURVEY s8d) of the canonical
     traversal (oracle restatement, CPU) on a sample of the frame's camera rays,
   * with a GPU: Grays/s of the frame (primary + shadow, serial frames) on each tree through the same HIP kernels.
-usage: tools/tree_quality.py [--gpu] [--levels 6 8] [--fixtures teapot torus]"""
+usage: python tests/tree_quality.py [--gpu] [--levels 6 8] [--fixtures teapot torus]"""
 import argparse
 import importlib
 import json
@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (this harness lives under tests/: it runs the checker -- oracle/ -- which tools/ may not)
 sys.path.insert(0, ROOT)
 vrt = importlib.import_module("vortex-raytracing_amd")
 from oracle import pyoracle as po   # noqa: E402
