@@ -117,3 +117,42 @@ def test_random_scenes_frames_with_shadow(vrt, po, gpu_device, seed):
         want_f, _, _, _ = po.render_ex(sc, w, h, po.shade_params(light_pos=lights[f]), 1)
         assert np.array_equal(buf[f].cpu().numpy().view(np.uint32), want_f), "frame %d of the batch" % f
     ds.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_reference_quirks_mode_equals_the_faithful_restatement_on_random_deep_tlas_scenes(vrt, po, gpu_device, seed):
+    """The opt-in quirks traversal (vxrt_trace_reference_quirks) against the oracle's FAITHFUL restatement -- the one pinned to the
+    reference's object code -- on random scenes of 6-14 instances (a TLAS deeper than one level, where the stale base_ptr of
+    rt_traversal.cpp:91-92 fires) and all ray kinds incl. zero direction components: bit-equal, closest hit and first accepted
+    candidate, and the quirk is live (some rays differ from the canonical traversal)."""
+    import torch
+    rng = np.random.default_rng(7000 + seed)
+    n_inst = int(rng.integers(6, 15))
+    meshes, xf = [], []
+    for i in range(n_inst):
+        meshes.append(_soup(rng, int(rng.integers(30, 200))))
+        m = np.eye(4)
+        m[:3, :3] = _rot(rng) @ np.diag(rng.uniform(8, 40, 3))
+        m[:3, 3] = (rng.uniform(150, 400), rng.uniform(40, 160), rng.uniform(-150, 150))
+        xf.append(m.astype(np.float32))
+    sc = vrt.scene.from_triangles(meshes, xf)
+    lo, hi = np.array([100.0, 0.0, -200.0]), np.array([450.0, 200.0, 200.0])
+    rays = _rays(rng, po, lo, hi)
+    img = po.Image(sc)
+    mem = torch.from_numpy(img.mem).to(gpu_device)
+    r = torch.from_numpy(np.ascontiguousarray(rays, np.float32)).to(gpu_device)
+    offs = (img.off["tlas"], img.off["blas"], img.off["bvh"], img.off["tri"])
+    s = torch.cuda.current_stream().cuda_stream
+    n = len(rays)
+    stale = 0
+    for mode, any_hit in ((vrt.rtapi.MODE_CLOSEST, False), (vrt.rtapi.MODE_ANY, True)):
+        out = torch.zeros(n * 24, dtype=torch.uint8, device=gpu_device)
+        vrt.rtapi.trace_reference_quirks(mem.data_ptr(), mem.numel(), offs, r.data_ptr(), n, out.data_ptr(), mode, None, s)
+        assert vrt.rtapi.status(s) == 0
+        want, st = po.trace_faithful(img, rays, any_hit=any_hit)
+        got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=want.dtype)[:n]
+        assert np.array_equal(_bits(got), _bits(want))
+        stale += st["stale_base"]
+    canon, _ = po.trace_canonical(sc, rays)
+    want, _ = po.trace_faithful(img, rays)
+    assert stale > 0 and (_bits(canon).reshape(n, -1) != _bits(want).reshape(n, -1)).any(1).sum() > 0

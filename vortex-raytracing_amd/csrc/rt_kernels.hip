@@ -1622,7 +1622,8 @@ __global__ __launch_bounds__(64) void rt_quirks_trace_kernel(QuirkImage im, cons
     ss_head = (ss_head + 1u) % 5u;
   };
   bool accepted = false;
-  for (uint32_t guard = 0; guard < (1u << 20); ++guard) {   // one pass of traverse() per accepted candidate
+  bool limit = true;
+  for (uint32_t guard = 0; guard < (1u << 16); ++guard) {   // one pass of traverse() per accepted candidate (a ray accepts a handful)
     uint32_t level = 0, base_ptr = im.tlas_ptr, node_ptr = im.tlas_ptr, blasIdx = 0;
     float cx = ox, cy = oy, cz = oz, cdx = dx, cdy = dy, cdz = dz;   // cur_ray
     bool finished = false, pending = false;
@@ -1644,7 +1645,8 @@ __global__ __launch_bounds__(64) void rt_quirks_trace_kernel(QuirkImage im, cons
       }
       return false;
     };
-    for (uint32_t it = 0; it < ITER_LIMIT && !finished && !pending; ++it) {
+    uint32_t it = 0;
+    for (; it < ITER_LIMIT && !finished && !pending; ++it) {
       uint32_t w[RT_NODE_DWORDS];
       q_read(im, w, node_ptr, RT_NODE_DWORDS);
       const uint32_t imask = w[3] >> 24, leftFirst = w[4], leafData = w[5];
@@ -1716,11 +1718,12 @@ __global__ __launch_bounds__(64) void rt_quirks_trace_kernel(QuirkImage im, cons
         if (!pending) finished = pop();
       }
     }
-    if (!pending) break;                       // traversal completed (or the iteration backstop)
+    if (!pending) { limit = !finished; break; }   // traversal completed -- or the iteration backstop ran out (reported below)
     hit.dist = pending_dist;                   // rt_unit.cpp:199-202 COMMIT_ACCEPT, then traverse again from the root with the kept trail
     accepted = true;
-    if (any_hit_first) break;
+    if (any_hit_first) { limit = false; break; }
   }
+  if (limit) atomicOr(status, STATUS_ITER_LIMIT);   // the walk did not end within the backstops (the reference would still be spinning)
   if (!accepted) { hit.dist = RT_LARGE_FLOAT; hit.bx = 0; hit.by = 0; hit.bz = 0; hit.blasIdx = 0; hit.triIdx = 0; }
   out[r] = hit;
 }
