@@ -155,6 +155,47 @@ def test_the_timed_call_itself_matches_oracle(vrt, po, gpu_device, atrium):
         assert torch.equal(one, bufs[0][f])
 
 
+def test_a_ranks_batches_with_the_learned_tile_order_match_oracle(vrt, po, gpu_device, atrium):
+    """What rank 1 of 4 does in a multi-GPU run of bench.py: batches of 10 frames' shares (interleaved tile rows, 81,600 tiles per
+    batch), on two streams.  From a context's second batch on, the tiles are traced longest first in the order learned from the
+    batch before (vxrt's LPT for batches of <= 100 K tiles) -- the pixels cannot depend on it: every batch equals the first,
+    frame 3's rows equal the same share rendered alone, and a band of its rows equals the oracle's frame."""
+    import torch
+    sc, ds = atrium
+    w, h, rank, world, n = 1920, 1080, 1, 4, 10
+    ig = vrt.sharding.InterleavedGather(h, w, rank, world, gpu_device, slots=1, collective=False, batch=n)
+    lights = [(300.0 - 20.0 * f, 480.0 - 8.0 * f, 60.0 + 15.0 * f) for f in range(n)]
+    plist = []
+    for f in range(n):
+        p = vrt.rtapi.default_shade_params()
+        p.light_pos[:] = lights[f]
+        plist.append(p)
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(2)]
+    bufs = [ig.new_frame_buffer(gpu_device) for _ in range(6)]
+    vrt.rtapi.accel_frames_in_flight(ds.accel, 2)
+    try:
+        torch.cuda.synchronize()
+        for i, b in enumerate(bufs):      # contexts follow their streams: each context sees three batches, the last two with a learned order
+            vrt.rtapi.render_interleaved_batch(ds.accel, w, h, rank, world, plist, b.data_ptr(), ig.frame_stride, 1, None, streams[i % 2].cuda_stream)
+        torch.cuda.synchronize()
+        assert vrt.rtapi.status(streams[0].cuda_stream) == 0
+    finally:
+        vrt.rtapi.accel_frames_in_flight(ds.accel, 1)
+    for b in bufs[1:]:
+        assert torch.equal(b, bufs[0])
+    rows = vrt.sharding.interleaved_rows(h, rank, world)
+    one = torch.zeros((ig.padded_height, w), dtype=torch.int32, device=gpu_device)
+    s0 = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.render_interleaved(ds.accel, w, h, rank, world, plist[3], one.data_ptr(), 1, None, None, None, s0)
+    torch.cuda.synchronize()
+    assert torch.equal(bufs[-1][3], one)
+    y0, y1 = 520, 552          # holds this rank's tile row 65 (rows 520-527) and the v == 0 row of the frame is next to it
+    mine = rows[(rows >= y0) & (rows < y1)]
+    assert len(mine) == 8
+    want, _, _, _ = po.render_ex(sc, w, h, po.shade_params(light_pos=lights[3]), 1, int(mine[0]), int(mine[-1]) + 1)
+    np.testing.assert_array_equal(bufs[-1][3].cpu().numpy().view(np.uint32)[mine], want[mine])
+
+
 def test_serial_frames_with_learned_tile_order_match_pipelined(vrt, po, gpu_device, atrium):
     """One frame in flight takes the longest-tile-first order from its second frame on; the frame cannot depend on it."""
     sc, ds = atrium
