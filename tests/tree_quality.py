@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Tree quality anchored to the REFERENCE's builder (tests/regression/raytracing/bvh.cpp:30-264, through oracle/_ref -- checker code,
 used here only to produce the tree that is measured): for the same triangles, the reference-built BVH4, the package's CPU SAH tree
-(csrc/scene_builder.cpp) and, with a GPU, the tree of vxrt_bvh_build (csrc/bvh_builder.hip) --
+(csrc/scene_builder.cpp) and, with a GPU, the tree of vxrt_bvh_build (csrc/bvh_builder.hip: Morton order, PLOC clustering, SAH-optimal 4-wide collapse) --
   * node / triangle fetches per ray and algorithmic bytes per ray (52 B per node, 36 B per triangle: SURVEY s8d) of the canonical
     traversal (oracle restatement, CPU) on a sample of the frame's camera rays,
   * with a GPU: Grays/s of the frame (primary + shadow, serial frames) on each tree through the same HIP kernels.
@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("--levels", type=int, nargs="*", default=[6, 8])
     ap.add_argument("--fixtures", nargs="*", default=["teapot", "torus"])
+    ap.add_argument("--leaf-max", type=int, nargs="*", default=[0], help="vxrt_bvh_build's largest leaf (0 = its default); several = one GPU tree each")
     a = ap.parse_args()
     if not po.have_ref():
         raise SystemExit("oracle/_ref/libvxref.so (the reference's builder) is not built")
@@ -82,7 +83,7 @@ def main():
                "reference_tree": fetches(g, g["rays"]), "cpu_sah_tree": fetches(ours, g["rays"])}
         if a.gpu:
             ds = vrt.tracer.DeviceScene.build_on_gpu(tri, None, None, None, "cuda:0")
-            row["gpu_morton_tree"] = fetches(ds.to_host(), g["rays"])
+            row["gpu_tree"] = fetches(ds.to_host(), g["rays"])
             ds.close()
         print(json.dumps(row), flush=True)
     LIGHT = (300.0, 480.0, 60.0)
@@ -115,9 +116,12 @@ def main():
             row["reference_tree"].update(gpu_rate(refd, w, h, LIGHT))
             row["cpu_sah_tree"].update(gpu_rate(sc, w, h, LIGHT))
             ex = sc["triEx"].reshape(-1, 64)
-            dsg = vrt.tracer.DeviceScene.build_on_gpu(tri, ex, sc["mat"], sc["tex"], "cuda:0")
-            row["gpu_morton_tree"] = fetches(dsg.to_host(), rays)
-            row["gpu_morton_tree"].update(gpu_rate(dsg, w, h, LIGHT))
+            for lm in a.leaf_max:
+                key = "gpu_tree" if lm == 0 else "gpu_tree_leaf_max_%d" % lm
+                dsg = vrt.tracer.DeviceScene.build_on_gpu(tri, ex, sc["mat"], sc["tex"], "cuda:0", leaf_max=lm)
+                row[key] = fetches(dsg.to_host(), rays)
+                row[key].update({"nodes": int(dsg.bvh_info.n_nodes), "depth": int(dsg.bvh_info.max_depth)})
+                row[key].update(gpu_rate(dsg, w, h, LIGHT))
         print(json.dumps(row), flush=True)
 
 

@@ -3,19 +3,20 @@
 // Reference: tests/regression/raytracing/bvh.cpp:30-264 -- BVH::build (binned SAH, binary), the collapse to 4-wide nodes and
 // the quantiser, all host code run once per mesh at scene load; triangles are reordered in place so that a leaf is a range
 // (bvh.cpp:126-128).  csrc/scene_builder.cpp is this package's CPU counterpart (threaded SAH, the quality builder).  This file
-// is the builder for geometry that changes per frame: the whole build is a dozen launches over data that never leaves HBM.
+// is the builder for geometry that changes per frame: some sixty short launches over data that never leaves HBM.
 //
 //   1. centroid bounds              one pass, wavefront reduction + 6 atomics per workgroup
-//   2. 63-bit Morton keys           21 bits per axis of the triangle's box centre
+//   2. 63-bit Morton keys           21 bits per axis of the triangle's box centre (extended order)
 //   3. radix sort (key, index)      rocPRIM device sort, 8 passes over 12 bytes per triangle
-//   4. binary radix tree            Karras 2012: every internal node finds its range and split independently (no recursion,
-//                                   no dependence between nodes); equal keys are told apart by their index
-//   5. boxes bottom-up              one thread per triangle climbs; the second thread to reach a node owns it
-//   6. collapse to 4-wide + quantise + emit, level by level: a node adopts its binary children and then, twice, replaces the
-//      adopted subtree of largest surface area by that subtree's two children; subtrees of <= leaf_max triangles become
-//      leaves (a subtree of the radix tree is a contiguous range of the sorted order).  Children are allocated after their
-//      parent, which is what vxrt_accel_build's validation asks of any tree.
-//   7. triangles (and their shading records) gathered into the sorted order.
+//   4. clustering                   PLOC: rounds of "merge the pairs that are each other's nearest neighbour within 4 positions of
+//                                   the Morton order" (nearest = smallest surface area of the union), boxes and the SAH dynamic
+//                                   programme of the 4-wide collapse computed as the nodes are made; the last 1,024 clusters in
+//                                   one workgroup.  (Rounds 1-2: Karras' binary radix tree + a bottom-up box pass.)
+//   5. collapse to 4-wide + quantise + emit, level by level, following the dynamic programme's choices; every child gets its
+//      range of the final triangle order from its parent; a subtree marked as a leaf (<= leaf_max triangles, and cheaper as
+//      a leaf) lists its triangles there.  Children are allocated after their parent, which is what vxrt_accel_build's
+//      validation asks of any tree.
+//   6. triangles (and their shading records) gathered into the final order.
 //
 // Quantisation follows the format (decode = origin + ldexp(q, e), rt_traversal.cpp:61-67) and is conservative by
 // construction: every q is checked against the decode's own rounding and the exponent is raised until all children fit.
@@ -42,16 +43,6 @@ constexpr int BB_MAX_LEVELS = 34;   // launches of the collapse pass; a tree dee
 
 struct Box3 { float lx, ly, lz, hx, hy, hz; };
 
-// One 48-byte record per node of the binary radix tree (internal i in [0, n-1), leaf j as n-1+j): everything the later passes
-// read about a node in three aligned 16-byte loads of ONE cache line (separate child / range / box arrays cost the collapse pass
-// some fifteen scattered lines per item).
-struct __attribute__((aligned(16))) BNode {
-  float lx, ly, lz; uint32_t left;
-  float hx, hy, hz; uint32_t right;
-  uint32_t first, last, pad0, pad1;
-};
-static_assert(sizeof(BNode) == 48, "record size");
-
 __device__ __forceinline__ int f2ord(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7fffffff); }
 
@@ -72,12 +63,12 @@ __device__ __forceinline__ Box3 prim_box(const float* __restrict__ prims, uint32
   return b;
 }
 
-__global__ void bb_init_kernel(int* cb, uint32_t* counters, uint32_t n_counters, uint2* level0) {
+__global__ void bb_init_kernel(int* cb, uint32_t* counters, uint32_t n_counters, uint4* level0) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 3) cb[i] = 0x7fffffff;
   else if (i < 6) cb[i] = (int)0x80000000;
   if (i < n_counters) counters[i] = (i == 0 || i == 8) ? 1u : 0u;
-  if (i == 0) level0[0] = make_uint2(0u, 0u);   // (node id 0 is the binary root, or the only leaf when n == 1)
+  if (i == 0) level0[0] = make_uint4(0u, 0u, 0u, 0u);   // (binary node 0 -- the root, or the only leaf when n == 1 -- into slot 0, triangles from 0)
 }
 
 // ---- 1. bounds of the box centres ----
@@ -158,83 +149,316 @@ __global__ __launch_bounds__(256) void bb_morton_kernel(const float* __restrict_
   vals[i] = i;
 }
 
-// ---- 4. binary radix tree (Karras, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees", 2012) ----
-// node ids: internal i in [0, n-1), leaf j as (n-1) + j; internal 0 is the root
-__device__ __forceinline__ int bb_delta(const uint64_t* __restrict__ k, int n, int i, int j) {
-  if (j < 0 || j >= n) return -1;
-  const uint64_t a = k[i], b = k[j];
-  return a == b ? 64 + __clz(i ^ j) : __clzll((long long)(a ^ b));
+// ---- 4. clustering: PLOC (Meister & Bittner, "Parallel locally-ordered clustering for BVH construction", 2018) ----
+// The clusters -- at first one per triangle, in Morton order -- are merged bottom-up in rounds: every cluster looks at the
+// BB_RADIUS clusters on either side of it in the array for the one whose union with it has the smallest surface area; two clusters
+// that choose each other become a node; the array is compacted in place order and the round repeats.  Unlike the binary radix tree
+// of rounds 1-2 (which splits the Morton range at its highest differing bit, a spatial median) the pairs are chosen by the area of
+// the result, which is what the traversal pays for.  Everything is deterministic: ties go to the lower position, node ids and the
+// compacted positions come from prefix sums, nothing from the order in which atomics land.
+//   node ids: leaf j (sorted position) is n-1+j; internal ids are handed out downwards from n-2, so the last merge -- the root -- is 0.
+// A round that merges fewer than 1/16 of the clusters is followed by one of forced pairing (positions 2k, 2k+1): inputs where
+// nearly nothing is mutual (a thousand coincident triangles: every union has the same area) still finish in O(log n) rounds.
+//
+// The SAH-optimal collapse to 4-wide nodes (the dynamic programme of Ylitie, Karras & Laine, "Efficient incoherent ray traversal on
+// GPUs through compressed wide BVHs", 2017, for width 4) rides in the merge: f[j] = least cost of covering the new node's subtree
+// with at most j child slots of a wide node, cost = expected bytes fetched per random ray (52 B per node record, 36 B per triangle,
+// times surface area); `plan` records the choices for the top-down pass (step 6).  A subtree of <= leaf_max triangles may become
+// a leaf where that is cheaper than a node over it.
+constexpr int BB_RADIUS = 4;          // search radius (measured on the CPU prototype, tools/ploc_prototype.py: 4 < 8 < 16 in SAH cost here)
+constexpr int BB_TAIL = 1024;         // clusters the single-workgroup tail takes over at
+constexpr float BB_NODE_COST = 52.0f, BB_TRI_COST = 36.0f;   // bytes
+
+// node of the binary tree: box, children, the dynamic programme's costs and choices
+struct __attribute__((aligned(16))) BNode {
+  float lx, ly, lz; uint32_t left;
+  float hx, hy, hz; uint32_t right;
+  float f1, f2, f3, f4;
+  uint32_t count, plan, pad0, pad1;
+};
+static_assert(sizeof(BNode) == 64, "record size");
+// active cluster of a round
+struct __attribute__((aligned(16))) Cluster {
+  float lx, ly, lz; uint32_t id;
+  float hx, hy, hz; uint32_t count;
+  float f1, f2, f3, f4;
+};
+static_assert(sizeof(Cluster) == 48, "cluster size");
+
+// plan bits: [1:0] a2, [3:2] a3, [5:4] a4 (slots given to the left child when the node's two children share 2 / 3 / 4 slots),
+// [6] [7] [8] "stays one child" with 2 / 3 / 4 slots offered, [9] leaf
+constexpr uint32_t PLAN_LEAF = 1u << 9;
+__device__ __forceinline__ uint32_t plan_a(uint32_t plan, uint32_t j) { return (plan >> (2u * (j - 2u))) & 3u; }
+__device__ __forceinline__ bool plan_self(uint32_t plan, uint32_t j) { return (plan >> (4u + j)) & 1u; }
+
+__device__ __forceinline__ float box_area(float lx, float ly, float lz, float hx, float hy, float hz) {
+  const float x = hx - lx, y = hy - ly, z = hz - lz;
+  return x * y + y * z + z * x;
 }
 
-__global__ __launch_bounds__(256) void bb_tree_kernel(const uint64_t* __restrict__ keys, int n, BNode* __restrict__ rec,
-                                                        uint32_t* __restrict__ parent) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n - 1) return;
-  const int d = bb_delta(keys, n, i, i + 1) - bb_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
-  const int dmin = bb_delta(keys, n, i, i - d);
-  int lmax = 2;
-  while (bb_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
-  int l = 0;
-  for (int t = lmax >> 1; t >= 1; t >>= 1)
-    if (bb_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
-  const int j = i + l * d;
-  const int dnode = bb_delta(keys, n, i, j);
-  int s = 0;
-  for (int t = l;;) {
-    t = (t + 1) >> 1;
-    if (bb_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-    if (t <= 1) break;
-  }
-  const int gamma = i + s * d + min(d, 0);
-  const int first = min(i, j), last = max(i, j);
-  const uint32_t left = first == gamma ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
-  const uint32_t right = last == gamma + 1 ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
-  rec[i].left = left; rec[i].right = right;
-  rec[i].first = (uint32_t)first; rec[i].last = (uint32_t)last;
-  parent[left] = (uint32_t)i;
-  parent[right] = (uint32_t)i;
-  if (i == 0) parent[0] = 0xffffffffu;
+__device__ __forceinline__ Cluster bb_merge(const Cluster& A, const Cluster& B, uint32_t id, uint32_t leaf_max, float tri_cost, uint32_t& plan) {
+  Cluster c;
+  c.lx = fminf(A.lx, B.lx); c.ly = fminf(A.ly, B.ly); c.lz = fminf(A.lz, B.lz);
+  c.hx = fmaxf(A.hx, B.hx); c.hy = fmaxf(A.hy, B.hy); c.hz = fmaxf(A.hz, B.hz);
+  c.id = id; c.count = A.count + B.count;
+  const float ar = box_area(c.lx, c.ly, c.lz, c.hx, c.hy, c.hz);
+  const float g2 = A.f1 + B.f1;
+  float g3 = A.f1 + B.f2; uint32_t a3 = 1;
+  if (A.f2 + B.f1 < g3) { g3 = A.f2 + B.f1; a3 = 2; }
+  float g4 = A.f1 + B.f3; uint32_t a4 = 1;
+  if (A.f2 + B.f2 < g4) { g4 = A.f2 + B.f2; a4 = 2; }
+  if (A.f3 + B.f1 < g4) { g4 = A.f3 + B.f1; a4 = 3; }
+  const float c_node = ar * BB_NODE_COST + g4;
+  const float c_leaf = c.count <= leaf_max ? ar * (BB_NODE_COST + tri_cost * (float)c.count) : __builtin_inff();
+  const bool leaf = c_leaf <= c_node;
+  c.f1 = leaf ? c_leaf : c_node;
+  const bool s2 = c.f1 <= g2, s3 = c.f1 <= g3, s4 = c.f1 <= g4;
+  c.f2 = s2 ? c.f1 : g2; c.f3 = s3 ? c.f1 : g3; c.f4 = s4 ? c.f1 : g4;
+  plan = 1u | (a3 << 2) | (a4 << 4) | ((uint32_t)s2 << 6) | ((uint32_t)s3 << 7) | ((uint32_t)s4 << 8) | (leaf ? PLAN_LEAF : 0u);
+  return c;
 }
 
-// ---- 5. boxes, bottom-up ----
-// Two threads meet at every internal node; the second one needs the first one's box.  A release/acquire pair at agent scope
-// (__threadfence) costs an L2 write-back + invalidate per use on this chip (the XCDs' L2s are not coherent with each other):
-// 6 ms for a million triangles.  The boxes are therefore exchanged with relaxed agent-scope atomics -- stores that write through
-// to the coherence point, loads that read there -- and the only ordering needed, "box complete before the counter moves", is the
-// wavefront waiting for its own stores (s_waitcnt) before it issues the counter's atomic.  Both sides of that ordering are spelled
-// out for the COMPILER as well: the wait is an asm statement with a memory clobber (no memory operation moves across it), and
-// the second arrival reads its sibling's box behind another one (relaxed atomics to different addresses may otherwise be
-// reordered).  The hardware part -- stores acknowledged at the coherence point before vmcnt reaches 0, loads issued in order
-// behind the returned atomic -- is what tests/test_gpu_bvh_builder.py checks exactly on the 1M-triangle tree (check_tree_fast).
-__device__ __forceinline__ float coherent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void bb_store_node(BNode* __restrict__ rec, const Cluster& c, uint32_t left, uint32_t right, uint32_t plan) {
+  float4* o = (float4*)(rec + c.id);
+  o[0] = make_float4(c.lx, c.ly, c.lz, __uint_as_float(left));
+  o[1] = make_float4(c.hx, c.hy, c.hz, __uint_as_float(right));
+  o[2] = make_float4(c.f1, c.f2, c.f3, c.f4);
+  o[3] = make_float4(__uint_as_float(c.count), __uint_as_float(plan), 0.0f, 0.0f);
+}
+__device__ __forceinline__ Cluster bb_load_cluster(const Cluster* __restrict__ p) {
+  const float4* q = (const float4*)p;
+  const float4 a = q[0], b = q[1], c = q[2];
+  Cluster r;
+  r.lx = a.x; r.ly = a.y; r.lz = a.z; r.id = __float_as_uint(a.w);
+  r.hx = b.x; r.hy = b.y; r.hz = b.z; r.count = __float_as_uint(b.w);
+  r.f1 = c.x; r.f2 = c.y; r.f3 = c.z; r.f4 = c.w;
+  return r;
+}
+__device__ __forceinline__ void bb_store_cluster(Cluster* __restrict__ p, const Cluster& c) {
+  float4* q = (float4*)p;
+  q[0] = make_float4(c.lx, c.ly, c.lz, __uint_as_float(c.id));
+  q[1] = make_float4(c.hx, c.hy, c.hz, __uint_as_float(c.count));
+  q[2] = make_float4(c.f1, c.f2, c.f3, c.f4);
+}
 
-__global__ __launch_bounds__(256) void bb_fit_kernel(const float* __restrict__ tri, const uint32_t* __restrict__ vals, uint32_t n,
-                                                       const uint32_t* __restrict__ parent, BNode* __restrict__ rec, uint32_t* __restrict__ flag, bool boxes) {
+// state of the clustering on the device: [0] clusters, [1] next internal id + 1, [2] forced pairing in this round, [3] rounds done,
+// [4] [5] clusters / next id at the start of the round being applied
+enum { ST_N = 0, ST_NEXT = 1, ST_FORCED = 2, ST_ROUNDS = 3, ST_N_OLD = 4, ST_NEXT_OLD = 5, ST_WORDS = 8 };
+
+__global__ __launch_bounds__(256) void bb_leaves_kernel(const float* __restrict__ prims, const uint32_t* __restrict__ vals, uint32_t n, bool boxes,
+                                                          float tri_cost, Cluster* __restrict__ cl, BNode* __restrict__ rec, uint32_t* __restrict__ st) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) { st[ST_N] = n; st[ST_NEXT] = n - 1; st[ST_FORCED] = 0; st[ST_ROUNDS] = 0; }
   if (j >= n) return;
-  Box3 b = prim_box(tri, vals[j], boxes);
-  uint32_t id = n - 1 + j;
-  rec[id].left = rec[id].right = 0xffffffffu; rec[id].first = rec[id].last = j;   // (a leaf: read back only by later launches)
-  for (;;) {
-    BNode* o = rec + id;
-    coherent_store(&o->lx, b.lx); coherent_store(&o->ly, b.ly); coherent_store(&o->lz, b.lz);
-    coherent_store(&o->hx, b.hx); coherent_store(&o->hy, b.hy); coherent_store(&o->hz, b.hz);
-    if (n == 1) return;
-    const uint32_t p = id == 0 ? 0xffffffffu : parent[id];
-    if (p == 0xffffffffu) return;                     // the root's box is written
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wavefront's stores have completed; nothing is moved across
-    if (__hip_atomic_fetch_add(flag + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;   // the sibling subtree is not finished: its last thread continues
-    asm volatile("" ::: "memory");                                // the sibling's box is read AFTER the counter said it is complete
-    const uint32_t l = rec[p].left, r = rec[p].right;   // (written by the previous launch)
-    const BNode* s = rec + (l == id ? r : l);
-    b.lx = fminf(b.lx, coherent_load(&s->lx)); b.ly = fminf(b.ly, coherent_load(&s->ly)); b.lz = fminf(b.lz, coherent_load(&s->lz));
-    b.hx = fmaxf(b.hx, coherent_load(&s->hx)); b.hy = fmaxf(b.hy, coherent_load(&s->hy)); b.hz = fmaxf(b.hz, coherent_load(&s->hz));
-    id = p;
+  const Box3 b = prim_box(prims, vals[j], boxes);
+  Cluster c;
+  c.lx = b.lx; c.ly = b.ly; c.lz = b.lz; c.hx = b.hx; c.hy = b.hy; c.hz = b.hz;
+  c.id = n - 1 + j; c.count = 1;
+  c.f1 = c.f2 = c.f3 = c.f4 = box_area(b.lx, b.ly, b.lz, b.hx, b.hy, b.hz) * (BB_NODE_COST + tri_cost);
+  bb_store_cluster(cl + j, c);
+  bb_store_node(rec, c, 0xffffffffu, 0xffffffffu, PLAN_LEAF);
+}
+
+// nearest neighbour of position g among [g - R, g + R] of boxes held in LDS (entry k of the tile = position s0 + k); -1 = none
+__device__ __forceinline__ int bb_nearest(const float (*sb)[6], int k, int g, int m, int s0, bool forced) {
+  if (forced) { const int j = g ^ 1; return j < m ? j : -1; }
+  float best = __builtin_inff(); int bj = -1;
+  const float lx = sb[k][0], ly = sb[k][1], lz = sb[k][2], hx = sb[k][3], hy = sb[k][4], hz = sb[k][5];
+#pragma unroll
+  for (int d = -BB_RADIUS; d <= BB_RADIUS; ++d) {
+    if (d == 0) continue;
+    const int j = g + d;
+    if (j < 0 || j >= m) continue;
+    const float* o = sb[j - s0];
+    const float a = box_area(fminf(lx, o[0]), fminf(ly, o[1]), fminf(lz, o[2]), fmaxf(hx, o[3]), fmaxf(hy, o[4]), fmaxf(hz, o[5]));
+    if (a < best || bj < 0) { best = a; bj = j; }   // (ascending j, strict <: ties go to the lower position; a NaN area never wins over a number)
+  }
+  return bj;
+}
+
+// decision of a round per position: bits [1:0] 0 stays, 1 leads a merge, 2 absorbed; bits [7:2] partner - position + BB_RADIUS
+enum { DEC_STAY = 0, DEC_LEAD = 1, DEC_GONE = 2 };
+constexpr int BB_TILE = 256, BB_HALO = 2 * BB_RADIUS;
+
+__global__ __launch_bounds__(256) void bb_ploc_decide_kernel(const Cluster* __restrict__ cl, const uint32_t* __restrict__ st,
+                                                               uint8_t* __restrict__ dec, uint2* __restrict__ tile_counts) {
+  const int m = (int)st[ST_N];
+  const bool forced = st[ST_FORCED] != 0u;
+  const int n_tiles = (m + BB_TILE - 1) / BB_TILE;
+  __shared__ float sb[BB_TILE + 2 * BB_HALO][6];
+  __shared__ int s_nn[BB_TILE + 2 * BB_HALO];
+  __shared__ uint32_t s_cnt[4][2];
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int s0 = t * BB_TILE - BB_HALO;   // position of LDS entry 0
+    for (int k = threadIdx.x; k < BB_TILE + 2 * BB_HALO; k += 256) {
+      const int g = s0 + k;
+      if (g >= 0 && g < m) {
+        const float4* q = (const float4*)(cl + g);
+        const float4 a = q[0], b = q[1];
+        sb[k][0] = a.x; sb[k][1] = a.y; sb[k][2] = a.z; sb[k][3] = b.x; sb[k][4] = b.y; sb[k][5] = b.z;
+      }
+    }
+    __syncthreads();
+    // neighbours of the tile's positions and of BB_RADIUS positions either side (their choice decides whether a pair is mutual)
+    for (int k = BB_RADIUS + threadIdx.x; k < BB_TILE + 2 * BB_HALO - BB_RADIUS; k += 256) {
+      const int g = s0 + k;
+      s_nn[k] = (g >= 0 && g < m) ? bb_nearest(sb, k, g, m, s0, forced) : -1;
+    }
+    __syncthreads();
+    const int k = BB_HALO + threadIdx.x, g = s0 + k;
+    uint32_t state = DEC_STAY; int j = -1;
+    if (g < m) {
+      j = s_nn[k];
+      if (j >= 0 && s_nn[j - s0] == g) state = g < j ? DEC_LEAD : DEC_GONE;
+      dec[g] = (uint8_t)(state | ((uint32_t)(j >= 0 ? j - g + BB_RADIUS : 0) << 2));
+    }
+    const unsigned long long keep = __ballot(g < m && state != DEC_GONE), lead = __ballot(g < m && state == DEC_LEAD);
+    if ((threadIdx.x & 63u) == 0) { s_cnt[threadIdx.x >> 6][0] = (uint32_t)__popcll(keep); s_cnt[threadIdx.x >> 6][1] = (uint32_t)__popcll(lead); }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      tile_counts[t] = make_uint2(s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0], s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1]);
+    __syncthreads();
   }
 }
 
-// ---- 6. collapse + quantise + emit ----
+// exclusive prefix of the tiles' (kept, merging) counts, and the state of the next round; one workgroup
+__global__ __launch_bounds__(1024) void bb_ploc_scan_kernel(const uint2* __restrict__ tile_counts, uint2* __restrict__ tile_base, uint32_t* __restrict__ st) {
+  const uint32_t m = st[ST_N];
+  const uint32_t n_tiles = (m + BB_TILE - 1) / BB_TILE;
+  __shared__ uint2 s_w[16];
+  __shared__ uint2 s_carry;
+  if (threadIdx.x == 0) s_carry = make_uint2(0u, 0u);
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  for (uint32_t base = 0; base < n_tiles; base += 1024u) {
+    const uint32_t t = base + threadIdx.x;
+    const uint2 v = t < n_tiles ? tile_counts[t] : make_uint2(0u, 0u);
+    uint2 inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t x = __shfl_up(inc.x, off), y = __shfl_up(inc.y, off);
+      if (lane >= (uint32_t)off) { inc.x += x; inc.y += y; }
+    }
+    if (lane == 63u) s_w[wv] = inc;
+    __syncthreads();
+    uint2 woff = s_carry;
+    for (uint32_t k = 0; k < wv; ++k) { woff.x += s_w[k].x; woff.y += s_w[k].y; }
+    if (t < n_tiles) tile_base[t] = make_uint2(woff.x + inc.x - v.x, woff.y + inc.y - v.y);
+    __syncthreads();
+    if (threadIdx.x == 1023u) s_carry = make_uint2(woff.x + inc.x, woff.y + inc.y);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint2 tot = s_carry;
+    st[ST_N_OLD] = m; st[ST_NEXT_OLD] = st[ST_NEXT];
+    st[ST_N] = tot.x; st[ST_NEXT] -= tot.y;
+    st[ST_FORCED] = (st[ST_FORCED] == 0u && tot.y < m / 16u) ? 1u : 0u;
+    st[ST_ROUNDS] += 1u;
+  }
+}
+
+__global__ __launch_bounds__(256) void bb_ploc_apply_kernel(const Cluster* __restrict__ cl, Cluster* __restrict__ out, const uint8_t* __restrict__ dec,
+                                                              const uint2* __restrict__ tile_base, const uint32_t* __restrict__ st,
+                                                              BNode* __restrict__ rec, uint32_t leaf_max, float tri_cost) {
+  const int m = (int)st[ST_N_OLD];
+  const uint32_t next = st[ST_NEXT_OLD];
+  const int n_tiles = (m + BB_TILE - 1) / BB_TILE;
+  __shared__ uint32_t s_cnt[4][2];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int g = t * BB_TILE + (int)threadIdx.x;
+    const uint32_t d = g < m ? dec[g] : (uint32_t)DEC_GONE;
+    const uint32_t state = d & 3u;
+    const unsigned long long keep = __ballot(state != DEC_GONE), lead = __ballot(state == DEC_LEAD);
+    if (lane == 0) { s_cnt[wv][0] = (uint32_t)__popcll(keep); s_cnt[wv][1] = (uint32_t)__popcll(lead); }
+    __syncthreads();
+    uint2 base = tile_base[t];
+    for (uint32_t k = 0; k < wv; ++k) { base.x += s_cnt[k][0]; base.y += s_cnt[k][1]; }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t p = base.x + (uint32_t)__popcll(keep & below);
+    if (state == DEC_STAY) {
+      bb_store_cluster(out + p, bb_load_cluster(cl + g));
+    } else if (state == DEC_LEAD) {
+      const int j = g + (int)(d >> 2) - BB_RADIUS;
+      const Cluster A = bb_load_cluster(cl + g), B = bb_load_cluster(cl + j);
+      uint32_t plan;
+      const Cluster c = bb_merge(A, B, next - 1u - (base.y + (uint32_t)__popcll(lead & below)), leaf_max, tri_cost, plan);
+      bb_store_node(rec, c, A.id, B.id, plan);
+      bb_store_cluster(out + p, c);
+    }
+  }
+}
+
+// the last BB_TAIL clusters: all remaining rounds in one workgroup, the clusters in LDS
+__global__ __launch_bounds__(1024) void bb_ploc_tail_kernel(const Cluster* __restrict__ cl, uint32_t* __restrict__ st, BNode* __restrict__ rec,
+                                                              uint32_t leaf_max, float tri_cost) {
+  __shared__ float sb[BB_TAIL][6];
+  __shared__ float sf[BB_TAIL][4];
+  __shared__ uint32_t s_id[BB_TAIL], s_count[BB_TAIL];
+  __shared__ int s_nn[BB_TAIL];
+  __shared__ uint32_t s_w[16][2];
+  int m = (int)st[ST_N];
+  uint32_t next = st[ST_NEXT];
+  bool forced = st[ST_FORCED] != 0u;
+  uint32_t rounds = st[ST_ROUNDS];
+  if (m > BB_TAIL) return;   // (the host only launches it below that)
+  const int i = (int)threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  if (i < m) {
+    const Cluster c = bb_load_cluster(cl + i);
+    sb[i][0] = c.lx; sb[i][1] = c.ly; sb[i][2] = c.lz; sb[i][3] = c.hx; sb[i][4] = c.hy; sb[i][5] = c.hz;
+    sf[i][0] = c.f1; sf[i][1] = c.f2; sf[i][2] = c.f3; sf[i][3] = c.f4;
+    s_id[i] = c.id; s_count[i] = c.count;
+  }
+  __syncthreads();
+  while (m > 1) {
+    s_nn[i] = i < m ? bb_nearest(sb, i, i, m, 0, forced) : -1;
+    __syncthreads();
+    uint32_t state = DEC_GONE; int j = -1;
+    if (i < m) {
+      j = s_nn[i];
+      state = (j >= 0 && s_nn[j] == i) ? (i < j ? DEC_LEAD : DEC_GONE) : DEC_STAY;
+    }
+    Cluster c;
+    uint32_t left = 0, right = 0;
+    if (state != DEC_GONE) {
+      c.lx = sb[i][0]; c.ly = sb[i][1]; c.lz = sb[i][2]; c.hx = sb[i][3]; c.hy = sb[i][4]; c.hz = sb[i][5];
+      c.f1 = sf[i][0]; c.f2 = sf[i][1]; c.f3 = sf[i][2]; c.f4 = sf[i][3];
+      c.id = s_id[i]; c.count = s_count[i];
+    }
+    Cluster B;
+    if (state == DEC_LEAD) {
+      B.lx = sb[j][0]; B.ly = sb[j][1]; B.lz = sb[j][2]; B.hx = sb[j][3]; B.hy = sb[j][4]; B.hz = sb[j][5];
+      B.f1 = sf[j][0]; B.f2 = sf[j][1]; B.f3 = sf[j][2]; B.f4 = sf[j][3];
+      B.id = s_id[j]; B.count = s_count[j];
+    }
+    const unsigned long long keep = __ballot(state != DEC_GONE), lead = __ballot(state == DEC_LEAD);
+    if (lane == 0) { s_w[wv][0] = (uint32_t)__popcll(keep); s_w[wv][1] = (uint32_t)__popcll(lead); }
+    __syncthreads();   // (also: every read of the old arrays is done)
+    uint32_t bk = 0, bl = 0, tk = 0, tl = 0;
+    for (uint32_t k = 0; k < 16u; ++k) { if (k < wv) { bk += s_w[k][0]; bl += s_w[k][1]; } tk += s_w[k][0]; tl += s_w[k][1]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t p = bk + (uint32_t)__popcll(keep & below);
+    if (state == DEC_LEAD) {
+      left = c.id; right = B.id;
+      uint32_t plan;
+      c = bb_merge(c, B, next - 1u - (bl + (uint32_t)__popcll(lead & below)), leaf_max, tri_cost, plan);
+      bb_store_node(rec, c, left, right, plan);
+    }
+    if (state != DEC_GONE) {
+      sb[p][0] = c.lx; sb[p][1] = c.ly; sb[p][2] = c.lz; sb[p][3] = c.hx; sb[p][4] = c.hy; sb[p][5] = c.hz;
+      sf[p][0] = c.f1; sf[p][1] = c.f2; sf[p][2] = c.f3; sf[p][3] = c.f4;
+      s_id[p] = c.id; s_count[p] = c.count;
+    }
+    forced = !forced && tl < (uint32_t)m / 16u;
+    m = (int)tk; next -= tl; ++rounds;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { st[ST_N] = (uint32_t)m; st[ST_NEXT] = next; st[ST_FORCED] = forced ? 1u : 0u; st[ST_ROUNDS] = rounds; }
+}
+
+// ---- 5. collapse + quantise + emit ----
 // smallest e with extent / 255 <= 2^e (bvh.cpp:215-264 picks ceil(log2(extent / 255))), from the float's own exponent: exact
 __device__ __forceinline__ int bb_pick_exp(float extent) {
   if (!(extent > 0.0f) || extent > 3.0e38f) return 0;
@@ -263,29 +487,30 @@ __device__ __forceinline__ bool bb_quant_axis(float origin, int e, float cmin, f
 
 struct CollapseArgs {
   const BNode* rec;
-  uint32_t n, leaf_max, tri_offset, node_capacity;
+  uint32_t n, tri_offset, node_capacity;
   uint32_t* nodes;          // 13 dwords per node
   uint32_t* counters;       // [0] nodes allocated, [1] leaves, [2] largest leaf, [3] deepest level, [4] error flags, [8 + L] items of level L
-  const uint2* in; uint2* out;
+  const uint4* in; uint4* out;   // items: (binary node, output slot, first position of its triangles in the final order, -)
   uint32_t level;
-  const uint32_t* prim_ids;   // TLAS build: sorted position -> instance (blasIdx); nullptr = BLAS build
+  const uint32_t* vals;     // sorted position -> primitive
+  uint32_t* order;          // BLAS build: final position -> primitive (the gather's index); nullptr = TLAS build (a leaf names its instance)
 };
 
-struct BRec { Box3 box; uint32_t left, right, first, last; };
+struct BRec { Box3 box; uint32_t left, right, count, plan; };
 __device__ __forceinline__ BRec bb_load_rec(const BNode* __restrict__ rec, uint32_t id) {
   const float4* p = (const float4*)(rec + id);
-  const float4 a = p[0], b = p[1], c = p[2];
+  const float4 a = p[0], b = p[1], c = p[3];
   BRec r;
   r.box.lx = a.x; r.box.ly = a.y; r.box.lz = a.z; r.left = __float_as_uint(a.w);
   r.box.hx = b.x; r.box.hy = b.y; r.box.hz = b.z; r.right = __float_as_uint(b.w);
-  r.first = __float_as_uint(c.x); r.last = __float_as_uint(c.y);
+  r.count = __float_as_uint(c.x); r.plan = __float_as_uint(c.y);
   return r;
 }
-__device__ __forceinline__ float bb_area(const Box3& b) {
-  const float x = b.hx - b.lx, y = b.hy - b.ly, z = b.hz - b.lz;
-  return x * y + y * z + z * x;
-}
 
+// Top-down, one launch per level: a node takes the child slots the dynamic programme chose (step 4) -- its two binary children
+// share four slots as plan.a4 says; a child offered j > 1 slots either stays one child or hands them on to its own two children
+// (plan.self / plan.a of that child) -- and gives every child its range of the final triangle order (its own range, cut up in slot
+// order).  A subtree marked as a leaf lists its triangles there.
 __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
   const uint32_t n_items = A.counters[8 + A.level];
   const uint32_t lane = threadIdx.x & 63u;
@@ -294,42 +519,39 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
   for (uint32_t base = blockIdx.x * blockDim.x; base < n_items; base += gridDim.x * blockDim.x) {
     const uint32_t it = base + threadIdx.x;
     const bool act = it < n_items;
-    const uint2 item = act ? A.in[it] : make_uint2(A.n - 1, 0u);
-    const uint32_t b = item.x, out = item.y;
+    const uint4 item = act ? A.in[it] : make_uint4(A.n - 1, 0u, 0u, 0u);
+    const uint32_t b = item.x, out = item.y, start = item.z;
     const BRec me = bb_load_rec(A.rec, b);
-    const uint2 rg = make_uint2(me.first, me.last);
-    const uint32_t count = rg.y - rg.x + 1;
+    const uint32_t count = me.count;
     const Box3 bx = me.box;
-    const bool leaf = count <= A.leaf_max;
+    const bool leaf = (me.plan & PLAN_LEAF) != 0u;
     // (all arrays below are indexed with compile-time constants only -- unrolled loops, selects on k == pick -- so that they
     // live in registers: with dynamic indices they went to scratch and a level took as long as ~250 dependent scratch accesses)
-    uint32_t c[4] = {0, 0, 0, 0};
+    uint32_t c[4] = {0, 0, 0, 0}, slots[4] = {0, 0, 0, 0};
     uint32_t nc = 0;
     BRec cr[4];
     cr[0] = cr[1] = cr[2] = cr[3] = me;
     if (act && !leaf) {
       c[0] = me.left; c[1] = me.right;
+      slots[0] = plan_a(me.plan, 4u); slots[1] = 4u - slots[0];
       nc = 2;
       cr[0] = bb_load_rec(A.rec, c[0]); cr[1] = bb_load_rec(A.rec, c[1]);
 #pragma unroll
       for (int round = 0; round < 2; ++round) {
-        int pick = -1; float best = -1.0f;
+        int pick = -1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if ((uint32_t)k < nc && cr[k].last - cr[k].first + 1 > A.leaf_max) {   // (else it becomes a leaf as it is; a single triangle always does)
-            const float ar = bb_area(cr[k].box);
-            if (ar > best) { best = ar; pick = k; }
-          }
-        }
+        for (int k = 3; k >= 0; --k)
+          if ((uint32_t)k < nc && slots[k] > 1u && cr[k].left != 0xffffffffu && !plan_self(cr[k].plan, slots[k])) pick = k;
         if (pick >= 0) {
-          uint32_t gl = 0, gr = 0;
+          uint32_t gl = 0, gr = 0, j = 0, pl = 0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if (k == pick) { gl = cr[k].left; gr = cr[k].right; }
+          for (int k = 0; k < 4; ++k) if (k == pick) { gl = cr[k].left; gr = cr[k].right; j = slots[k]; pl = cr[k].plan; }
+          const uint32_t ja = plan_a(pl, j);
           const BRec L = bb_load_rec(A.rec, gl), R = bb_load_rec(A.rec, gr);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            if (k == pick) { c[k] = gl; cr[k] = L; }
-            if ((uint32_t)k == nc) { c[k] = gr; cr[k] = R; }
+            if (k == pick) { c[k] = gl; cr[k] = L; slots[k] = ja; }
+            if ((uint32_t)k == nc) { c[k] = gr; cr[k] = R; slots[k] = j - ja; }
           }
           ++nc;
         }
@@ -370,8 +592,22 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
     int e[3] = {bb_pick_exp(bx.hx - bx.lx), bb_pick_exp(bx.hy - bx.ly), bb_pick_exp(bx.hz - bx.lz)};
     uint32_t ql[4][3] = {}, qh[4][3] = {};
     if (leaf) {
-      if (A.prim_ids) { w[4] = 0; w[5] = A.prim_ids[rg.x]; }   // TLAS leaf (bvh.cpp:325-328): leafData = blasIdx
-      else { w[4] = rg.x + A.tri_offset; w[5] = count; }       // bvh.cpp:260: already offset by the mesh's first triangle
+      // the subtree's triangles, left to right: the t-th one is found by walking down with the counts (a leaf holds <= 15)
+      uint32_t first_prim = 0;
+      for (uint32_t t = 0; t < count; ++t) {
+        uint32_t x = b, r = t;
+        for (;;) {
+          const uint4 lr = make_uint4(A.rec[x].left, A.rec[x].right, 0u, 0u);
+          if (lr.x == 0xffffffffu) break;
+          const uint32_t cl = A.rec[lr.x].count;
+          if (r < cl) x = lr.x; else { r -= cl; x = lr.y; }
+        }
+        const uint32_t prim = A.vals[x - (A.n - 1u)];
+        if (t == 0) first_prim = prim;
+        if (A.order) A.order[start + t] = prim;
+      }
+      if (!A.order) { w[4] = 0; w[5] = first_prim; }              // TLAS leaf (bvh.cpp:325-328): leafData = blasIdx
+      else { w[4] = start + A.tri_offset; w[5] = count; }         // bvh.cpp:260: already offset by the mesh's first triangle
     } else {
       if (first + nc > A.node_capacity) { atomicOr(A.counters + 4, 1u); continue; }
       const float org[3] = {bx.lx, bx.ly, bx.lz};
@@ -393,11 +629,12 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
         }
       }
       w[4] = first;     // relative to this BLAS's first node (rt_traversal.cpp:92,119); TLAS: to its node 0
-      w[5] = A.prim_ids ? 0xffffffffu : 0u;   // internal TLAS nodes carry UINT32_MAX (bvh.cpp:417)
+      w[5] = A.order ? 0u : 0xffffffffu;   // internal TLAS nodes carry UINT32_MAX (bvh.cpp:417)
+      uint32_t cstart = start;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if ((uint32_t)k < nc) A.out[pos + k] = make_uint2(c[k], first + k);
+      for (int k = 0; k < 4; ++k) if ((uint32_t)k < nc) { A.out[pos + k] = make_uint4(c[k], first + k, cstart, 0u); cstart += cr[k].count; }
     }
-    w[3] = (uint32_t)(uint8_t)(int8_t)e[0] | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16) | (A.prim_ids ? 1u << 24 : 0u);   // imask: 1 = TLAS node
+    w[3] = (uint32_t)(uint8_t)(int8_t)e[0] | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16) | (A.order ? 0u : 1u << 24);   // imask: 1 = TLAS node
     // children: 4 x { meta, lo x y z, hi x y z } = 28 bytes from dword 6 on
     uint64_t cbits[4];
 #pragma unroll
@@ -417,7 +654,7 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
   }
 }
 
-// ---- 7. gather into the sorted order ----
+// ---- 6. gather into the final order ----
 __global__ __launch_bounds__(256) void bb_gather_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ vals, uint32_t n, uint32_t dwords,
                                                           uint32_t* __restrict__ dst) {
   const uint64_t total = (uint64_t)n * dwords;
@@ -431,6 +668,7 @@ __global__ __launch_bounds__(256) void bb_gather_kernel(const uint32_t* __restri
 // hipMalloc / hipFree pairs per build); vxrt_bvh_release_scratch() returns it.
 struct Arena {
   void* base = nullptr; size_t cap = 0; size_t used = 0; int dev = -1;
+  uint32_t* pinned = nullptr;   // 128 host words for the read-backs (cluster count between chunks of rounds, counters at the end)
   template <class T> T* get(size_t count) {
     const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
     if (used + bytes > cap) return nullptr;
@@ -445,9 +683,10 @@ Arena g_arena;
 bool arena_reserve(size_t bytes) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (g_arena.base && (g_arena.dev != dev || g_arena.cap < bytes)) { (void)hipFree(g_arena.base); g_arena = Arena(); }
+  if (g_arena.base && (g_arena.dev != dev || g_arena.cap < bytes)) { (void)hipFree(g_arena.base); g_arena.base = nullptr; g_arena.cap = 0; }
+  if (!g_arena.pinned && hipHostMalloc((void**)&g_arena.pinned, 128 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { g_arena.pinned = nullptr; return false; }
   if (!g_arena.base) {
-    if (hipMalloc(&g_arena.base, bytes) != hipSuccess) { g_arena = Arena(); return false; }
+    if (hipMalloc(&g_arena.base, bytes) != hipSuccess) { g_arena.base = nullptr; g_arena.cap = 0; return false; }
     g_arena.cap = bytes; g_arena.dev = dev;
   }
   g_arena.used = 0;
@@ -458,7 +697,7 @@ bool arena_reserve(size_t bytes) {
 
 static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tri_offset, uint32_t leaf_max,
                         void* d_nodes, uint32_t node_capacity, vxrt_bvh_info_t* info, void* stream, bool boxes) {
-  if (!d_tri || !d_nodes || n_tris == 0 || n_tris > 0x0fffffffu) return -1;   // (the radix-tree search probes positions up to 3 n in 32-bit arithmetic)
+  if (!d_tri || !d_nodes || n_tris == 0 || n_tris > 0x0fffffffu) return -1;
   if (leaf_max == 0) leaf_max = 2;
   if (leaf_max > 15) leaf_max = 15;
   if (boxes) { leaf_max = 1; d_triEx = nullptr; }
@@ -469,65 +708,102 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   const uint32_t n_counters = 8 + BB_MAX_LEVELS + 2;
   size_t tmp_bytes = 0;
   if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
-  const size_t per_tri = 2 * 8 + 2 * 4 + 2 * 48 + 2 * 4 + 4 + 2 * 8 + (d_triEx ? 64 : 36);
-  if (!arena_reserve((size_t)n * per_tri + tmp_bytes + 64 * 1024)) return -1;
+  const uint32_t blocks = (n + 255u) / 256u;
+  const size_t per_tri = 2 * 8 + 2 * 4 + 2 * sizeof(BNode) + 2 * sizeof(Cluster) + 1 + 2 * 16 + 4 + (d_triEx ? 64 : 36);
+  if (!arena_reserve((size_t)n * per_tri + (size_t)blocks * 16 + tmp_bytes + 64 * 1024)) return -1;
   Arena& sc = g_arena;
   int* cb = sc.get<int>(8);
   uint32_t* counters = sc.get<uint32_t>(n_counters);
+  uint32_t* st = sc.get<uint32_t>(ST_WORDS);
   uint64_t* keys0 = sc.get<uint64_t>(n);
   uint64_t* keys1 = sc.get<uint64_t>(n);
   uint32_t* vals0 = sc.get<uint32_t>(n);
   uint32_t* vals1 = sc.get<uint32_t>(n);
   BNode* rec = sc.get<BNode>(2 * (size_t)n);
-  uint32_t* parent = sc.get<uint32_t>(2 * (size_t)n);
-  uint32_t* flag = sc.get<uint32_t>(n);
-  uint2* q0 = sc.get<uint2>(n);
-  uint2* q1 = sc.get<uint2>(n);
+  Cluster* cl0 = sc.get<Cluster>(n);
+  Cluster* cl1 = sc.get<Cluster>(n);
+  uint8_t* dec = sc.get<uint8_t>(n);
+  uint2* tile_counts = sc.get<uint2>(blocks);
+  uint2* tile_base = sc.get<uint2>(blocks);
+  uint4* q0 = sc.get<uint4>(n);
+  uint4* q1 = sc.get<uint4>(n);
+  uint32_t* order = sc.get<uint32_t>(n);
   uint32_t* gather = sc.get<uint32_t>((size_t)n * (d_triEx ? 16 : 9));
   void* tmp = sc.get<uint8_t>(tmp_bytes ? tmp_bytes : 16);
-  if (!cb || !counters || !keys0 || !keys1 || !vals0 || !vals1 || !rec || !parent || !flag || !q0 || !q1 || !gather || !tmp) return -1;
-  const uint32_t blocks = (n + 255u) / 256u;
+  if (!cb || !counters || !st || !keys0 || !keys1 || !vals0 || !vals1 || !rec || !cl0 || !cl1 || !dec || !tile_counts || !tile_base || !q0 || !q1 ||
+      !order || !gather || !tmp || !sc.pinned) return -1;
   const uint32_t wide = blocks < 4096u ? blocks : 4096u;
+  const float tri_cost = boxes ? 0.0f : BB_TRI_COST;
 
   hipLaunchKernelGGL(bb_init_kernel, dim3(1), dim3(256), 0, s, cb, counters, n_counters, q0);
-  if (hipMemsetAsync(flag, 0, (size_t)n * 4, s) != hipSuccess) return -1;
   hipLaunchKernelGGL(bb_bounds_kernel, dim3(wide < 512u ? wide : 512u), dim3(256), 0, s, (const float*)d_tri, n, cb, boxes);
   hipLaunchKernelGGL(bb_morton_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, n, cb, keys0, vals0, boxes);
   if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
-  if (n > 1) hipLaunchKernelGGL(bb_tree_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, s, keys1, (int)n, rec, parent);
-  hipLaunchKernelGGL(bb_fit_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, vals1, n, parent, rec, flag, boxes);
 
-  CollapseArgs A;
-  A.rec = rec; A.n = n; A.leaf_max = leaf_max; A.tri_offset = tri_offset; A.node_capacity = node_capacity;
-  A.nodes = (uint32_t*)d_nodes; A.counters = counters; A.prim_ids = boxes ? vals1 : nullptr;
-  for (uint32_t L = 0; L < (uint32_t)BB_MAX_LEVELS; ++L) {
-    A.in = (L & 1u) ? q1 : q0; A.out = (L & 1u) ? q0 : q1; A.level = L;
-    // (level L holds at most 4^L items)
-    uint32_t g = wide;
-    if (L < 8) { const uint32_t items = 1u << (2 * L); g = (items + 255u) / 256u < wide ? (items + 255u) / 256u : wide; }
-    hipLaunchKernelGGL(bb_collapse_kernel, dim3(g), dim3(256), 0, s, A);
+  // clustering: rounds of (decide, scan, apply) over the whole array while it is long, eight at a time between looks at the
+  // cluster count (the count only falls, so the last one read bounds the grid); the single-workgroup tail takes the rest
+  hipLaunchKernelGGL(bb_leaves_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, vals1, n, boxes, tri_cost, cl0, rec, st);
+  Cluster* cur = cl0; Cluster* nxt = cl1;
+  uint32_t m_upper = n;
+  for (int chunk = 0; m_upper > (uint32_t)BB_TAIL; ++chunk) {
+    if (chunk == 64) return -1;   // (512 rounds: every second round at least halves the array or merges a sixteenth of it)
+    const uint32_t tiles = (m_upper + BB_TILE - 1) / BB_TILE, g = tiles < 2048u ? tiles : 2048u;
+    for (int r = 0; r < 8; ++r) {
+      hipLaunchKernelGGL(bb_ploc_decide_kernel, dim3(g), dim3(256), 0, s, (const Cluster*)cur, (const uint32_t*)st, dec, tile_counts);
+      hipLaunchKernelGGL(bb_ploc_scan_kernel, dim3(1), dim3(1024), 0, s, (const uint2*)tile_counts, tile_base, st);
+      hipLaunchKernelGGL(bb_ploc_apply_kernel, dim3(g), dim3(256), 0, s, (const Cluster*)cur, nxt, (const uint8_t*)dec, (const uint2*)tile_base,
+                         (const uint32_t*)st, rec, leaf_max, tri_cost);
+      Cluster* t = cur; cur = nxt; nxt = t;
+    }
+    if (hipMemcpyAsync(sc.pinned, st, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (sc.pinned[0] > m_upper || sc.pinned[0] == 0u) return -1;
+    m_upper = sc.pinned[0];
   }
-  // triangles (and shading records) into the sorted order, in place through a scratch copy (bvh.cpp:126-128 reorders in place);
+  hipLaunchKernelGGL(bb_ploc_tail_kernel, dim3(1), dim3(1024), 0, s, (const Cluster*)cur, st, rec, leaf_max, tri_cost);
+
+  // collapse, level by level; sixteen levels, then as many more as the item counts ask for
+  CollapseArgs A;
+  A.rec = rec; A.n = n; A.tri_offset = tri_offset; A.node_capacity = node_capacity;
+  A.nodes = (uint32_t*)d_nodes; A.counters = counters; A.vals = vals1; A.order = boxes ? nullptr : order;
+  const uint32_t cwide = blocks < 1024u ? blocks : 1024u;
+  uint32_t L = 0;
+  for (;;) {
+    const uint32_t stop = L + 16u < (uint32_t)BB_MAX_LEVELS ? L + 16u : (uint32_t)BB_MAX_LEVELS;
+    for (; L < stop; ++L) {
+      A.in = (L & 1u) ? q1 : q0; A.out = (L & 1u) ? q0 : q1; A.level = L;
+      // (level L holds at most 4^L items)
+      uint32_t g = cwide;
+      if (L < 8) { const uint32_t items = 1u << (2 * L); g = (items + 255u) / 256u < cwide ? (items + 255u) / 256u : cwide; }
+      hipLaunchKernelGGL(bb_collapse_kernel, dim3(g), dim3(256), 0, s, A);
+    }
+    if (L >= (uint32_t)BB_MAX_LEVELS) break;
+    if (hipMemcpyAsync(sc.pinned, counters + 8 + L, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (sc.pinned[0] == 0u) break;
+  }
+  // triangles (and shading records) into the final order, in place through a scratch copy (bvh.cpp:126-128 reorders in place);
   // instances stay where they are (a TLAS leaf names its instance)
   if (!boxes) {
-    hipLaunchKernelGGL(bb_gather_kernel, dim3(wide), dim3(256), 0, s, (const uint32_t*)d_tri, vals1, n, 9u, gather);
+    hipLaunchKernelGGL(bb_gather_kernel, dim3(wide), dim3(256), 0, s, (const uint32_t*)d_tri, (const uint32_t*)order, n, 9u, gather);
     if (hipMemcpyAsync(d_tri, gather, (size_t)n * 36, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
   }
   if (d_triEx) {
-    hipLaunchKernelGGL(bb_gather_kernel, dim3(wide), dim3(256), 0, s, (const uint32_t*)d_triEx, vals1, n, 16u, gather);
+    hipLaunchKernelGGL(bb_gather_kernel, dim3(wide), dim3(256), 0, s, (const uint32_t*)d_triEx, (const uint32_t*)order, n, 16u, gather);
     if (hipMemcpyAsync(d_triEx, gather, (size_t)n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
   }
-  std::vector<uint32_t> hc(n_counters);
-  BNode hroot;
-  if (hipMemcpyAsync(hc.data(), counters, n_counters * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-  if (hipMemcpyAsync(&hroot, rec, sizeof hroot, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;   // record 0: the root (or the only leaf)
+  uint32_t* hc = sc.pinned;   // counters, then the clustering state, then the root's record
+  if (hipMemcpyAsync(hc, counters, n_counters * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipMemcpyAsync(hc + 64, st, ST_WORDS * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipMemcpyAsync(hc + 80, rec, sizeof(BNode), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;   // record 0: the root (or the only leaf)
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   if (hipGetLastError() != hipSuccess) return -1;
+  BNode hroot;
+  memcpy(&hroot, hc + 80, sizeof hroot);
   if (info) {
     info->n_nodes = hc[0]; info->n_leaves = hc[1]; info->max_leaf = hc[2]; info->max_depth = hc[3];
     info->bounds[0] = hroot.lx; info->bounds[1] = hroot.ly; info->bounds[2] = hroot.lz;
     info->bounds[3] = hroot.hx; info->bounds[4] = hroot.hy; info->bounds[5] = hroot.hz;
   }
+  if (hc[64 + ST_N] != 1u || hc[64 + ST_NEXT] != 0u) return -1;   // the clustering did not end in one root with every id used
   if (hc[4] != 0u) return -1;                                  // capacity or exponent range exhausted
   if (hc[8 + BB_MAX_LEVELS] != 0u) return -2;                  // deeper than the collapse pass goes
   if (hc[3] >= (uint32_t)RT_MAX_LEVELS) return -2;             // deeper than the reference's trail (rt_traversal.h:8): use the SAH builder
@@ -549,5 +825,6 @@ extern "C" int vxrt_tlas_build(const float* d_instance_boxes, uint32_t n_instanc
 extern "C" void vxrt_bvh_release_scratch(void) {
   std::lock_guard<std::mutex> lk(g_arena_mu);
   if (g_arena.base) (void)hipFree(g_arena.base);
+  if (g_arena.pinned) (void)hipHostFree(g_arena.pinned);
   g_arena = Arena();
 }
