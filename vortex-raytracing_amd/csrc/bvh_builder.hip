@@ -109,7 +109,20 @@ __device__ __forceinline__ uint64_t spread21(uint32_t v) {
   return x;
 }
 
-__global__ __launch_bounds__(256) void bb_morton_kernel(const float* __restrict__ tri, uint32_t n, const int* __restrict__ cb,
+// axis and bit of every key position (one thread: 63 steps over three numbers)
+__global__ void bb_axis_sequence_kernel(const int* __restrict__ cb, uint32_t* __restrict__ seq) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float e3[3] = {ord2f(cb[3]) - ord2f(cb[0]), ord2f(cb[4]) - ord2f(cb[1]), ord2f(cb[5]) - ord2f(cb[2])};
+  int used[3] = {0, 0, 0};
+  for (int b = 0; b < 63; ++b) {
+    int a = -1; float best = -1.0f;
+    for (int k = 0; k < 3; ++k) if (used[k] < 21 && (a < 0 || e3[k] > best)) { best = e3[k]; a = k; }   // (a NaN extent: the first axis with bits left)
+    seq[b] = (uint32_t)a | ((uint32_t)(20 - used[a]) << 2);
+    used[a]++; e3[a] *= 0.5f;
+  }
+}
+
+__global__ __launch_bounds__(256) void bb_morton_kernel(const float* __restrict__ tri, uint32_t n, const int* __restrict__ cb, const uint32_t* __restrict__ seq,
                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, bool boxes) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -128,19 +141,14 @@ __global__ __launch_bounds__(256) void bb_morton_kernel(const float* __restrict_
 #if BB_EXTENDED_MORTON
   // extended Morton order (Vinkler et al. 2017): the next bit always comes from the axis whose cell is still the longest, so an
   // elongated scene is not cut across its short axes as often as along its long one (plain interleaving gives every axis 21 bits
-  // whatever its extent).  The axis sequence depends on the bounds only: the same for every thread.
-  float e3[3] = {ord2f(cb[3]) - ord2f(cb[0]), ord2f(cb[4]) - ord2f(cb[1]), ord2f(cb[5]) - ord2f(cb[2])};
-  int used[3] = {0, 0, 0};
+  // whatever its extent).  The axis sequence depends on the bounds only: bb_axis_sequence_kernel computed it once
+  // (seq[b] = axis | shift << 2 for key bit b, most significant first; 63 scalar loads here).
   uint64_t key = 0;
+#pragma unroll 9
   for (int b = 0; b < 63; ++b) {
-    int a = -1; float best = -1.0f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) if (used[k] < 21 && e3[k] > best) { best = e3[k]; a = k; }
+    const uint32_t sq = seq[b], a = sq & 3u, sh = sq >> 2;
     const uint32_t qa = a == 0 ? q[0] : (a == 1 ? q[1] : q[2]);
-    const int ua = a == 0 ? used[0] : (a == 1 ? used[1] : used[2]);
-    key = (key << 1) | ((qa >> (20 - ua)) & 1u);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) if (k == a) { used[k]++; e3[k] *= 0.5f; }
+    key = (key << 1) | ((qa >> sh) & 1u);
   }
   keys[i] = key;
 #else
@@ -468,29 +476,29 @@ __device__ __forceinline__ int bb_pick_exp(float extent) {
   return max(-126, min(126, e));
 }
 
-// q_lo, q_hi of one axis of one child at exponent e; false if the child does not fit 8 bits there
-__device__ __forceinline__ bool bb_quant_axis(float origin, int e, float cmin, float cmax, uint32_t& qlo, uint32_t& qhi) {
-  const float s = ldexpf(1.0f, e);
-  float fl = floorf((cmin - origin) / s), fh = ceilf((cmax - origin) / s);
+// q_lo, q_hi of one axis of one child at scale s = 2^e (inv = 2^-e, both exact: |e| <= 126); false if the child does not fit 8 bits there
+__device__ __forceinline__ bool bb_quant_axis(float origin, float s, float inv, float cmin, float cmax, uint32_t& qlo, uint32_t& qhi) {
+  float fl = floorf((cmin - origin) * inv), fh = ceilf((cmax - origin) * inv);
   if (!(fl >= 0.0f)) fl = 0.0f;
   if (!(fh >= fl)) fh = fl;
   if (fh > 255.0f) return false;
   int lo = (int)fl, hi = (int)fh;
   if (lo > 255) return false;
-  // conservative after the decode's own rounding (origin + q * 2^e rounds once)
-  while (lo > 0 && origin + ldexpf((float)lo, e) > cmin) --lo;
-  while (hi < 255 && origin + ldexpf((float)hi, e) < cmax) ++hi;
-  if (origin + ldexpf((float)hi, e) < cmax) return false;
+  // conservative after the decode's own rounding (origin + q * 2^e rounds once; q * 2^e itself is exact)
+  while (lo > 0 && origin + (float)lo * s > cmin) --lo;
+  while (hi < 255 && origin + (float)hi * s < cmax) ++hi;
+  if (origin + (float)hi * s < cmax) return false;
   qlo = (uint32_t)lo; qhi = (uint32_t)hi;
   return true;
 }
+__device__ __forceinline__ float bb_pow2(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }   // e in [-126, 127]
 
 struct CollapseArgs {
   const BNode* rec;
   uint32_t n, tri_offset, node_capacity;
   uint32_t* nodes;          // 13 dwords per node
   uint32_t* counters;       // [0] nodes allocated, [1] leaves, [2] largest leaf, [3] deepest level, [4] error flags, [8 + L] items of level L
-  const uint4* in; uint4* out;   // items: (binary node, output slot, first position of its triangles in the final order, -)
+  const uint4* in; uint4* out;   // items, one per internal node of the level: (binary node, output slot, first position of its triangles in the final order, -)
   uint32_t level;
   const uint32_t* vals;     // sorted position -> primitive
   uint32_t* order;          // BLAS build: final position -> primitive (the gather's index); nullptr = TLAS build (a leaf names its instance)
@@ -507,10 +515,47 @@ __device__ __forceinline__ BRec bb_load_rec(const BNode* __restrict__ rec, uint3
   return r;
 }
 
-// Top-down, one launch per level: a node takes the child slots the dynamic programme chose (step 4) -- its two binary children
-// share four slots as plan.a4 says; a child offered j > 1 slots either stays one child or hands them on to its own two children
-// (plan.self / plan.a of that child) -- and gives every child its range of the final triangle order (its own range, cut up in slot
-// order).  A subtree marked as a leaf lists its triangles there.
+// a leaf record in slot `out`: the subtree of binary node b (<= 15 triangles), its triangles listed from `start` of the final order
+__device__ __forceinline__ void bb_emit_leaf(const CollapseArgs& A, uint32_t b, const BRec& r, uint32_t out, uint32_t start) {
+  // (binary leaf j has id n-1+j: a child id says whether it is one, no load needed)
+  uint32_t first_prim = 0;
+  const uint32_t nl = A.n - 1u;
+  if (r.left == 0xffffffffu) {
+    first_prim = A.vals[b - nl];
+    if (A.order) A.order[start] = first_prim;
+  } else if (r.count == 2u) {   // (the usual leaf: two triangles, both children are binary leaves)
+    first_prim = A.vals[r.left - nl];
+    if (A.order) { A.order[start] = first_prim; A.order[start + 1u] = A.vals[r.right - nl]; }
+  } else {
+    // left to right: the t-th triangle is found by walking down with the counts
+    for (uint32_t t = 0; t < r.count; ++t) {
+      uint32_t x = b, rem = t;
+      while (x < nl) {
+        const uint32_t l = A.rec[x].left;
+        const uint32_t cl = l >= nl ? 1u : A.rec[l].count;
+        if (rem < cl) x = l; else { rem -= cl; x = A.rec[x].right; }
+      }
+      const uint32_t prim = A.vals[x - nl];
+      if (t == 0) first_prim = prim;
+      if (A.order) A.order[start + t] = prim;
+    }
+  }
+  uint32_t* o = A.nodes + (size_t)out * RT_NODE_DWORDS;
+  o[0] = __float_as_uint(r.box.lx); o[1] = __float_as_uint(r.box.ly); o[2] = __float_as_uint(r.box.lz);
+  const int e0 = bb_pick_exp(r.box.hx - r.box.lx), e1 = bb_pick_exp(r.box.hy - r.box.ly), e2 = bb_pick_exp(r.box.hz - r.box.lz);
+  o[3] = (uint32_t)(uint8_t)(int8_t)e0 | ((uint32_t)(uint8_t)(int8_t)e1 << 8) | ((uint32_t)(uint8_t)(int8_t)e2 << 16) | (A.order ? 0u : 1u << 24);   // imask: 1 = TLAS node
+  if (!A.order) { o[4] = 0; o[5] = first_prim; }                 // TLAS leaf (bvh.cpp:325-328): leafData = blasIdx
+  else { o[4] = start + A.tri_offset; o[5] = r.count; }          // bvh.cpp:260: already offset by the mesh's first triangle
+#pragma unroll
+  for (int k = 6; k < RT_NODE_DWORDS; ++k) o[k] = 0u;
+}
+
+// Top-down, one launch per level, one item per INTERNAL node of the 4-wide tree: the node takes the child slots the dynamic
+// programme chose (step 4) -- its two binary children share four slots as plan.a4 says; a child offered j > 1 slots either stays
+// one child or hands them on to its own two children (plan.self / plan.a of that child) -- gives every child its range of the final
+// triangle order (its own range, cut up in slot order), writes its own record and the records of the children that are leaves
+// (two thirds of all nodes: as items of their own they would idle through the internal nodes' work in the same wavefront), and
+// queues the others for the next level.
 __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
   const uint32_t n_items = A.counters[8 + A.level];
   const uint32_t lane = threadIdx.x & 63u;
@@ -518,47 +563,71 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
   // each, from a prefix sum over its lanes -- per item they would be 600,000 atomics on one address per level)
   for (uint32_t base = blockIdx.x * blockDim.x; base < n_items; base += gridDim.x * blockDim.x) {
     const uint32_t it = base + threadIdx.x;
-    const bool act = it < n_items;
+    bool act = it < n_items;
     const uint4 item = act ? A.in[it] : make_uint4(A.n - 1, 0u, 0u, 0u);
     const uint32_t b = item.x, out = item.y, start = item.z;
     const BRec me = bb_load_rec(A.rec, b);
-    const uint32_t count = me.count;
     const Box3 bx = me.box;
-    const bool leaf = (me.plan & PLAN_LEAF) != 0u;
+    if (act && (me.plan & PLAN_LEAF) != 0u) {   // only the root can arrive here as a leaf (a mesh of a few triangles)
+      bb_emit_leaf(A, b, me, out, start);
+      atomicAdd(A.counters + 1, 1u); atomicMax(A.counters + 2, me.count);
+      act = false;
+    }
     // (all arrays below are indexed with compile-time constants only -- unrolled loops, selects on k == pick -- so that they
     // live in registers: with dynamic indices they went to scratch and a level took as long as ~250 dependent scratch accesses)
     uint32_t c[4] = {0, 0, 0, 0}, slots[4] = {0, 0, 0, 0};
     uint32_t nc = 0;
     BRec cr[4];
     cr[0] = cr[1] = cr[2] = cr[3] = me;
-    if (act && !leaf) {
+    if (act) {
       c[0] = me.left; c[1] = me.right;
       slots[0] = plan_a(me.plan, 4u); slots[1] = 4u - slots[0];
       nc = 2;
       cr[0] = bb_load_rec(A.rec, c[0]); cr[1] = bb_load_rec(A.rec, c[1]);
+      // the two children's own splits are known now: their four children are fetched together (one latency, not two)
+      const bool sp0 = slots[0] > 1u && cr[0].left != 0xffffffffu && !plan_self(cr[0].plan, slots[0]);
+      const bool sp1 = slots[1] > 1u && cr[1].left != 0xffffffffu && !plan_self(cr[1].plan, slots[1]);
+      BRec g0l = me, g0r = me, g1l = me, g1r = me;
+      if (sp0) { g0l = bb_load_rec(A.rec, cr[0].left); g0r = bb_load_rec(A.rec, cr[0].right); }
+      if (sp1) { g1l = bb_load_rec(A.rec, cr[1].left); g1r = bb_load_rec(A.rec, cr[1].right); }
+      if (sp0) {
+        const uint32_t j = slots[0], ja = plan_a(cr[0].plan, j), gl = cr[0].left, gr = cr[0].right;
+        c[0] = gl; cr[0] = g0l; slots[0] = ja;
+        c[2] = gr; cr[2] = g0r; slots[2] = j - ja;
+        nc = 3;
+      }
+      if (sp1) {
+        const uint32_t j = slots[1], ja = plan_a(cr[1].plan, j), gl = cr[1].left, gr = cr[1].right;
+        c[1] = gl; cr[1] = g1l; slots[1] = ja;
 #pragma unroll
-      for (int round = 0; round < 2; ++round) {
+        for (int k = 2; k < 4; ++k) if ((uint32_t)k == nc) { c[k] = gr; cr[k] = g1r; slots[k] = j - ja; }
+        ++nc;
+      }
+      // at most one more split: a grandchild that was handed two of three slots
+      if (nc == 3u) {
         int pick = -1;
 #pragma unroll
-        for (int k = 3; k >= 0; --k)
-          if ((uint32_t)k < nc && slots[k] > 1u && cr[k].left != 0xffffffffu && !plan_self(cr[k].plan, slots[k])) pick = k;
+        for (int k = 2; k >= 0; --k)
+          if (slots[k] > 1u && cr[k].left != 0xffffffffu && !plan_self(cr[k].plan, slots[k])) pick = k;
         if (pick >= 0) {
           uint32_t gl = 0, gr = 0, j = 0, pl = 0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if (k == pick) { gl = cr[k].left; gr = cr[k].right; j = slots[k]; pl = cr[k].plan; }
+          for (int k = 0; k < 3; ++k) if (k == pick) { gl = cr[k].left; gr = cr[k].right; j = slots[k]; pl = cr[k].plan; }
           const uint32_t ja = plan_a(pl, j);
           const BRec L = bb_load_rec(A.rec, gl), R = bb_load_rec(A.rec, gr);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (k == pick) { c[k] = gl; cr[k] = L; slots[k] = ja; }
-            if ((uint32_t)k == nc) { c[k] = gr; cr[k] = R; slots[k] = j - ja; }
-          }
-          ++nc;
+          for (int k = 0; k < 3; ++k) if (k == pick) { c[k] = gl; cr[k] = L; slots[k] = ja; }
+          c[3] = gr; cr[3] = R; slots[3] = j - ja;
+          nc = 4;
         }
       }
     }
-    // wavefront prefix sum of the child counts -> node slots and next-level queue positions
-    uint32_t incl = nc;
+    uint32_t ni = 0, nl = 0, lmax = 0;   // children that go on: internal ones; leaves among them and their largest
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((uint32_t)k < nc) { if (cr[k].plan & PLAN_LEAF) { ++nl; lmax = max(lmax, cr[k].count); } else ++ni; }
+    // wavefront prefix sums: node slots over all children, next-level queue positions over the internal ones
+    uint32_t incl = nc | (ni << 16);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += t; }
     const uint32_t total = __shfl(incl, 63);
@@ -569,77 +638,56 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
     __syncthreads();
     if (threadIdx.x == 0) {
       const uint32_t bt = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-      s_base[0] = bt ? atomicAdd(A.counters + 0, bt) : 0u;
-      s_base[1] = bt ? atomicAdd(A.counters + 8 + A.level + 1, bt) : 0u;
+      s_base[0] = (bt & 0xffffu) ? atomicAdd(A.counters + 0, bt & 0xffffu) : 0u;
+      s_base[1] = (bt >> 16) ? atomicAdd(A.counters + 8 + A.level + 1, bt >> 16) : 0u;
     }
     __syncthreads();
     uint32_t woff = 0;
     for (uint32_t k = 0; k < wv; ++k) woff += s_tot[k];
-    const uint32_t first = s_base[0] + woff + incl - nc, pos = s_base[1] + woff + incl - nc;
+    const uint32_t excl = woff + incl - (nc | (ni << 16));
+    const uint32_t first = s_base[0] + (excl & 0xffffu), pos = s_base[1] + (excl >> 16);
     __syncthreads();   // (s_tot / s_base are rewritten by the next iteration)
-    const unsigned long long leafm = __ballot(act && leaf);
-    uint32_t lmax = act && leaf ? count : 0u;
+    uint32_t nls = nl, lm = lmax;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lmax = max(lmax, (uint32_t)__shfl_down(lmax, off));
-    if (lane == 0 && leafm != 0ull) {
-      atomicAdd(A.counters + 1, (uint32_t)__popcll(leafm));
-      atomicMax(A.counters + 2, lmax);
-      atomicMax(A.counters + 3, A.level);
+    for (int off = 32; off > 0; off >>= 1) { nls += __shfl_down(nls, off); lm = max(lm, (uint32_t)__shfl_down(lm, off)); }
+    if (lane == 0 && nls != 0u) {
+      atomicAdd(A.counters + 1, nls);
+      atomicMax(A.counters + 2, lm);
+      atomicMax(A.counters + 3, A.level + 1u);
     }
     if (!act) continue;
+    if (first + nc > A.node_capacity) { atomicOr(A.counters + 4, 1u); continue; }
     uint32_t w[13];
     w[0] = __float_as_uint(bx.lx); w[1] = __float_as_uint(bx.ly); w[2] = __float_as_uint(bx.lz);
     int e[3] = {bb_pick_exp(bx.hx - bx.lx), bb_pick_exp(bx.hy - bx.ly), bb_pick_exp(bx.hz - bx.lz)};
     uint32_t ql[4][3] = {}, qh[4][3] = {};
-    if (leaf) {
-      // the subtree's triangles, left to right: the t-th one is found by walking down with the counts (a leaf holds <= 15)
-      uint32_t first_prim = 0;
-      for (uint32_t t = 0; t < count; ++t) {
-        uint32_t x = b, r = t;
-        for (;;) {
-          const uint4 lr = make_uint4(A.rec[x].left, A.rec[x].right, 0u, 0u);
-          if (lr.x == 0xffffffffu) break;
-          const uint32_t cl = A.rec[lr.x].count;
-          if (r < cl) x = lr.x; else { r -= cl; x = lr.y; }
-        }
-        const uint32_t prim = A.vals[x - (A.n - 1u)];
-        if (t == 0) first_prim = prim;
-        if (A.order) A.order[start + t] = prim;
-      }
-      if (!A.order) { w[4] = 0; w[5] = first_prim; }              // TLAS leaf (bvh.cpp:325-328): leafData = blasIdx
-      else { w[4] = start + A.tri_offset; w[5] = count; }         // bvh.cpp:260: already offset by the mesh's first triangle
-    } else {
-      if (first + nc > A.node_capacity) { atomicOr(A.counters + 4, 1u); continue; }
-      const float org[3] = {bx.lx, bx.ly, bx.lz};
+    const float org[3] = {bx.lx, bx.ly, bx.lz};
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        for (;;) {
-          bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+      for (;;) {
+        bool ok = true;
+        const float sc = bb_pow2(e[a]), inv = bb_pow2(-e[a]);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if ((uint32_t)k < nc && ok) {
-              const float cmin = a == 0 ? cr[k].box.lx : (a == 1 ? cr[k].box.ly : cr[k].box.lz);
-              const float cmax = a == 0 ? cr[k].box.hx : (a == 1 ? cr[k].box.hy : cr[k].box.hz);
-              ok = bb_quant_axis(org[a], e[a], cmin, cmax, ql[k][a], qh[k][a]);
-            }
+        for (int k = 0; k < 4; ++k) {
+          if ((uint32_t)k < nc && ok) {
+            const float cmin = a == 0 ? cr[k].box.lx : (a == 1 ? cr[k].box.ly : cr[k].box.lz);
+            const float cmax = a == 0 ? cr[k].box.hx : (a == 1 ? cr[k].box.hy : cr[k].box.hz);
+            ok = bb_quant_axis(org[a], sc, inv, cmin, cmax, ql[k][a], qh[k][a]);
           }
-          if (ok) break;
-          if (e[a] >= 126) { atomicOr(A.counters + 4, 2u); break; }
-          ++e[a];
         }
+        if (ok) break;
+        if (e[a] >= 126) { atomicOr(A.counters + 4, 2u); break; }
+        ++e[a];
       }
-      w[4] = first;     // relative to this BLAS's first node (rt_traversal.cpp:92,119); TLAS: to its node 0
-      w[5] = A.order ? 0u : 0xffffffffu;   // internal TLAS nodes carry UINT32_MAX (bvh.cpp:417)
-      uint32_t cstart = start;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) if ((uint32_t)k < nc) { A.out[pos + k] = make_uint4(c[k], first + k, cstart, 0u); cstart += cr[k].count; }
     }
+    w[4] = first;     // relative to this BLAS's first node (rt_traversal.cpp:92,119); TLAS: to its node 0
+    w[5] = A.order ? 0u : 0xffffffffu;   // internal TLAS nodes carry UINT32_MAX (bvh.cpp:417)
     w[3] = (uint32_t)(uint8_t)(int8_t)e[0] | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16) | (A.order ? 0u : 1u << 24);   // imask: 1 = TLAS node
     // children: 4 x { meta, lo x y z, hi x y z } = 28 bytes from dword 6 on
     uint64_t cbits[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const bool on = !leaf && (uint32_t)k < nc;
+      const bool on = (uint32_t)k < nc;
       cbits[k] = on ? (1ull | ((uint64_t)ql[k][0] << 8) | ((uint64_t)ql[k][1] << 16) | ((uint64_t)ql[k][2] << 24) |
                        ((uint64_t)qh[k][0] << 32) | ((uint64_t)qh[k][1] << 40) | ((uint64_t)qh[k][2] << 48)) : 0ull;   // 7 bytes
     }
@@ -651,6 +699,16 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
     uint32_t* o = A.nodes + (size_t)out * RT_NODE_DWORDS;
 #pragma unroll
     for (int k = 0; k < RT_NODE_DWORDS; ++k) o[k] = w[k];
+    // the children: leaves are written now, the others queued
+    uint32_t cstart = start, qpos = pos;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((uint32_t)k < nc) {
+        if (cr[k].plan & PLAN_LEAF) bb_emit_leaf(A, c[k], cr[k], first + k, cstart);
+        else A.out[qpos++] = make_uint4(c[k], first + k, cstart, 0u);
+        cstart += cr[k].count;
+      }
+    }
   }
 }
 
@@ -715,6 +773,7 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   int* cb = sc.get<int>(8);
   uint32_t* counters = sc.get<uint32_t>(n_counters);
   uint32_t* st = sc.get<uint32_t>(ST_WORDS);
+  uint32_t* seq = sc.get<uint32_t>(64);
   uint64_t* keys0 = sc.get<uint64_t>(n);
   uint64_t* keys1 = sc.get<uint64_t>(n);
   uint32_t* vals0 = sc.get<uint32_t>(n);
@@ -730,14 +789,15 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   uint32_t* order = sc.get<uint32_t>(n);
   uint32_t* gather = sc.get<uint32_t>((size_t)n * (d_triEx ? 16 : 9));
   void* tmp = sc.get<uint8_t>(tmp_bytes ? tmp_bytes : 16);
-  if (!cb || !counters || !st || !keys0 || !keys1 || !vals0 || !vals1 || !rec || !cl0 || !cl1 || !dec || !tile_counts || !tile_base || !q0 || !q1 ||
+  if (!cb || !counters || !st || !seq || !keys0 || !keys1 || !vals0 || !vals1 || !rec || !cl0 || !cl1 || !dec || !tile_counts || !tile_base || !q0 || !q1 ||
       !order || !gather || !tmp || !sc.pinned) return -1;
   const uint32_t wide = blocks < 4096u ? blocks : 4096u;
   const float tri_cost = boxes ? 0.0f : BB_TRI_COST;
 
   hipLaunchKernelGGL(bb_init_kernel, dim3(1), dim3(256), 0, s, cb, counters, n_counters, q0);
   hipLaunchKernelGGL(bb_bounds_kernel, dim3(wide < 512u ? wide : 512u), dim3(256), 0, s, (const float*)d_tri, n, cb, boxes);
-  hipLaunchKernelGGL(bb_morton_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, n, cb, keys0, vals0, boxes);
+  hipLaunchKernelGGL(bb_axis_sequence_kernel, dim3(1), dim3(64), 0, s, (const int*)cb, seq);
+  hipLaunchKernelGGL(bb_morton_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d_tri, n, (const int*)cb, (const uint32_t*)seq, keys0, vals0, boxes);
   if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
 
   // clustering: rounds of (decide, scan, apply) over the whole array while it is long, eight at a time between looks at the
