@@ -232,14 +232,16 @@ int vxrt_render_interleaved(vxrt_accel_t* accel, uint32_t width, uint32_t height
 
 /* BLAS construction on the GPU, in the reference's formats.  Replaces, for one mesh, BVH::build + the 4-wide collapse + the
  * quantiser of tests/regression/raytracing/bvh.cpp:30-264 (host code run at scene load in the reference; csrc/scene_builder.cpp
- * is the CPU counterpart here).  Morton order + binary radix tree + 4-wide collapse by surface area; see csrc/bvh_builder.hip.
+ * is the CPU counterpart here).  Morton order, PLOC clustering (mutual nearest neighbours by surface area of the union), 4-wide
+ * collapse by the SAH dynamic programme; see csrc/bvh_builder.hip.
  *   tri      device, n_tris x 36 B (tri_t); REORDERED IN PLACE so that a leaf is a range (bvh.cpp:126-128)
  *   triEx    device, n_tris x 64 B (tri_ex_t), reordered alongside; may be NULL
  *   tri_offset  added to every leaf's leftFirst (index of the mesh's first triangle in the scene's buffer, bvh.cpp:260)
- *   leaf_max    largest leaf, 1..15 (0 = 2, the fastest to traverse on the 1M-triangle scene: profiles/r02_h_gpu_builder.jsonl)
+ *   leaf_max    largest leaf, 1..15 (0 = 2); a subtree of <= leaf_max triangles becomes a leaf where the surface-area cost of that
+ *               is lower than a node over it (2 / 3 / 4 measured equal within 1 % on the 1M-triangle scene: profiles/r03_t_builder_cost_ab.txt)
  *   nodes    device, node_capacity x 52 B (bvh_quantized_node_t), node_capacity >= 2 * n_tris - 1 (the reference allocates
  *            2 * numTris, scene.cpp:40); node 0 is the root, children follow their parent
- * Synchronises `stream` once to read the counts back.  Returns 0; -1 on bad arguments, allocation failure or a box that cannot
+ * Synchronises `stream` a few times (the cluster count between groups of clustering rounds, the counts at the end).  Returns 0; -1 on bad arguments, allocation failure or a box that cannot
  * be quantised; -2 if the tree is deeper than the 32 levels the reference's trail supports (use the SAH builder). */
 typedef struct vxrt_bvh_info {
   uint32_t n_nodes, n_leaves, max_leaf, max_depth;

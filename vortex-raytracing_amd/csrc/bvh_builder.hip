@@ -27,6 +27,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <mutex>
 #include <vector>
@@ -792,7 +793,9 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   if (!cb || !counters || !st || !seq || !keys0 || !keys1 || !vals0 || !vals1 || !rec || !cl0 || !cl1 || !dec || !tile_counts || !tile_base || !q0 || !q1 ||
       !order || !gather || !tmp || !sc.pinned) return -1;
   const uint32_t wide = blocks < 4096u ? blocks : 4096u;
-  const float tri_cost = boxes ? 0.0f : BB_TRI_COST;
+  // (VXRT_BVH_TRI_COST: the triangle's cost against the node record's 52, for measurements; the default is the format's byte ratio)
+  static const float tri_cost_env = [] { const char* e = getenv("VXRT_BVH_TRI_COST"); return e ? (float)atof(e) : BB_TRI_COST; }();
+  const float tri_cost = boxes ? 0.0f : tri_cost_env;
 
   hipLaunchKernelGGL(bb_init_kernel, dim3(1), dim3(256), 0, s, cb, counters, n_counters, q0);
   hipLaunchKernelGGL(bb_bounds_kernel, dim3(wide < 512u ? wide : 512u), dim3(256), 0, s, (const float*)d_tri, n, cb, boxes);
