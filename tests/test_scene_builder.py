@@ -1,8 +1,12 @@
 """CPU: the host-side BVH4 builder / quantiser (csrc/scene_builder.cpp).  Its tree shape is its own
 (the reference widens clusters from uninitialised bounds, bvh.cpp:79-86), so it is validated by
 invariants and by traversal equivalence against brute force and against the reference-built tree."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 NODE = np.dtype([("o", "<f4", 3), ("e", "i1", 3), ("imask", "u1"), ("lf", "<u4"), ("ld", "<u4"), ("ch", "u1", (4, 7))])
 assert NODE.itemsize == 52
@@ -97,6 +101,42 @@ def test_builder_invariants(vrt, args):
     assert sc.info["n_tris"] == sc.n_tris
     tl = sc["tlas"].view(NODE)
     assert len(tl) == 1 and tl[0]["imask"] == 1 and tl[0]["ld"] == 0     # single mesh: TLAS root is the instance leaf (bvh.cpp:325-328)
+
+
+def test_binary_tree_plus_optimal_collapse_variant_keeps_the_invariants():
+    """VXS_COLLAPSE=1 (binary SAH tree + the SAH dynamic programme's 4-wide collapse; the knobs are read when the library loads, so a
+    child process): same invariants, same closest distances as the default builder's tree of the same triangles."""
+    import subprocess, sys
+    code = (
+        "import sys, importlib, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "vrt = importlib.import_module('vortex-raytracing_amd')\n"
+        "from test_scene_builder import check_tree, check_tree_fast\n"
+        "from oracle import pyoracle as po\n"
+        "for args in (('atrium', 4, 0, 3), ('hairball', 60, 20, 7), ('blob', 3, 0, 2)):\n"
+        "    sc = vrt.scene.procedural(*args)\n"
+        "    d = check_tree(sc)\n"
+        "    assert d == sc.info['max_depth'] < 32 and check_tree_fast(sc) == d and sc.info['max_leaf'] <= 4\n"
+        "    rays = po.camera_rays(64, 48)\n"
+        "    rays = rays[(rays[:, 3:] != 0).all(1)]\n"
+        "    h, _ = po.trace_canonical(sc, rays)\n"
+        "    np.save(sys.argv[1] + '_' + args[0] + '.npy', h['dist'])\n"
+        "    print(args[0], sc.n_bvh_nodes)\n") % (ROOT, os.path.join(ROOT, "tests"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        outs = {}
+        for mode in ("0", "1"):
+            env = dict(os.environ, VXS_COLLAPSE=mode)
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "m" + mode)], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[mode] = dict(l.split() for l in r.stdout.strip().splitlines())
+        hits = 0
+        for name in ("atrium", "hairball", "blob"):
+            a, b = np.load(os.path.join(d, "m0_%s.npy" % name)), np.load(os.path.join(d, "m1_%s.npy" % name))
+            hits += int((a < 1e29).sum())
+            assert (a == b).mean() > 0.999      # (a re-quantised box chain can drop a grazing hit in either tree: DESIGN.md s3)
+        assert hits > 300
+        assert outs["0"] != outs["1"]          # the variant really built different trees
 
 
 def test_atrium_level8_is_the_1m_triangle_scene(vrt):
