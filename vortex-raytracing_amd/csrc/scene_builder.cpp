@@ -51,10 +51,13 @@ static float kLeafK = 1.0f;  // keep <= kLeafMax triangles in one leaf when the 
 static int kLeafMax = 4;
 static int kThreads = 8;     // worker threads of the BLAS builder (VXS_THREADS overrides; the tree and its layout do not depend on it)
 static int kWiden = 0;      // 0: widen the cluster with the largest SAH gain (reference), 1: the one with the largest area
-static int kCollapse = 0;   // 0: widen greedily while building; 1: build the binary SAH tree to the bottom, then collapse it to 4-wide by the SAH
-                            // dynamic programme (below).  Measured equal on the 1M-triangle frame -- 9 % fewer nodes, the same bytes per ray
-                            // (1,293.4 against 1,294.7) and frame rate (profiles/r03_t_cpu_collapse_ab.txt) -- so the builder the round's
-                            // numbers were taken with stays the default.  VXS_COLLAPSE overrides
+static int kCollapse = 1;   // 1: build the binary SAH tree to the bottom, optimise it by reinsertion (kOptimize passes), collapse it to 4-wide by the SAH
+                            // dynamic programme; 0: widen greedily while building (the builder up to profiles/r03_s).  VXS_COLLAPSE overrides.
+                            // Measured on the 1M-triangle frame (profiles/r03_t_cpu_collapse_ab.txt, r03_v_reinsertion_*.txt): the collapse alone
+                            // changes nothing (9 % fewer nodes, the same bytes per ray and frame rate); with the reinsertion passes +7.8 %
+static int kOptimize = 2;   // passes of insertion-based optimisation of the binary tree before the collapse (1 pass +6.9 %, 2 +7.8 %, 3 the same). VXS_OPTIMIZE
+static int kOptimizeLocal = 0;   // 1: the workers optimise their subtrees (in parallel), one serial pass moves the nodes of the top: 4x faster, +6 %. VXS_OPTIMIZE_LOCAL
+static double kOptimizeFraction = 1.0;   // share of the nodes, largest first, a pass takes. VXS_OPTIMIZE_FRACTION
 constexpr float kNodeCost = 52.0f, kTriCost = 36.0f;   // bytes a visit fetches: the unit of the collapse's cost
 
 struct Box {
@@ -171,6 +174,7 @@ private:
     const uint32_t defer_below = std::max<uint32_t>(4096u, n_ / 256u);
     std::vector<uint32_t> deferred;
     build_binary(bn, 0, defer_below, &deferred);
+    const uint32_t n_top = (uint32_t)bn.size();
     if (!deferred.empty()) {
       std::vector<std::vector<BinNode>> sub(deferred.size());
       std::vector<size_t> order(deferred.size());
@@ -185,6 +189,7 @@ private:
           sub[t].reserve(2 * (size_t)bn[deferred[t]].count + 1);
           sub[t].push_back(bn[deferred[t]]);
           build_binary(sub[t], 0, 0u, nullptr);
+          if (kOptimize > 0 && kOptimizeLocal) optimize_by_reinsertion(sub[t]);
         }
       };
       const int nthreads = (int)std::min<size_t>((size_t)kThreads, deferred.size());
@@ -201,9 +206,20 @@ private:
         std::vector<BinNode>().swap(L);
       }
     }
-    // the dynamic programme, children before parents (a child's index is always above its parent's)
-    for (size_t i = bn.size(); i-- > 0;) {
-      BinNode& x = bn[i];
+    if (kOptimize > 0) optimize_by_reinsertion(bn, kOptimizeLocal ? n_top : 0xffffffffu);
+    // the dynamic programme, children before parents
+    std::vector<uint32_t> post;
+    post.reserve(bn.size());
+    {
+      std::vector<uint32_t> st{0u};
+      while (!st.empty()) {
+        const uint32_t i = st.back(); st.pop_back();
+        post.push_back(i);
+        if (bn[i].left) { st.push_back(bn[i].left); st.push_back(bn[i].right); }
+      }
+    }
+    for (size_t pi = post.size(); pi-- > 0;) {
+      BinNode& x = bn[post[pi]];
       const float ar = x.box.half_area();
       if (!x.left) {
         const float c = ar * (kNodeCost + kTriCost * (float)x.count);
@@ -255,6 +271,104 @@ private:
       nodes_[t.wide].triCount = 0; nodes_[t.wide].leftFirst = first; nodes_[t.wide].childCount = nc;
       for (uint32_t k = nc; k-- > 0;) st.push_back({first + k, c[k], t.depth + 1});
     }
+  }
+
+  // Insertion-based optimisation of the binary tree (Bittner, Hapala & Havran, "Fast insertion-based optimization of bounding volume
+  // hierarchies", 2013, in the subtree-reinsertion form of Meister & Bittner 2018): a node is cut out together with its parent (its
+  // sibling takes the parent's place), the tree is searched best-first for the position where putting it back costs the least
+  // surface area -- the area of the new common parent plus what every ancestor's box grows by -- and the freed parent node is reused
+  // there.  The position it came from is among the candidates, so a step never raises the cost.  Nodes are taken largest area
+  // first, kOptimize passes.  Leaves stop being ranges of the triangle array: the array is put into the final tree's leaf order
+  // afterwards.
+  // `limit`: only nodes with an index below it are moved (the pass over the serially built top after the subtrees were optimised by
+  // their workers); the search always covers the whole tree under node 0.
+  void optimize_by_reinsertion(std::vector<BinNode>& bn, uint32_t limit = 0xffffffffu) {
+    const uint32_t N = (uint32_t)bn.size();
+    if (N < 8) return;
+    std::vector<uint32_t> parent(N, 0u);
+    for (uint32_t i = 0; i < N; ++i) if (bn[i].left) { parent[bn[i].left] = i; parent[bn[i].right] = i; }
+    auto unite = [](const Box& a, const Box& b) { Box r; r.lo = vmin(a.lo, b.lo); r.hi = vmax(a.hi, b.hi); return r; };
+    auto same = [](const Box& a, const Box& b) { return a.lo.x == b.lo.x && a.lo.y == b.lo.y && a.lo.z == b.lo.z && a.hi.x == b.hi.x && a.hi.y == b.hi.y && a.hi.z == b.hi.z; };
+    auto refit_up = [&](uint32_t i) {   // boxes of i and its ancestors from their children, until one does not change
+      for (;;) {
+        const Box b = unite(bn[bn[i].left].box, bn[bn[i].right].box);
+        if (same(b, bn[i].box)) break;
+        bn[i].box = b;
+        if (i == 0) break;
+        i = parent[i];
+      }
+    };
+    struct Cand { float ci; uint32_t node; bool operator<(const Cand& o) const { return ci > o.ci; } };   // (min-heap on the induced cost)
+    std::vector<Cand> heap;
+    std::vector<uint32_t> order;
+    order.reserve(N);
+    for (int pass = 0; pass < kOptimize; ++pass) {
+      order.clear();
+      for (uint32_t i = 1; i < N && i < limit; ++i) if (parent[i] != 0u) order.push_back(i);
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bn[a].box.half_area() > bn[b].box.half_area(); });
+      const size_t take = (size_t)((double)order.size() * kOptimizeFraction);
+      for (size_t oi = 0; oi < take; ++oi) {
+        const uint32_t X = order[oi];
+        const uint32_t P = parent[X];
+        if (P == 0u) continue;            // (moved under the root by an earlier step of this pass)
+        const uint32_t G = parent[P];
+        const uint32_t S = bn[P].left == X ? bn[P].right : bn[P].left;
+        // cut X and P out: S takes P's place under G
+        if (bn[G].left == P) bn[G].left = S; else bn[G].right = S;
+        parent[S] = G;
+        refit_up(G);
+        // best position: least (area of the common parent + growth of every ancestor)
+        const Box xb = bn[X].box;
+        const float ax = xb.half_area();
+        float best_cost = INFINITY; uint32_t best = S;
+        heap.clear();
+        heap.push_back({0.0f, bn[0].left}); std::push_heap(heap.begin(), heap.end());
+        heap.push_back({0.0f, bn[0].right}); std::push_heap(heap.begin(), heap.end());
+        // (X lay inside the root's box and still does: the root itself grows by nothing; the root is not a candidate, it stays node 0)
+        while (!heap.empty()) {
+          std::pop_heap(heap.begin(), heap.end());
+          const Cand c = heap.back(); heap.pop_back();
+          if (c.ci + ax >= best_cost) break;
+          const BinNode& t = bn[c.node];
+          const float direct = unite(t.box, xb).half_area();
+          const float total = c.ci + direct;
+          if (total < best_cost) { best_cost = total; best = c.node; }
+          const float ci = total - t.box.half_area();
+          if (t.left && ci + ax < best_cost) {
+            heap.push_back({ci, t.left}); std::push_heap(heap.begin(), heap.end());
+            heap.push_back({ci, t.right}); std::push_heap(heap.begin(), heap.end());
+          }
+        }
+        // P goes where `best` was, over best and X
+        const uint32_t T = best, Q = parent[T];
+        if (bn[Q].left == T) bn[Q].left = P; else bn[Q].right = P;
+        parent[P] = Q;
+        bn[P].left = T; bn[P].right = X;
+        parent[T] = P; parent[X] = P;
+        bn[P].box = unite(bn[T].box, xb);
+        refit_up(Q);
+      }
+    }
+    // triangles into the leaf order of the final tree; ranges and counts from the leaves up
+    const uint32_t r0 = bn[0].first, rn = bn[0].count;   // (the root's range: a worker's subtree owns a slice of the array)
+    std::vector<rt_tri_t> tri2(rn);
+    std::vector<rt_triex_t> ex2(triEx_ ? rn : 0);
+    uint32_t pos = 0;
+    std::vector<uint32_t> st{0u}, post;
+    post.reserve(N);
+    while (!st.empty()) {   // (left before right: pushed in reverse)
+      const uint32_t i = st.back(); st.pop_back();
+      post.push_back(i);
+      if (bn[i].left) { st.push_back(bn[i].right); st.push_back(bn[i].left); continue; }
+      for (uint32_t k = 0; k < bn[i].count; ++k) { tri2[pos + k] = tri_[bn[i].first + k]; if (triEx_) ex2[pos + k] = triEx_[bn[i].first + k]; }
+      bn[i].first = r0 + pos; pos += bn[i].count;
+    }
+    for (size_t pi = post.size(); pi-- > 0;) {
+      BinNode& x = bn[post[pi]];
+      if (x.left) { x.first = bn[x.left].first; x.count = bn[x.left].count + bn[x.right].count; }
+    }
+    std::memcpy(tri_ + r0, tri2.data(), (size_t)rn * sizeof(rt_tri_t));
+    if (triEx_) std::memcpy(triEx_ + r0, ex2.data(), (size_t)rn * sizeof(rt_triex_t));
   }
 
   // binary binned-SAH tree under node `root` of `bn` (its range set), split until single triangles or no split separates anything
@@ -1239,6 +1353,9 @@ static void read_knobs() {
   if (const char* e = std::getenv("VXS_BINS")) { int v = std::atoi(e); if (v >= 2 && v <= kMaxBins) kBins = v; }
   if (const char* e = std::getenv("VXS_WIDEN")) kWiden = std::atoi(e);
   if (const char* e = std::getenv("VXS_COLLAPSE")) kCollapse = std::atoi(e);
+  if (const char* e = std::getenv("VXS_OPTIMIZE")) kOptimize = std::atoi(e);
+  if (const char* e = std::getenv("VXS_OPTIMIZE_LOCAL")) kOptimizeLocal = std::atoi(e);
+  if (const char* e = std::getenv("VXS_OPTIMIZE_FRACTION")) kOptimizeFraction = std::atof(e);
   { unsigned hc = std::thread::hardware_concurrency(); kThreads = (int)std::min<unsigned>(hc ? hc : 1u, 16u); }
   if (const char* e = std::getenv("VXS_THREADS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) kThreads = v; }
   if (const char* e = std::getenv("VXS_LEAF_K")) kLeafK = (float)std::atof(e);
