@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of an environment knob on one GPU box, alternating runs: driver command (20 steps) and a 200-step run per setting.
 # usage: tools/ab_env.sh <outfile> <reps> VAR=val1 VAR=val2 ...     (e.g. VXRT_FUSED=1 VXRT_FUSED=0)
+export VXRT_SCENE_CACHE=${VXRT_SCENE_CACHE:-/tmp/vxrt_scene_cache}   # built scenes are kept between the processes of this script (keyed by the builder's knobs)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$1; REPS=$2; shift 2
 mkdir -p "$(dirname "$OUT")"

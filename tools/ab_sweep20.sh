@@ -1,5 +1,6 @@
 #!/bin/bash
 # sweeps on one GPU box for the driver's command (20 steps) and a 200-step run: frames per set of launches, frames in flight, side reserve
+export VXRT_SCENE_CACHE=${VXRT_SCENE_CACHE:-/tmp/vxrt_scene_cache}   # built scenes are kept between the processes of this script (keyed by the builder's knobs)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 run() { "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   ', d['value'], d['ms_per_step'])"; }
 for rep in 1 2; do

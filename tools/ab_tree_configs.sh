@@ -1,6 +1,7 @@
 #!/bin/bash
 # builder settings against each other on the headline bench line and the other configurations.
 # usage: tools/ab_tree_configs.sh <out file under gpurun_out> "<env A>" "<env B>" ...
+export VXRT_SCENE_CACHE=${VXRT_SCENE_CACHE:-/tmp/vxrt_scene_cache}   # built scenes are kept between the processes of this script (keyed by the builder's knobs)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$ROOT"
 OUT=$ROOT/gpurun_out/$1; shift

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-end PMC set for the bench step (serial frames), one small counter group per rocprofv3 pass,
 # counters only.  usage: tools/pmc_passes.sh <outdir>
+export VXRT_SCENE_CACHE=${VXRT_SCENE_CACHE:-/tmp/vxrt_scene_cache}   # built scenes are kept between the processes of this script (keyed by the builder's knobs)
 set -u
 OUT=$1; shift
 mkdir -p "$OUT"

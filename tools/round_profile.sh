@@ -2,6 +2,7 @@
 # Round-end evidence in one GPU call: GPU tests, PMC passes -> profiles/valu_profile.json constants, the default bench line (which
 # reads them) and the serial one, the driver's command, rocprofv3 kernel stats + timelines of the pipelined and the serial command,
 # the other configurations and the VALU figure of their kernels.  usage: tools/round_profile.sh <tag>
+export VXRT_SCENE_CACHE=${VXRT_SCENE_CACHE:-/tmp/vxrt_scene_cache}   # built scenes are kept between the processes of this script (keyed by the builder's knobs)
 set -u
 TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

@@ -3,6 +3,7 @@
 Produces the buffers Tracer::init/setup upload (reference tracer.cpp:124-161,217-241) in the
 reference's byte formats."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -91,10 +92,34 @@ def _from_handle(h, name):
         lib.vxs_scene_destroy(h)
 
 
+def _cache_path(name, a, b, seed):
+    """File of a built scene under $VXRT_SCENE_CACHE (unset: no cache).  The key holds the builder's knobs (VXS_*) and the library's
+    build time: measurement scripts that start a dozen processes over the same 1M-triangle scene build it once."""
+    d = os.environ.get("VXRT_SCENE_CACHE")
+    if not d:
+        return None
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvxrt_scene.so")
+    key = repr((name, a, b, seed, sorted((k, v) for k, v in os.environ.items() if k.startswith("VXS_")), os.path.getmtime(lib)))
+    return os.path.join(d, "scene_%s_%s.npz" % (name, hashlib.sha1(key.encode()).hexdigest()[:16]))
+
+
 def procedural(name, a=0, b=0, seed=1):
     """'cornell' | 'blob' (a = icosphere subdivisions) | 'atrium' (a = level; 8 -> 1,048,576 tris)
     | 'hairball' (a strands x b segments)."""
-    return _from_handle(_load().vxs_scene_create_procedural(name.encode(), a, b, seed), name)
+    path = _cache_path(name, a, b, seed)
+    if path and os.path.exists(path):
+        with np.load(path) as z:
+            info = dict(zip(("max_depth", "n_leaves", "max_leaf", "n_bvh_nodes", "n_tlas_nodes", "n_tris"), z["__info"].tolist()))
+            return Scene({k: z[k] for k in z.files if not k.startswith("__")}, info, z["__bounds"].copy(), name)
+    sc = _from_handle(_load().vxs_scene_create_procedural(name.encode(), a, b, seed), name)
+    if path:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + ".%d.tmp.npz" % os.getpid()
+        np.savez(tmp, __info=np.array([sc.info[k] for k in ("max_depth", "n_leaves", "max_leaf", "n_bvh_nodes", "n_tlas_nodes", "n_tris")], np.int64),
+                 __bounds=np.asarray(sc.bounds, np.float32), **sc.buffers)
+        os.replace(tmp, path)
+    return sc
 
 
 def from_triangles(meshes, transforms=None):
