@@ -56,6 +56,7 @@ static int kCollapse = 1;   // 1: build the binary SAH tree to the bottom, optim
                             // Measured on the 1M-triangle frame (profiles/r03_t_cpu_collapse_ab.txt, r03_v_reinsertion_*.txt): the collapse alone
                             // changes nothing (9 % fewer nodes, the same bytes per ray and frame rate); with the reinsertion passes +7.8 %
 static int kOptimize = 2;   // passes of insertion-based optimisation of the binary tree before the collapse (1 pass +6.9 %, 2 +7.8 %, 3 the same). VXS_OPTIMIZE
+static int kVerbose = 0;      // VXS_VERBOSE
 static int kOptimizeLocal = 0;   // 1: the workers optimise their subtrees (in parallel), one serial pass moves the nodes of the top: 4x faster, +6 %. VXS_OPTIMIZE_LOCAL
 static double kOptimizeFraction = 1.0;   // share of the nodes, largest first, a pass takes. VXS_OPTIMIZE_FRACTION
 constexpr float kNodeCost = 52.0f, kTriCost = 36.0f;   // bytes a visit fetches: the unit of the collapse's cost
@@ -302,7 +303,15 @@ private:
     std::vector<Cand> heap;
     std::vector<uint32_t> order;
     order.reserve(N);
+    auto report = [&](int pass) {   // VXS_VERBOSE: surface-area cost of the binary tree (internal nodes' areas over the root's)
+      if (!kVerbose) return;
+      double a = 0;
+      for (uint32_t i = 0; i < N; ++i) if (bn[i].left && (i == 0 || parent[i] != 0xffffffffu)) a += bn[i].box.half_area();
+      std::fprintf(stderr, "[scene_builder] reinsertion pass %d: %u nodes, internal area / root area = %.3f\n", pass, N, a / bn[0].box.half_area());
+    };
+    report(0);
     for (int pass = 0; pass < kOptimize; ++pass) {
+      if (pass) report(pass);
       order.clear();
       for (uint32_t i = 1; i < N && i < limit; ++i) if (parent[i] != 0u) order.push_back(i);
       std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bn[a].box.half_area() > bn[b].box.half_area(); });
@@ -349,6 +358,7 @@ private:
         refit_up(Q);
       }
     }
+    report(kOptimize);
     // triangles into the leaf order of the final tree; ranges and counts from the leaves up
     const uint32_t r0 = bn[0].first, rn = bn[0].count;   // (the root's range: a worker's subtree owns a slice of the array)
     std::vector<rt_tri_t> tri2(rn);
@@ -1354,6 +1364,7 @@ static void read_knobs() {
   if (const char* e = std::getenv("VXS_WIDEN")) kWiden = std::atoi(e);
   if (const char* e = std::getenv("VXS_COLLAPSE")) kCollapse = std::atoi(e);
   if (const char* e = std::getenv("VXS_OPTIMIZE")) kOptimize = std::atoi(e);
+  if (const char* e = std::getenv("VXS_VERBOSE")) kVerbose = std::atoi(e);
   if (const char* e = std::getenv("VXS_OPTIMIZE_LOCAL")) kOptimizeLocal = std::atoi(e);
   if (const char* e = std::getenv("VXS_OPTIMIZE_FRACTION")) kOptimizeFraction = std::atof(e);
   { unsigned hc = std::thread::hardware_concurrency(); kThreads = (int)std::min<unsigned>(hc ? hc : 1u, 16u); }
