@@ -111,7 +111,7 @@ public:
       V3 s = tv(tri[i].v0) + tv(tri[i].v1) + tv(tri[i].v2);
       cent_[i] = {s.x / 3, s.y / 3, s.z / 3};     // scene.cpp:87
     }
-    if (kCollapse == 1 && width_ == 4) { build_collapsed(); return; }
+    if (kCollapse == 1 && (width_ == 4 || width_ == 2)) { build_collapsed(); return; }
     nodes_.reserve(2 * (size_t)n + 1);
     nodes_.emplace_back();
     nodes_[0].leftFirst = 0;
@@ -223,12 +223,20 @@ private:
       BinNode& x = bn[post[pi]];
       const float ar = x.box.half_area();
       if (!x.left) {
-        const float c = ar * (kNodeCost + kTriCost * (float)x.count);
+        const float c = ar * ((width_ == 2 ? 32.0f : kNodeCost) + kTriCost * (float)x.count);
         x.f[0] = x.f[1] = x.f[2] = x.f[3] = c;
         x.plan = kPlanLeaf;
         continue;
       }
       const float* A = bn[x.left].f; const float* B = bn[x.right].f;
+      if (width_ == 2) {   // the raycast twin's BVH2: no collapse, only the leaf-or-node choice (32-byte nodes)
+        const float c_node = ar * 32.0f + A[0] + B[0];
+        const float c_leaf = (int)x.count <= kLeafMax ? ar * (32.0f + kTriCost * (float)x.count) : INFINITY;
+        const bool leaf = c_leaf <= c_node;
+        x.f[0] = x.f[1] = x.f[2] = x.f[3] = leaf ? c_leaf : c_node;
+        x.plan = 1u | (7u << 6) | (leaf ? kPlanLeaf : 0u);
+        continue;
+      }
       const float g2 = A[0] + B[0];
       float g3 = A[0] + B[1]; uint32_t a3 = 1;
       if (A[1] + B[0] < g3) { g3 = A[1] + B[0]; a3 = 2; }
@@ -254,8 +262,8 @@ private:
       const BinNode& x = bn[t.bin];
       nodes_[t.wide].box = x.box;
       if (x.plan & kPlanLeaf) { nodes_[t.wide].leftFirst = x.first; nodes_[t.wide].triCount = x.count; nodes_[t.wide].childCount = 0; continue; }
-      uint32_t c[4] = {x.left, x.right, 0, 0}, slots[4] = {plan_a(x.plan, 4u), 0, 0, 0}, nc = 2;
-      slots[1] = 4u - slots[0];
+      uint32_t c[4] = {x.left, x.right, 0, 0}, slots[4] = {width_ == 4 ? plan_a(x.plan, 4u) : 1u, 0, 0, 0}, nc = 2;
+      slots[1] = width_ - slots[0];
       for (;;) {   // a child offered j > 1 slots hands them to its own children unless it stays one child
         int pick = -1;
         for (uint32_t k = 0; k < nc && pick < 0; ++k)
