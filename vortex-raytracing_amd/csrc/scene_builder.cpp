@@ -59,7 +59,8 @@ static int kOptimize = 2;   // passes of insertion-based optimisation of the bin
 static int kVerbose = 0;      // VXS_VERBOSE
 static int kOptimizeLocal = 0;   // 1: the workers optimise their subtrees (in parallel), one serial pass moves the nodes of the top: 4x faster, +6 %. VXS_OPTIMIZE_LOCAL
 static double kOptimizeFraction = 1.0;   // share of the nodes, largest first, a pass takes. VXS_OPTIMIZE_FRACTION
-constexpr float kNodeCost = 52.0f, kTriCost = 36.0f;   // bytes a visit fetches: the unit of the collapse's cost
+constexpr float kNodeCost = 52.0f;   // bytes a node visit fetches: the unit of the collapse's cost
+static float kTriCost = 36.0f;       // ... and a triangle test.  VXS_TRI_COST (measured flat between 18 and 72: profiles/r03_v_tri_cost_ab.txt)
 
 struct Box {
   V3 lo{kBig, kBig, kBig}, hi{-kBig, -kBig, -kBig};
@@ -1373,6 +1374,7 @@ static void read_knobs() {
   if (const char* e = std::getenv("VXS_COLLAPSE")) kCollapse = std::atoi(e);
   if (const char* e = std::getenv("VXS_OPTIMIZE")) kOptimize = std::atoi(e);
   if (const char* e = std::getenv("VXS_VERBOSE")) kVerbose = std::atoi(e);
+  if (const char* e = std::getenv("VXS_TRI_COST")) kTriCost = (float)std::atof(e);
   if (const char* e = std::getenv("VXS_OPTIMIZE_LOCAL")) kOptimizeLocal = std::atoi(e);
   if (const char* e = std::getenv("VXS_OPTIMIZE_FRACTION")) kOptimizeFraction = std::atof(e);
   { unsigned hc = std::thread::hardware_concurrency(); kThreads = (int)std::min<unsigned>(hc ? hc : 1u, 16u); }
