@@ -8,7 +8,7 @@
 //   1. centroid bounds              one pass, wavefront reduction + 6 atomics per workgroup
 //   2. 63-bit Morton keys           21 bits per axis of the triangle's box centre (extended order)
 //   3. radix sort (key, index)      rocPRIM device sort, 8 passes over 12 bytes per triangle
-//   4. clustering                   PLOC: rounds of "merge the pairs that are each other's nearest neighbour within 4 positions of
+//   4. clustering                   PLOC: rounds of "merge the pairs that are each other's nearest neighbour within 8 positions of
 //                                   the Morton order" (nearest = smallest surface area of the union), boxes and the SAH dynamic
 //                                   programme of the 4-wide collapse computed as the nodes are made; the last 1,024 clusters in
 //                                   one workgroup.  (Rounds 1-2: Karras' binary radix tree + a bottom-up box pass.)
@@ -174,7 +174,11 @@ __global__ __launch_bounds__(256) void bb_morton_kernel(const float* __restrict_
 // with at most j child slots of a wide node, cost = expected bytes fetched per random ray (52 B per node record, 36 B per triangle,
 // times surface area); `plan` records the choices for the top-down pass (step 6).  A subtree of <= leaf_max triangles may become
 // a leaf where that is cheaper than a node over it.
-constexpr int BB_RADIUS = 4;          // search radius (measured on the CPU prototype, tools/ploc_prototype.py: 4 < 8 < 16 in SAH cost here)
+#ifndef BB_RADIUS_N
+#define BB_RADIUS_N 8
+#endif
+constexpr int BB_RADIUS = BB_RADIUS_N;   // search radius.  The CPU prototype's surface-area cost ranks 4 < 8 < 16 (tools/ploc_prototype.py); the frame on the GPU says
+                                         // 8: 7.43-7.55 Grays/s against 7.26-7.35 at 4, 7.25 at 6, 7.32 at 10, 7.43 at 12, 7.42 at 16 (profiles/r03_v_ploc_radius.txt); +0.13 ms
 constexpr int BB_TAIL = 1024;         // clusters the single-workgroup tail takes over at
 constexpr float BB_NODE_COST = 52.0f, BB_TRI_COST = 36.0f;   // bytes
 
