@@ -2020,7 +2020,7 @@ struct FrameCtx {
   uint32_t* bin_hist = nullptr; uint32_t* bin_keys = nullptr; uint32_t* bin_order = nullptr; uint64_t bin_cap = 0, bin_ray_cap = 0;   // secondary-ray binning
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr;
-  bool busy = false, inited = false;
+  bool busy = false, inited = false, done_recorded = false;
   hipStream_t last_stream = nullptr;
 };
 
@@ -2031,6 +2031,7 @@ struct vxrt_accel {
   void* top_img = nullptr; uint32_t* top_roots = nullptr;   // LDS-staged top of the tree: image; [0] n, [1] TLAS root, [2..] BLAS roots
   FrameCtx ctx[MAX_FRAMES_IN_FLIGHT];
   uint32_t n_ctx = 1, next_ctx = 0;
+  bool stream_seen = false, multi_stream = false; hipStream_t first_stream = nullptr;   // (see release_ctx)
   float* uvtab = nullptr;      // camera tables: u[W] then v[H]
   uint32_t uv_w = 0, uv_h = 0;
   // camera pixels whose primary ray has a zero direction component (u == 0 or v == 0): listed on the
@@ -2070,6 +2071,7 @@ static void accel_free(vxrt_accel* a) {
 
 // next frame context, ordered on `s` behind its previous use
 static FrameCtx* acquire_ctx(vxrt_accel* a, hipStream_t s) {
+  if (!a->stream_seen) { a->stream_seen = true; a->first_stream = s; } else if (s != a->first_stream) a->multi_stream = true;
   // the context this stream used last (no event hop: the stream orders the two frames), else one never used, else round robin.
   // (Plain round robin pairs contexts with streams only while the caller's stream rotation and the call count stay in step: an odd
   // number of warm-up frames was enough to put every later frame behind a cross-stream event wait, -3 %.)
@@ -2092,7 +2094,10 @@ static FrameCtx* acquire_ctx(vxrt_accel* a, hipStream_t s) {
     if (hipMemset(c.ctl, 0, CTL_DWORDS * sizeof(uint32_t)) != hipSuccess) return nullptr;
     c.inited = true;
   }
-  if (c.busy && c.last_stream != s && hipStreamWaitEvent(s, c.ev_done, 0) != hipSuccess) return nullptr;   // (same stream: already ordered)
+  if (c.busy && c.last_stream != s) {   // (same stream: already ordered)
+    if (c.done_recorded) { if (hipStreamWaitEvent(s, c.ev_done, 0) != hipSuccess) return nullptr; }
+    else if (hipStreamSynchronize(c.last_stream) != hipSuccess) return nullptr;   // (the accel's first call on a second stream: see release_ctx)
+  }
   if (c.ctl_dirty) {
     if (hipMemsetAsync(c.ctl, 0, CTL_DWORDS * sizeof(uint32_t), s) != hipSuccess) return nullptr;
     c.ctl_dirty = false;
@@ -2100,8 +2105,12 @@ static FrameCtx* acquire_ctx(vxrt_accel* a, hipStream_t s) {
   return &c;
 }
 
-static int release_ctx(FrameCtx* c, hipStream_t s) {
-  if (hipEventRecord(c->ev_done, s) != hipSuccess) return -1;
+// The completion event orders a context's next use on ANOTHER stream.  An accel that has only ever seen one stream (serial frames,
+// the vx_* sequence) does not pay for it -- an event record is a barrier packet on the stream, ~10 us between a frame's shading
+// launch and the next frame's traversal -- and the first call on a second stream waits for the first stream on the host instead.
+static int release_ctx(vxrt_accel* a, FrameCtx* c, hipStream_t s) {
+  c->done_recorded = a->multi_stream || a->n_ctx > 1;
+  if (c->done_recorded && hipEventRecord(c->ev_done, s) != hipSuccess) return -1;
   c->busy = true; c->last_stream = s;
   return 0;
 }
@@ -2461,7 +2470,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   if (!c) return -1;
   // from here on a failure releases the context the way a success does: its event is recorded behind whatever was enqueued, the
   // context is marked busy on this stream and its control block is cleared before the next use
-  auto fail = [&]() -> int { c->ctl_dirty = true; (void)release_ctx(c, s); return -1; };
+  auto fail = [&]() -> int { c->ctl_dirty = true; (void)release_ctx(a, c, s); return -1; };
   // hit-record buffer between the two passes (one per frame in flight)
   const uint64_t pixels = batch > 1 ? (uint64_t)n_tiles * 64u : (uint64_t)tiles_x * ((height + 7) / 8 + 1) * 64u;   // tile-major records of any row window of the frame
   if (c->hitbuf_pixels < pixels) {
@@ -2656,16 +2665,16 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   if (gi_fused) {
     // nothing follows: the pixels are written.  The control block stays as the launches left it; the context's next call clears it.
     if (hipGetLastError() != hipSuccess) return fail();
-    return release_ctx(c, s);
+    return release_ctx(a, c, s);
   }
   if (ao) {
     if (render_ao_tail(a, c, p, width, y0, y1, ao, A.utab, A.vtab, dst, colors, unoccluded, counters, s) != 0) return fail();
-    return release_ctx(c, s);
+    return release_ctx(a, c, s);
   }
   if (p.max_depth > 1 && a->max_reflectivity > 0.0f) {
     // reflective instances: the shading pass becomes the level-0 step of the mirror-bounce wavefront
     if (render_bounce_tail(a, c, p, width, y0, y1, shadow, A.utab, A.vtab, dst, (HitRec*)hits, colors, counters, s) != 0) return fail();
-    return release_ctx(c, s);
+    return release_ctx(a, c, s);
   }
   const uint64_t npx = (uint64_t)width * tiles_y * 8u * batch;
   const uint32_t lpt_blocks = lpt_sort ? QUEUE_SHARDS : 0u;
@@ -2678,7 +2687,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   if (hipGetLastError() != hipSuccess) return fail();
   if (lpt_sort) L.valid = true;
   c->ctl_dirty = false;
-  return release_ctx(c, s);
+  return release_ctx(a, c, s);
 }
 
 int vxrt_render(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
@@ -2770,7 +2779,7 @@ int vxrt_trace_stats(vxrt_accel_t* a, const float* rays, uint64_t n, const float
   FrameCtx* c = acquire_ctx(a, s);
   if (!c) return -1;
   if (trace_on_ctx(a, c, rays, n, tmax, (HitRec*)hits, mode, s, nullptr, counters) != 0) return -1;
-  return release_ctx(c, s);
+  return release_ctx(a, c, s);
 }
 
 int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax,
@@ -2783,7 +2792,7 @@ int vxrt_trace(vxrt_accel_t* a, const float* rays, uint64_t n, const float* tmax
   FrameCtx* c = acquire_ctx(a, s);
   if (!c) return -1;
   if (trace_on_ctx(a, c, rays, n, tmax, (HitRec*)hits, mode, s) != 0) return -1;
-  return release_ctx(c, s);
+  return release_ctx(a, c, s);
 }
 
 // Opt-in compatibility mode: the reference RTU's traversal restated literally, quirks included, on a flat memory image (see

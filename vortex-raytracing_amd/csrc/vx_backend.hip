@@ -24,6 +24,13 @@
 
 extern "C" uint32_t* vxrt_status_word_device(void);   // rt_kernels.hip
 
+// rays counter and status word of a run into host memory the device can write (see vx_device::enqueue_readback)
+__global__ void vx_readback_kernel(const unsigned long long* __restrict__ rays, const uint32_t* __restrict__ status, unsigned long long* __restrict__ host) {
+  host[0] = *rays;
+  host[1] = (unsigned long long)*status;
+  __threadfence_system();
+}
+
 namespace {
 
 constexpr uint64_t kUserBase = 0x10000;      // USER_BASE_ADDR (hw/VX_config.toml), runtime/simx/vortex.cpp:52
@@ -68,7 +75,9 @@ struct vx_device {
   std::unordered_map<uint32_t, uint32_t> dcrs;
   unsigned long long* d_rays = nullptr;
   unsigned long long last_rays = 0;
-  unsigned long long* h_back = nullptr;   // pinned: [0] rays, [1] status word of the run, copied back by the stream itself
+  unsigned long long* h_back = nullptr;   // pinned: [0] rays, [1] status word of the run, written by the stream's last kernel
+  static constexpr uint64_t kStageSlot = 4096; static constexpr uint32_t kStageSlots = 64;
+  char* stage = nullptr; uint32_t stage_next = 0;   // pinned staging ring of the small uploads
   // small buffers (kernel_arg_t, SBT, kernel selector images: re-allocated per run by the reference host, tracer.cpp:
   // 272-281) come from slabs of kSlotBytes slots instead of one hipMalloc/hipFree each
   std::vector<void*> slabs;
@@ -98,6 +107,7 @@ struct vx_device {
     if (hipEventCreate(&ev_begin) != hipSuccess || hipEventCreate(&ev_end) != hipSuccess) return -1;
     if (hipMalloc((void**)&d_rays, sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipHostMalloc((void**)&h_back, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return -1;
+    if (hipHostMalloc((void**)&stage, kStageSlot * kStageSlots, hipHostMallocDefault) != hipSuccess) return -1;
     h_back[0] = h_back[1] = 0;
     return 0;
   }
@@ -114,6 +124,7 @@ struct vx_device {
     if (q_rays) (void)hipFree(q_rays);
     if (q_hits) (void)hipFree(q_hits);
     if (h_back) (void)hipHostFree(h_back);
+    if (stage) (void)hipHostFree(stage);
     if (ev_begin) (void)hipEventDestroy(ev_begin);
     if (ev_end) (void)hipEventDestroy(ev_end);
     if (stream) (void)hipStreamDestroy(stream);
@@ -234,13 +245,14 @@ struct vx_device {
   }
 
   // rays counter and status word travel back in the stream, so joining a run costs no extra synchronous copy
+  // (a one-thread kernel that stores both words into the pinned, device-visible h_back: two 8-byte copies through the copy engine cost
+  // the frame more than the launch)
   int enqueue_readback() {
     uint32_t* st = vxrt_status_word_device();
     if (!st) return -1;
     h_back[1] = 0;
-    if (hipMemcpyAsync(&h_back[0], d_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
-    if (hipMemcpyAsync(&h_back[1], st, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
-    return 0;
+    hipLaunchKernelGGL(vx_readback_kernel, dim3(1), dim3(1), 0, stream, (const unsigned long long*)d_rays, (const uint32_t*)st, h_back);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
   }
 
   void finish_run() {
@@ -257,7 +269,18 @@ struct vx_device {
     wait_idle();
     (void)hipSetDevice(hip_dev);
     const uint64_t off = va - a->va;
-    if (size && hipMemcpy((char*)a->dptr + off, src, size, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (size && size <= kStageSlot && stage) {
+      // small uploads (the kernel arguments of every frame, tracer.cpp:262-288): copied into a pinned slot -- the caller's buffer is
+      // free again on return, as vx_copy_to_dev promises -- and sent by the stream the runs use, ahead of the next run, without a
+      // synchronous copy's round trip.  A slot is reused after kStageSlots further uploads; the stream is drained then.
+      if (stage_next == kStageSlots) { if (hipStreamSynchronize(stream) != hipSuccess) return -1; stage_next = 0; }
+      char* slot = stage + (size_t)stage_next++ * kStageSlot;
+      std::memcpy(slot, src, size);
+      if (hipMemcpyAsync((char*)a->dptr + off, slot, size, hipMemcpyHostToDevice, stream) != hipSuccess) return -1;
+    } else if (size) {
+      if (hipStreamSynchronize(stream) != hipSuccess) return -1;   // (behind any staged upload still in the stream)
+      if (hipMemcpy((char*)a->dptr + off, src, size, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    }
     if (!a->shadow.empty() && off + size <= a->shadow.size()) std::memcpy(a->shadow.data() + off, src, size);
     a->version++;
     return 0;
@@ -268,6 +291,7 @@ struct vx_device {
     if (!a) return -1;
     wait_idle();
     (void)hipSetDevice(hip_dev);
+    if (hipStreamSynchronize(stream) != hipSuccess) return -1;   // (behind any staged upload still in the stream)
     if (size && hipMemcpy(dst, (char*)a->dptr + (va - a->va), size, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return 0;
   }
