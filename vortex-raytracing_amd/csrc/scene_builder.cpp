@@ -43,9 +43,11 @@ inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline V3 normalize(V3 v) { float l = std::sqrt(dot(v, v)); return l > 0 ? v * (1.0f / l) : V3{0, 1, 0}; }
 
 constexpr float kBig = RT_LARGE_FLOAT;
-constexpr int kMaxBins = 32;
-static int kBins = 24;      // reference: 8 (bvh.cpp:8); 16 gives 6 % fewer node visits per ray on the atrium, 24 another 1.1 % and +1.3 % frame rate (32: the
-                            // same; an exact sweep of every split position below 16..1024 triangles: no further change). profiles/r03_j_builder_knobs.txt. VXS_BINS overrides
+constexpr int kMaxBins = 256;
+static int kBins = 128;     // reference: 8 (bvh.cpp:8).  Under the reinsertion passes the outcome scatters with the bin count by +-1.5 % of the frame rate without
+                            // a trend -- 12: 10.44, 16: 10.27, 24: 10.32, 32: 10.44, 40: 10.50, 48: 10.33, 64: 10.47, 96: 10.42, 128: 10.52-10.56, 256: 10.31-10.37
+                            // Grays/s (profiles/r03_v_bins_ab.txt; 100-step runs) -- the optimiser ends in a different local optimum each time; 128 is
+                            // the best measured.  (The greedy builder: 16 bins 6 % fewer node visits than 8, 24 another 1.1 %.)  VXS_BINS overrides
 static float kLeafK = 1.0f;  // keep <= kLeafMax triangles in one leaf when the best split saves less than kLeafK node-areas
                              // (reference: always split, i.e. 0; VXS_LEAF_K overrides): -9 % node visits, +15 % triangle tests
 static int kLeafMax = 4;
