@@ -59,7 +59,9 @@ static int kCollapse = 1;   // 1: build the binary SAH tree to the bottom, optim
                             // changes nothing (9 % fewer nodes, the same bytes per ray and frame rate); with the reinsertion passes +7.8 %
 static int kOptimize = 2;   // passes of insertion-based optimisation of the binary tree before the collapse (1 pass +6.9 %, 2 +7.8 %, 3 the same). VXS_OPTIMIZE
 static int kVerbose = 0;      // VXS_VERBOSE
-static int kOptimizeLocal = 0;   // 1: the workers optimise their subtrees (in parallel), one serial pass moves the nodes of the top: 4x faster, +6 %. VXS_OPTIMIZE_LOCAL
+static int kOptimizeLocal = -1;  // 1: the workers optimise their subtrees (in parallel), one serial pass moves the nodes of the top; 0: every node over the whole tree
+                                 // (serial); -1: the whole tree up to 2 M triangles, subtrees above.  1M-triangle atrium: 3.7 s and +6 % against 15 s and +7.8 %;
+                                 // 10M-triangle hairball: 11 s and 3.32 Grays/s (16-spp AO) against 135-155 s and 3.37.  VXS_OPTIMIZE_LOCAL
 static double kOptimizeFraction = 1.0;   // share of the nodes, largest first, a pass takes. VXS_OPTIMIZE_FRACTION
 constexpr float kNodeCost = 52.0f;   // bytes a node visit fetches: the unit of the collapse's cost
 static float kTriCost = 36.0f;       // ... and a triangle test.  VXS_TRI_COST (measured flat between 18 and 72: profiles/r03_v_tri_cost_ab.txt)
@@ -176,6 +178,7 @@ private:
     // the top serially; subtrees below `defer_below` triangles by worker threads into private arrays (disjoint triangle ranges: the
     // in-place partition needs no locks), appended in the order the serial pass met them: nothing depends on the thread count
     const uint32_t defer_below = std::max<uint32_t>(4096u, n_ / 256u);
+    const bool local = kOptimizeLocal < 0 ? n_ > 2000000u : kOptimizeLocal != 0;
     std::vector<uint32_t> deferred;
     build_binary(bn, 0, defer_below, &deferred);
     const uint32_t n_top = (uint32_t)bn.size();
@@ -193,7 +196,7 @@ private:
           sub[t].reserve(2 * (size_t)bn[deferred[t]].count + 1);
           sub[t].push_back(bn[deferred[t]]);
           build_binary(sub[t], 0, 0u, nullptr);
-          if (kOptimize > 0 && kOptimizeLocal) optimize_by_reinsertion(sub[t]);
+          if (kOptimize > 0 && local) optimize_by_reinsertion(sub[t]);
         }
       };
       const int nthreads = (int)std::min<size_t>((size_t)kThreads, deferred.size());
@@ -210,7 +213,7 @@ private:
         std::vector<BinNode>().swap(L);
       }
     }
-    if (kOptimize > 0) optimize_by_reinsertion(bn, kOptimizeLocal ? n_top : 0xffffffffu);
+    if (kOptimize > 0) optimize_by_reinsertion(bn, local ? n_top : 0xffffffffu);
     // the dynamic programme, children before parents
     std::vector<uint32_t> post;
     post.reserve(bn.size());
