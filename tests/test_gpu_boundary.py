@@ -156,6 +156,31 @@ def test_runs_do_not_rebuild_or_reallocate(vrt, gpu_device):
     tr.close()
 
 
+def test_kernel_arguments_through_the_staging_ring_stay_in_order(vrt, po, gpu_device):
+    """vx_upload_bytes of the 216-byte kernel_arg_t goes through a pinned ring of 64 slots on the run's stream (no synchronous copy):
+    200 runs alternating between two argument blocks -- past several wraps of the ring -- each render the frame of THEIR block."""
+    sc = vrt.scene.procedural("blob", 3, 0, 1)
+    w, h = 96, 64
+    tr = vrt.tracer.Tracer(w, h)
+    tr.init(sc)
+    lights = ((300.0, 480.0, 60.0), (100.0, 300.0, 50.0))
+    want, args = [], []
+    for lp in lights:
+        tr.setup(light_pos=lp)
+        args.append(tr.kernel_arg)
+        want.append(tr.run().copy())
+        rpx, _, _ = po.render(sc, w, h, po.shade_params(light_pos=lp))
+        assert np.array_equal(want[-1], rpx)
+    assert not np.array_equal(want[0], want[1])
+    mallocs = tr.dev.hip_stat(1)
+    for i in range(200):
+        k = (i * 7 + i // 3) & 1
+        tr.kernel_arg = args[k]
+        assert np.array_equal(tr.run(), want[k]), i
+    assert tr.dev.hip_stat(1) == mallocs
+    tr.close()
+
+
 def test_reference_quirks_dcr_renders_what_the_rtu_would_on_this_address_space(vrt, po, gpu_device):
     """DCR 0x7F4 = 1 through the vx_* boundary: the frame is traced by the literal restatement of the reference RTU (stale base_ptr
     of rt_traversal.cpp:91-92 included) on a flat image of the device's address space, with the RTX DCR values as base pointers.

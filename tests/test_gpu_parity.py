@@ -380,6 +380,32 @@ def test_frames_in_flight_do_not_change_results(vrt, po, gpu_device):
     np.testing.assert_array_equal(again, serial[0])
 
 
+def test_one_context_moving_between_streams_keeps_the_frames_ordered(vrt, po, gpu_device):
+    """An accel with one frame context that has only seen one stream records no completion event per frame; its first frame on ANOTHER
+    stream must still wait for the frames before it (the context's hit buffer and control block are shared), and from then on the
+    event orders them: frames alternating between three streams, never synchronised in between, equal the serial ones."""
+    import torch
+    sc = vrt.scene.procedural("blob", 4, 0, 1)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    w, h = 320, 200
+    plist = []
+    for lp in ((40.0, 60.0, 20.0), (-30.0, 50.0, 10.0), (5.0, 80.0, -40.0)):
+        p = vrt.rtapi.default_shade_params()
+        p.light_pos[:] = lp
+        plist.append(p)
+    serial = [gpu_render(vrt, ds, w, h, shadow=1, params=p)[0] for p in plist]      # (the default stream: the accel's first)
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(3)]
+    outs = [torch.zeros((h, w), dtype=torch.int32, device=gpu_device) for _ in range(24)]
+    torch.cuda.synchronize()
+    for i, buf in enumerate(outs):
+        vrt.rtapi.render(ds.accel, w, h, 0, h, plist[i % 3], buf.data_ptr(), 1, None, None, None, streams[(i * 5 + i // 4) % 3].cuda_stream)
+    torch.cuda.synchronize()
+    assert vrt.rtapi.status(streams[0].cuda_stream) == 0
+    for i, buf in enumerate(outs):
+        np.testing.assert_array_equal(buf.cpu().numpy().view(np.uint32), serial[i % 3])
+    ds.close()
+
+
 def test_inverted_child_boxes_take_the_generic_slab_form(vrt, po, golden, gpu_device):
     """The fast slab test picks the near/far plane by the sign of 1/d, which presumes q_lo <= q_hi; a
     tree with inverted child boxes (legal bytes for the reference, which just evaluates min/max) must
