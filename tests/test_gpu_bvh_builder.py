@@ -203,3 +203,24 @@ def test_multi_instance_scene_built_on_the_gpu(vrt, po, gpu_device, n_inst):
     assert np.array_equal(c["dist"] < 1e29, hit)
     np.testing.assert_allclose(got["dist"], c["dist"], rtol=2e-5)
     ds.close()
+
+
+@pytest.mark.parametrize("name", ["teapot", "torus", "cone"])
+def test_gpu_tree_quality_anchored_to_the_reference_builder(vrt, po, golden, gpu_device, name):
+    """The committed fixtures hold the tree the REFERENCE's builder made of its own assets.  On the same triangles and the fixture's
+    rays the tree vxrt_bvh_build makes (Morton order, PLOC, SAH-optimal collapse) must not cost more algorithmic bytes per ray (52 B
+    per node fetch, 36 B per triangle test) than the reference's, and must find the same distances; the host builder's
+    tree is the yardstick printed beside it (tests/tree_quality.py --gpu does this at the benchmark's scale: profiles/r03_v_tree_quality.txt)."""
+    g = golden(name)
+    tri = g["tri"].view(np.float32).reshape(-1, 9)
+    ds = vrt.tracer.DeviceScene.build_on_gpu(tri, None, None, None, gpu_device)
+    gpu = ds.to_host()
+    cpu = vrt.scene.from_triangles([tri])
+    a, sa = po.trace_canonical(g, g["rays"])
+    b, sb = po.trace_canonical(gpu, g["rays"])
+    c, sc_ = po.trace_canonical(cpu, g["rays"])
+    assert (a["dist"] == b["dist"]).mean() > 0.999      # (a re-quantised box chain can drop a grazing hit in either tree: DESIGN.md s3)
+    cost = lambda s: 52 * s["node_reads"] + 36 * s["tri_reads"]
+    print("%s: bytes per ray -- reference tree %d, GPU-built %d, host builder %d" % (name, cost(sa) // len(a), cost(sb) // len(b), cost(sc_) // len(c)))
+    assert cost(sb) <= 1.02 * cost(sa)
+    ds.close()
