@@ -397,3 +397,36 @@ def test_tree_quality_anchored_to_the_reference_builder(vrt, po, golden, name):
         name, sa["node_reads"] / len(a), sa["tri_reads"] / len(a), ref_bytes // len(a), sb["node_reads"] / len(b), sb["tri_reads"] / len(b), our_bytes // len(b)))
     assert our_bytes <= 1.02 * ref_bytes
     assert sb["node_reads"] < sa["node_reads"]
+
+
+def test_builder_on_small_and_degenerate_meshes(vrt, po):
+    """Meshes of 1..257 random triangles, 300 coincident ones (no split separates them), a flat axis-aligned sheet, six triangles with
+    one centroid: the tree keeps the invariants and every ray finds the brute-force distance (the binary tree + reinsertion + collapse
+    path has to cope with leaves that cannot be split and with subtrees of two or three nodes)."""
+    rng = np.random.default_rng(7)
+
+    def soup(n, spread=100.0, size=10.0):
+        c = rng.uniform(-spread, spread, size=(n, 1, 3)).astype(np.float32) + np.array([200, 100, 0], np.float32)
+        return (c + rng.uniform(-size, size, size=(n, 3, 3)).astype(np.float32)).reshape(n, 9)
+
+    cases = [("soup%d" % n, soup(n)) for n in (1, 2, 3, 4, 5, 7, 9, 17, 64, 257)]
+    cases.append(("coincident", np.tile(soup(3), (100, 1))))
+    g = np.linspace(-50, 50, 11, dtype=np.float32)
+    sheet = []
+    for i in range(10):
+        for j in range(10):
+            a, b, c, d = ([g[j] + 200, 100, g[i]], [g[j + 1] + 200, 100, g[i]], [g[j] + 200, 100, g[i + 1]], [g[j + 1] + 200, 100, g[i + 1]])
+            sheet += [a + b + c, b + d + c]
+    cases.append(("flat sheet", np.array(sheet, np.float32)))
+    cases.append(("one centroid", np.tile(np.array([[190, 90, -10, 210, 90, -10, 200, 120, 10]], np.float32), (6, 1))))
+    rays = po.camera_rays(24, 18)
+    rays = rays[(rays[:, 3:] != 0).all(1)]
+    hits = 0
+    for name, tri in cases:
+        sc = vrt.scene.from_triangles([tri])
+        d = check_tree(sc)
+        assert d == sc.info["max_depth"] < 32 and check_tree_fast(sc) == d, name
+        h, _ = po.trace_canonical(sc, rays)
+        assert np.array_equal(h["dist"], brute_force(sc, rays, po)), name
+        hits += int((h["dist"] < 1e29).sum())
+    assert hits > 20
