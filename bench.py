@@ -14,13 +14,19 @@ How the K timed steps are issued (all of it inside the timed region, every ray o
     20-step run would otherwise time the clock ramp: DESIGN.md s10).
 
 Multi-GPU (one process per GPU, torch.distributed over RCCL): ONE frame is split by 8-row tile rows of the reference grid
-(kernel.cpp:128-133) -- rank r renders the tile rows r, r + N, r + 2N, ... (interleaving balances the ranks, the cost of a tile
-varies 4x over the frame) with no data-path collective; frames are traced in batches of up to 32 per set of launches
-(vxrt_render_interleaved_batch: a rank's share of one frame is too small to fill its GPU) and ONE gather over xGMI per batch
+(kernel.cpp:128-133) -- rank r renders the tile rows r, r + N, r + 2N, ... (interleaving balances the ranks by construction: the
+cost of a tile varies 4x over the frame) with no data-path collective; frames are traced in sets of up to 16 per set of launches
+(vxrt_render_interleaved_batch: a rank's share of one frame is too small to fill its GPU) and ONE gather over xGMI per set
 assembles the images on rank 0 on its own stream (north_star: "RCCL gather only for final image assembly").  STRONG scaling:
-the frame, and so the total work, is fixed as N grows; value = rays of the whole frame x K / max-over-ranks time.  `--shard rows`
-uses contiguous bands, one frame per set of launches.  `--rehearse-world N` does on ONE GPU what rank 0 of N would do per frame,
-without the collective (diagnostic).
+the frame, and so the total work, is fixed as N grows; value = rays of the whole frame x K / max-over-ranks time.
+`--shard bands` (built and measured in round 4, not the default): N contiguous bands cut on tile boundaries where the measured
+COST is equal (planned from the ranks' own frame times during the untimed settle phase, sharding.rebalance_bands), rank 0
+rendering its band in place in the final images and receiving every other band straight into its place -- one group of
+ncclSend / ncclRecv per set, no extraction or interleaving copy -- with the sets of the timed steps tapering (20 -> 10, 5, 2, 2, 1).
+It loses on both counts: a band of the expensive part of the frame is 11 tile rows high at N = 8, so the cut cannot
+be placed finer than 9 % of a rank's work, and a set of one or two frames' shares is a single round of tiles that takes as long
+as ten.  `--shard rows` = equal-height bands, one frame per set of launches.  `--rehearse-world N` does on ONE GPU what rank 0 of
+N would do, without the collective (diagnostic).
 
 Prints one JSON line (driver contract) with `roofline` and `cpu_baseline` objects.  The roofline is the VALU roof: this
 traversal is cache-resident pointer chasing whose binding resource is vector-ALU issue, priced with the
@@ -51,8 +57,10 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--level", type=int, default=8, help="atrium tessellation level; 8 -> 1,048,576 triangles")
-    ap.add_argument("--shard", choices=["tilerows", "rows"], default="tilerows",
-                    help="how ONE frame is split over the GPUs: interleaved 8-row tile rows (default) or contiguous row bands")
+    ap.add_argument("--shard", choices=["tilerows", "bands", "rows"], default="tilerows",
+                    help="how ONE frame is split over the GPUs: interleaved 8-row tile rows, one gather + one interleaving copy per set (default); contiguous bands cut at equal measured cost, received in place (measured slower: DESIGN.md s6); equal-height bands, one frame per launch")
+    ap.add_argument("--taper", default="auto",
+                    help="--shard bands: sizes of the sets the timed steps are issued in, e.g. 10,5,3,2 (sum = --steps); auto = sharding.taper(steps); none = equal sets as --batch decides")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per set of launches, and per collective with several GPUs (0 = automatic: up to 5 on one GPU, up to 16 with several, the timed steps split into equal groups; 1 = one frame per set of launches)")
     ap.add_argument("--rehearse-world", type=int, default=0,
@@ -242,15 +250,68 @@ def load_profile_constants():
     return None
 
 
+def kernel_source_id():
+    """16 hex digits that change when the code of the timed kernels changes: sha256 over the product's HIP sources and the headers
+    they include, comments and white space removed, + the compiler flags.  (The sources, not the built library: the .so is rebuilt
+    wherever the tree is checked out, the sources are what is committed.)"""
+    import hashlib
+    import re
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "vortex-raytracing_amd", "csrc")
+    for f in ("rt_kernels.hip", "rt_types.h", os.path.join("..", "..", "include", "vortex_hip.h")):
+        try:
+            t = open(os.path.join(base, f)).read()
+        except OSError:
+            return None
+        t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+        t = re.sub(r"//[^\n]*", " ", t)
+        h.update(re.sub(r"\s+", " ", t).encode())
+    try:
+        bld = importlib.import_module("vortex-raytracing_amd.build")
+        h.update(" ".join(bld.HIP_FLAGS).encode())
+    except Exception:
+        return None
+    return h.hexdigest()[:16]
+
+
+def tree_id(scene):
+    """16 hex digits of the tree the frame is traced through: sha256 over the reference-format TLAS, instance, BVH and triangle
+    buffers (the compact layout the kernels read is a deterministic function of them)."""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    for k in ("tlas", "blas", "bvh", "tri"):
+        h.update(np.ascontiguousarray(scene[k]).view(np.uint8).tobytes())
+    return h.hexdigest()[:16]
+
+
+def profile_mismatch(prof, ident):
+    """Why the checked-in per-frame counters (profiles/valu_profile.json) do NOT describe this run, or None if they do: the file
+    carries the identity of the run it was taken from -- frame size, tree hash and node count, kernel source id, and the traversal
+    counts the counting build reported there -- and every one of them must equal this run's."""
+    want = prof.get("identity")
+    if not want:
+        return "profiles/valu_profile.json carries no identity block (written by an older tools/roofline_from_pmc.py)"
+    for k in ("width", "height", "shadow", "bvh_nodes", "tree_sha16", "kernel_source_sha16", "node_fetches_timed", "tri_fetches_timed", "rays"):
+        if want.get(k) != ident.get(k):
+            return "profiles/valu_profile.json was taken on another %s (%r there, %r here): re-run tools/round_profile.sh" % (k, want.get(k), ident.get(k))
+    return None
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, as fresh child processes (one per
     GPU, `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`), BEFORE anything in this process touches
-    HIP (device_count does not initialise the GPU on this image), relay rank 0's JSON line and exit with the children's code.
+    HIP (the device count itself is taken in a child process), relay rank 0's JSON line and exit with the children's code.
     Never exec: the parent stays a plain process.  Fewer than N visible devices is an error, not an N=1 run."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
+    # the device count comes from a child process: nothing in THIS process may open the HIP runtime before the ranks are started
+    # (torch.cuda.device_count() can fall through to hipGetDeviceCount on builds without amdsmi)
+    try:
+        have = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                  text=True, timeout=300).stdout.strip().splitlines()[-1])
+    except Exception:
+        have = 0
     if a.dist_backend == "nccl" and have < a.gpus:
         sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to report an N=%d run as N=%d\n" % (a.gpus, have, have, a.gpus))
         return 3
@@ -350,12 +411,29 @@ def main():
         streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
     # (with several ranks a framebuffer stays busy until its gather has run: twice as many, so that rendering never waits for the link)
     n_frames = max(2, nfl) * (2 if multi else 1)
-    ig = None
-    # Several ranks: a rank's share of one frame is small against its GPU (4,080 tiles for 6,096 resident wavefronts at 1080p / 8)
-    # and takes as long as its slowest tile -- about half a full frame's time, whatever N.  The steps are therefore issued in batches
-    # of B frames per set of launches (vxrt_render_interleaved_batch) and assembled with one collective per batch.
+    ig = bg = None
+    bands = multi and a.shard == "bands"
+    band_plan = None
+    # Several ranks: a rank's share of one frame is small against its GPU (4,080 tiles for 8,192 resident wavefronts at 1080p / 8)
+    # and takes as long as its slowest tile -- about half a full frame's time, whatever N.  The steps are therefore issued in sets
+    # of B frames per set of launches and assembled with one collective per set.
     B = 1
-    if multi and a.shard == "tilerows":
+    set_sizes = None            # bands: sizes of the timed region's sets
+    if bands:
+        B = max(1, min(32, a.batch if a.batch > 0 else 16))
+        if a.taper == "auto" and a.batch <= 0:
+            set_sizes = sharding.taper(a.steps, B, 1, 0.5)
+        elif a.taper not in ("auto", "none"):
+            set_sizes = [int(x) for x in a.taper.split(",")]
+            if sum(set_sizes) != a.steps or min(set_sizes) < 1 or max(set_sizes) > 32:
+                raise SystemExit("bench.py: --taper must list set sizes of 1..32 frames that add up to --steps")
+        else:
+            n_groups = max(nfl, -(-a.steps // B))
+            per = -(-a.steps // n_groups)
+            set_sizes = [min(per, a.steps - g) for g in range(0, a.steps, per)]
+        B = max(set_sizes)
+        frames = None           # allocated once the band plan is known (below)
+    elif multi and a.shard == "tilerows":
         # default: as large as a batch may be (16), but the K timed steps split into equal groups, at least one per stream
         # (K = 20 -> 2 groups of 10, not 16 + 4)
         n_groups = max(nfl, -(-a.steps // 16))
@@ -375,9 +453,64 @@ def main():
     counters = torch.zeros(8, dtype=torch.int64, device=dev)
     frame_stride = ig.frame_stride if ig is not None else H * W
 
-    def launch(buf, count_ptr=None, st=None, k=1):
+    if bands:
+        # ---- the band plan: cut the rows where the COST is equal.  Every rank times sets of frames of its own band (GPU events, nothing
+        # else running), the times are all-gathered, every rank computes the same new cut from them (sharding.rebalance_bands); a
+        # few rounds, the plan with the smallest slowest-rank time is kept.  All of it before the warmup steps, none of it timed.
+        # (The rehearsal on one GPU times every rank's band in turn instead of gathering.)
+        bounds = sharding.equal_bands(H, world)
+        cal_k = 4
+        cal = torch.zeros((cal_k, H, W), dtype=torch.int32, device=dev)
+
+        def band_ms(r, bnds, reps=3):
+            b0, b1 = bnds[r], bnds[r + 1]
+            best = None
+            for i in range(reps + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                rtapi.render_rows_batch(ds.accel, W, H, b0, b1, [params] * cal_k, cal.data_ptr(), H * W, shadow, None, sptr)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                if i:                                   # (the first call of a new window builds its tables)
+                    t = e0.elapsed_time(e1) / cal_k
+                    best = t if best is None else min(best, t)
+            return best
+
+        history = []
+        for it in range(5 if world > 1 else 0):
+            if rehearse:
+                times = [band_ms(r, bounds) for r in range(world)]
+            else:
+                mine = torch.tensor([band_ms(rank, bounds)], dtype=torch.float64, device=cdev)
+                allt = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allt, mine)
+                times = [float(t.item()) for t in allt]
+            history.append((max(times), list(bounds), [round(t, 4) for t in times]))
+            nb = sharding.rebalance_bands(bounds, times, H, damping=1.0 if it < 2 else 0.5)
+            if nb == bounds or any(nb == h[1] for h in history):
+                break
+            bounds = nb
+        if history:
+            best = min(history, key=lambda h: h[0])
+            bounds = best[1]
+            band_plan = {"bounds": bounds, "ms_per_frame_by_rank_when_planned": best[2], "rounds": len(history),
+                         "imbalance_max_over_mean": round(best[0] / (sum(best[2]) / len(best[2])), 4)}
+        del cal
+        y0, y1 = bounds[rank], bounds[rank + 1]
+        n_slots = min(len(set_sizes) + 2, 4)
+        slot_sizes = [B] * n_slots
+        bg = sharding.BandGather(H, W, rank, world, bounds, dev, slot_sizes, collective=not rehearse, via_cpu=(cdev == "cpu"))
+        frames = bg.bufs
+
+    def launch(buf, count_ptr=None, st=None, k=1, slot=0):
         sp = (st or stream).cuda_stream
-        if B > 1 and k > 0 and count_ptr is None and st is not None:
+        if bands:
+            dst, fstride = bg.target(slot)
+            if count_ptr is None:
+                rtapi.render_rows_batch(ds.accel, W, H, y0, y1, [params] * k, dst, fstride, shadow, None, sp)
+            else:
+                rtapi.render(ds.accel, W, H, y0, y1, params, dst, shadow, None, None, count_ptr, sp)
+        elif B > 1 and k > 0 and count_ptr is None and st is not None:
             if not multi:
                 rtapi.render_batch(ds.accel, W, H, [params] * k, buf.data_ptr(), frame_stride, shadow, None, sp)
             else:
@@ -396,6 +529,12 @@ def main():
     if world == 1:
         algo = rtapi.render_stats(ds.accel, W, H, 0, H, params, frames[0].data_ptr(), shadow, sptr)                  # reference-order counts
         algo_timed = rtapi.render_stats(ds.accel, W, H, 0, H, params, frames[0].data_ptr(), shadow, sptr, timed=True)  # the traversal that is timed
+    elif rank == 0:
+        # several ranks: rank 0 counts the WHOLE frame once (into a scratch frame), so that the N-rank line can say which tree and
+        # which traversal its roofline numerator belongs to; the timed region traces the ranks' bands only
+        scratch = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        algo_timed = rtapi.render_stats(ds.accel, W, H, 0, H, params, scratch.data_ptr(), shadow, sptr, timed=True)
+        del scratch
 
     rtapi.accel_frames_in_flight(ds.accel, nfl)
     gather_stream = torch.cuda.Stream(device=dev) if multi else None
@@ -404,7 +543,7 @@ def main():
     no_gather = bool(rehearse and os.environ.get("VXRT_BENCH_NO_GATHER"))   # (diagnostic: the share's launches alone)
 
     def step(i, ev=None, k=1):
-        """Issues launch group i: k steps (k = 1 except with several ranks, where a group is a batch of up to B frames)."""
+        """Issues launch group i: k steps (k = 1 except with several ranks, where a group is a set of up to B frames)."""
         b = i % len(frames)
         buf = frames[b]
         st = streams[i % nfl]
@@ -412,14 +551,16 @@ def main():
             st.wait_event(gdone[b])            # do not overwrite a frame that is still being gathered
         if ev is not None:
             ev[0].record(st)
-        launch(buf, st=st, k=k)
+        launch(buf, st=st, k=k, slot=b)
         if ev is not None:
             ev[1].record(st)
         if multi and not no_gather:
             # image assembly overlaps the next step's traversal: the gather runs on its own stream
             gather_stream.wait_stream(st)
             with torch.cuda.stream(gather_stream):
-                if a.shard == "tilerows":
+                if bands:
+                    bg.gather(b, k)
+                elif a.shard == "tilerows":
                     ig.gather(buf, b, via_cpu=(cdev == "cpu"))
                 else:
                     band = buf[y0:y1]
@@ -439,17 +580,33 @@ def main():
     iso_ms = sum(iso) / len(iso)
     def groups(n):     # n steps as launch groups of at most B
         return [min(B, n - g) for g in range(0, n, B)]
-    timed_groups = groups(a.steps)
+    timed_groups = list(set_sizes) if bands else groups(a.steps)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in timed_groups]
     # The GPU raises its clocks over the first tens of milliseconds of sustained load (measured: the frame period of a 20-step
     # run shrinks from 0.52 to 0.49 ms between its first and last step).  A short run would time that ramp, not the path, so the
     # clocks are brought to their sustained state first with untimed frames of the same kind; then the W warmup steps, which run as
     # the timed ones do (same streams, same frames in flight) and directly before them.
-    for i, k in enumerate(groups(a.settle_frames) + groups(a.warmup)):
-        step(i, k=k)
+    settled = a.settle_frames
+    if bands:
+        # the settle phase repeats the timed region's own sequence of sets on the same streams and buffers (a frame context learns
+        # its longest-tile-first order per set size from its previous set of that size), then the W warmup steps as a prefix of it
+        settled = 0
+        while settled < a.settle_frames:
+            for j, k in enumerate(timed_groups):
+                step(j, k=k)
+            settled += sum(timed_groups)
+        left = a.warmup
+        for j, k in enumerate(timed_groups):
+            if left <= 0:
+                break
+            step(j, k=min(k, left))
+            left -= min(k, left)
+    else:
+        for i, k in enumerate(groups(a.settle_frames) + groups(a.warmup)):
+            step(i, k=k)
     # every frame rendered before the timed region opens (one for the ray count, two counting builds, the isolated launches,
-    # the clock-settling frames, the W warmup steps): none of them is timed, none of their results is reused
-    frames_before = 1 + (2 if world == 1 else 0) + len(iso) + a.settle_frames + a.warmup
+    # the band-planning sets, the clock-settling frames, the W warmup steps): none of them is timed, none of their results is reused
+    frames_before = 1 + (2 if world == 1 else (1 if rank == 0 else 0)) + len(iso) + settled + a.warmup + (band_plan["rounds"] * 16 * (world if rehearse else 1) if band_plan else 0)
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
@@ -540,12 +697,17 @@ def main():
                                      "bytes_per_ray": round(rstats["bytes_per_ray"], 1), "algorithmic_GBs": round(gbs, 1),
                                      "frac_of_hbm_peak": round(gbs / (HBM_PEAK_GBS * world), 4), "frac_of_l2_peak": round(gbs / (L2_PEAK_GBS * world), 4),
                                      "node_fetches_per_ray": round(rstats["node_fetches"] / n, 2),
-                                     "tri_fetches_per_ray": round(rstats["tri_fetches"] / n, 2)}
+                                     "tri_fetches_per_ray": round(rstats["tri_fetches"] / n, 2),
+                                     "node_fetches": rstats["node_fetches"], "tri_fetches": rstats["tri_fetches"]}
         del rays, hits
 
     if rank == 0:
         if not multi:
             par = "1 GPU: whole frames, %d per set of launches (vxrt_render_batch), %d sets in flight" % (B, nfl) if B > 1 else "1 GPU: whole frame"
+        elif bands:
+            par = ("one frame split into %d contiguous bands of rows cut at equal measured cost on 8-row tile boundaries (rank r: rows bounds[r]..bounds[r+1]), "
+                   "frames traced in sets of %s per set of launches, each band received in place on rank 0: one group of RCCL send/recv (a gather with per-rank sizes) per set"
+                   % (world, "/".join(str(k) for k in timed_groups)))
         elif a.shard == "tilerows":
             par = "one frame split by interleaved 8-row tile rows (rank r: rows r, r+%d, ... of %d tile rows) x%d GPUs, %d frames per set of launches, one RCCL gather of the shares to rank 0 per set" % (world, (H + 7) // 8, world, B)
         else:
@@ -562,10 +724,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic (procedural 'Sponza-class' atrium, seed 3; no Sponza/bunny asset exists offline)",
             "config": {"workload": "configs[2]: Sponza-class %d tris, %dx%d, primary + 1 shadow ray per hit%s" % (scene.n_tris, W, H, "" if shadow else " (shadow disabled)"),
-                       "rays_per_step": rays_all, "rays_per_step_rank0": rays_rank, "frames_in_flight": nfl, "frames_per_launch_group": B, "clock_settle_frames_untimed": a.settle_frames, "frames_rendered_before_the_timed_region": frames_before, "parallelism": par,
+                       "rays_per_step": rays_all, "rays_per_step_rank0": rays_rank, "frames_in_flight": nfl, "frames_per_launch_group": B, "clock_settle_frames_untimed": settled, "frames_rendered_before_the_timed_region": frames_before, "parallelism": par,
                        "world_size": dist_world, "rank_devices": rank_devices, "dist_backend": (a.dist_backend if grouped else None),
                        "bvh_nodes": scene.n_bvh_nodes, "bvh_depth": scene.info.get("max_depth")},
         }
+        if bands:
+            out["config"].update({"shard": "bands", "sets_of_the_timed_steps": timed_groups, "band_plan": band_plan, "rows_rank0": [y0, y1]})
+        elif multi:
+            out["config"]["shard"] = a.shard
         prof = load_profile_constants()
         # one step = the launches of vxrt_render: persistent traversal kernel (dominant, > 93 % of the step), the EXACT launches
         # for the rays with NaN-capable slabs, and the shading pass; priced together
@@ -590,7 +756,30 @@ def main():
                 "why_valu": "the scene is cache-resident (measured HBM traffic = a few % of the HBM peak) and relieving the memory path measured neutral (LDS-staged "
                             "top of the tree: 39 % of node steps from LDS, -17 % vector-memory instructions, +0 %: profiles/r02_b_lds_top_counters.txt); what moves the time "
                             "is the number of VALU instructions"}
-        if prof and world == 1 and W == 1920 and H == 1080 and a.level == 8 and shadow:
+        # what the per-frame profile constants must have been taken on to be usable here (and what a new profile pass records)
+        ident = {"width": W, "height": H, "shadow": int(shadow), "bvh_nodes": scene.n_bvh_nodes, "tree_sha16": tree_id(scene),
+                 "kernel_source_sha16": kernel_source_id(),
+                 "node_fetches_timed": algo_timed["node_fetches"] if algo_timed else None,
+                 "tri_fetches_timed": algo_timed["tri_fetches"] if algo_timed else None,
+                 "rays": algo_timed["rays"] if algo_timed else None}
+        roof["identity"] = ident
+        why_not = None
+        if not prof:
+            why_not = "profiles/valu_profile.json not found"
+        else:
+            why_not = profile_mismatch(prof, ident)
+        if why_not:
+            roof["frac_is_null_because"] = why_not
+        if prof and world > 1 and not why_not and not rehearse:
+            # N ranks: the frame's instructions are a property of the frame, whoever traces which band: the whole job's rate against
+            # N x the per-GPU roof (clock: rank 0's probe)
+            n_valu = prof["valu_instr_per_frame"]
+            ach = n_valu / (elapsed / a.steps) / 1e9
+            roof.update({"achieved": round(ach, 1), "peak": round(world * SIMDS * clock / 2.0, 1), "frac": round(ach / (world * SIMDS * clock / 2.0), 4),
+                         "peak_is": "%d GPUs x 1024 SIMDs x clock held on rank 0 / 2 cycles per wave64 VALU instruction" % world,
+                         "achieved_is": "wave64 VALU instructions of one whole frame (profile constant) x steps / max-over-ranks wall time of the timed region",
+                         "valu_instr_per_frame": n_valu, "valu_source": prof.get("source")})
+        if prof and world == 1 and not why_not:
             # profile constants of THIS workload (instruction counts per frame are a property of the frame and the code), source named in the file
             n_valu = prof["valu_instr_per_frame"]
             ach = n_valu / (kern_ms * 1e-3) / 1e9
@@ -626,6 +815,30 @@ def main():
             roof["counts_reference_order"] = algo
             roof["counts_timed_traversal"] = algo_timed
         out["roofline"] = roof
+        rr = extras.get("random_rays")
+        if rr:
+            # north_star's second figure with its own roofline block: N random rays per GPU against the fixed BVH, as absolute, against
+            # the VALU issue roof (numerator: SQ_INSTS_VALU of the ray-buffer kernel's launch, a profile constant tied to this tree, this
+            # kernel source and these rays by the fetch counts the counting build reports) and, as north_star words it, the SURVEY s8d
+            # bytes against the HBM roofline
+            blk = {"bound": "valu", "kernel": "rt_persistent_kernel<JOB_TRACE> (+ its EXACT launch)", "rays_per_gpu": rr["rays_per_gpu"], "n_gpus": world,
+                   "mrays_s": rr["mrays_s"], "ms_per_launch": rr["ms_per_launch"], "achieved": None, "peak": round(world * SIMDS * clock / 2.0, 1),
+                   "unit": "G wave64 VALU instructions/s", "frac": None,
+                   "bytes": {"bytes_per_ray": rr["bytes_per_ray"], "algorithmic_GBs": rr["algorithmic_GBs"], "hbm_peak_GBs": HBM_PEAK_GBS * world,
+                             "frac_of_hbm_peak": rr["frac_of_hbm_peak"], "frac_of_l2_peak": rr["frac_of_l2_peak"]}}
+            pr = prof.get("random_rays") if prof else None
+            why_rr = why_not
+            if not why_rr and not pr:
+                why_rr = "profiles/valu_profile.json holds no counter pass of the ray-buffer kernel"
+            if not why_rr and (pr.get("n") != rr["rays_per_gpu"] or pr.get("node_fetches") != rr["node_fetches"] or pr.get("tri_fetches") != rr["tri_fetches"]):
+                why_rr = "the profiled ray buffer differs from this run's (rays or fetch counts)"
+            if why_rr:
+                blk["frac_is_null_because"] = why_rr
+            else:
+                ach = pr["valu_instr_per_launch"] * world / (rr["ms_per_launch"] * 1e-3) / 1e9
+                blk.update({"achieved": round(ach, 1), "frac": round(ach / (world * SIMDS * clock / 2.0), 4), "valu_instr_per_launch": pr["valu_instr_per_launch"],
+                            "valu_source": pr.get("source")})
+            out["roofline_random_rays"] = blk
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, vrt, W, H, LIGHT, a.cpu_seconds, random_sample)
         if extras:

@@ -268,6 +268,22 @@ int vxrt_render_interleaved_batch(vxrt_accel_t* accel, uint32_t width, uint32_t 
                                   const vxrt_shade_params_t* params, int shadow, uint32_t* dst, uint64_t dst_frame_stride,
                                   unsigned long long* rays_traced, void* stream);
 
+/* diagnostic: the traversal launch of vxrt_render_interleaved_batch in the counting build with vxrt_render_wave_log's per-wavefront
+ * log ([15] = 100 MHz clock at which the wavefront found every queue shard empty); pixels are not produced.  tools/wave_balance_batch.py */
+int vxrt_render_interleaved_batch_wave_log(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t phase, uint32_t stride, uint32_t n_frames,
+                                           const vxrt_shade_params_t* params, int shadow, uint32_t* dst, uint64_t dst_frame_stride,
+                                           unsigned long long* counters, unsigned long long* wave_log, void* stream);
+
+/* The same for a contiguous band of rows [y0, y1) (0 <= y0 <= y1 <= height; any row, tiles are counted from y0): what a rank
+ * renders when the frame is split into bands whose heights are balanced by cost (bench.py --shard bands).  dst addresses every
+ * frame as a FULL frame does -- pixel (x, y) of frame f at dst[f * dst_frame_stride + x + y * width] -- and only rows [y0, y1)
+ * are written, so a caller that keeps only its band passes (band buffer - y0 * width) and dst_frame_stride = (y1 - y0) * width:
+ * the band then lies contiguous in memory, ready to be sent, and rank 0 receives every band straight into its place in the
+ * final image (no extraction and no interleaving copy: the grid being sharded is kernel.cpp:128-133). */
+int vxrt_render_rows_batch(vxrt_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, uint32_t n_frames,
+                           const vxrt_shade_params_t* params, int shadow, uint32_t* dst, uint64_t dst_frame_stride,
+                           unsigned long long* rays_traced, void* stream);
+
 /* The same for whole frames (one rank): n_frames frames of width x height, frame f lit and shaded with params[f], written to
  * dst + f * dst_frame_stride.  Every wavefront then works through n_frames times as many tiles per launch, so a launch's ramp and
  * tail weigh less: +8 % at 1920x1080 with 5 frames per set of launches. */
@@ -398,6 +414,10 @@ int vxrt_trace_reference_quirks(const void* image, uint64_t image_size, uint32_t
  * [288 + 32 k] of the EXACT launch over the deferred list, [544 + 32 k] of the a-priori EXACT launch.  A vxrt_trace call leaves the
  * block as its launches left it (the next call clears it). */
 int vxrt_debug_read_control(vxrt_accel_t* accel, uint32_t ctx, uint32_t* out, uint32_t n_dwords, void* stream);
+/* diagnostic (tools/tile_tail.py): what frame context `ctx` learned for sets of `batch` frames -- per-tile cost (100 MHz clocks a tile
+ * occupied its wavefront in the last launch; start clocks behind them after a wave-log launch), the tile order and its 2 x 8 ranges */
+int vxrt_debug_read_lpt(vxrt_accel_t* accel, uint32_t ctx, uint32_t batch, uint32_t* cost, uint32_t cost_cap, uint32_t* order, uint32_t order_cap,
+                        uint32_t* tab32, void* stream);
 
 /* Status word of the launches on this device since the last call: 0 = ok, bit0 = traversal stack overflow
  * (tree deeper than the 32 levels the reference's own trail supports; the twin: deeper than BVH_STACK_SIZE),

@@ -359,13 +359,9 @@ def camera_rays(w, h, y0=0, y1=None):
     y1 = h if y1 is None else y1
     out = np.zeros(((y1 - y0) * w, 6), np.float32)
     L = orc()
-    tmp = (C.c_float * 6)()
-    i = 0
-    for y in range(y0, y1):
-        for x in range(w):
-            L.orc_generate_ray(x, y, w, h, tmp)
-            out[i] = tmp[:]
-            i += 1
+    L.orc_camera_rays.restype = None
+    L.orc_camera_rays.argtypes = [C.c_uint32] * 4 + [C.c_void_p]
+    L.orc_camera_rays(w, h, y0, y1, _p(out))
     return out
 
 
@@ -426,6 +422,116 @@ def render_gi(scene, w, h, params=None, seed=0, y0=0, y1=None):
     L.orc_render_gi(w, h, y0, y1, _p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(b["triEx"]), _p(b["mat"]),
                     _p(b["tex"]), C.byref(params), seed, _p(px), _p(col), C.byref(n))
     return px, col.reshape(h, w, 3), int(n.value)
+
+
+def _threads(threads=None):
+    if threads:
+        return max(1, int(threads))
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def _row_chunks(y0, y1, ranges=None, rows_per_call=4):
+    """Row ranges for the threaded checkers: small chunks dealt to a pool, so that cheap (sky) and expensive rows even out.
+    ranges: optional list of (y0, y1) row ranges to render instead of the single range [y0, y1)."""
+    step = max(1, rows_per_call)
+    out = []
+    for a, b in (ranges if ranges is not None else [(y0, y1)]):
+        out += [(y, min(y + step, b)) for y in range(a, b, step)]
+    return out
+
+
+def trace_mt(fn, scene, rays, threads=None, tmax=None, **kw):
+    """fn = trace_faithful / trace_canonical / trace_ref over a ray buffer from a thread pool (the foreign calls release the GIL; every
+    call owns its output).  Returns the hit records only."""
+    import concurrent.futures as cf
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    if fn is not trace_canonical and not isinstance(scene, Image):
+        scene = Image(scene)
+    n = len(rays)
+    t = _threads(threads)
+    cuts = np.linspace(0, n, min(n, t * 8) + 1).astype(np.int64) if n else np.zeros(1, np.int64)
+
+    def one(i):
+        a, b = int(cuts[i]), int(cuts[i + 1])
+        if tmax is not None and fn is not trace_ref:
+            return fn(scene, rays[a:b], tmax=tmax[a:b], **kw)[0]
+        return fn(scene, rays[a:b], **kw)[0]
+
+    with cf.ThreadPoolExecutor(t) as ex:
+        parts = list(ex.map(one, range(len(cuts) - 1)))
+    return np.concatenate(parts) if parts else np.zeros(0, HIT_DTYPE)
+
+
+def render_ex_mt(scene, w, h, params=None, shadow=0, y0=0, y1=None, threads=None, ranges=None):
+    """render_ex over rows [y0, y1) from a thread pool: orc_render_ex writes only the rows it is given and ctypes releases the GIL
+    for the foreign call, so disjoint row ranges share the output arrays.  Makes WHOLE full-size frames checkable in seconds
+    (tests/test_gpu_configs.py); same arithmetic as render_ex -- one call per row range instead of one call."""
+    import concurrent.futures as cf
+    y1 = h if y1 is None else y1
+    params = params or shade_params()
+    px = np.zeros((h, w), np.uint32)
+    hits = np.zeros(h * w, HIT_DTYPE)
+    col = np.zeros((h * w, 3), np.float32)
+    b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")}
+    L = orc()
+
+    def one(r):
+        n = C.c_uint64(0)
+        L.orc_render_ex(w, h, r[0], r[1], _p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(b["triEx"]), _p(b["mat"]),
+                        _p(b["tex"]), C.byref(params), shadow, _p(px), _p(hits), _p(col), C.byref(n))
+        return int(n.value)
+
+    with cf.ThreadPoolExecutor(_threads(threads)) as ex:
+        total = sum(ex.map(one, _row_chunks(y0, y1, ranges)))
+    return px, hits.reshape(h, w), col.reshape(h, w, 3), total
+
+
+def render_gi_mt(scene, w, h, params=None, seed=0, y0=0, y1=None, threads=None, ranges=None):
+    """render_gi over rows [y0, y1) from a thread pool (see render_ex_mt)."""
+    import concurrent.futures as cf
+    y1 = h if y1 is None else y1
+    params = params or shade_params()
+    px = np.zeros((h, w), np.uint32)
+    col = np.zeros((h * w, 3), np.float32)
+    b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")}
+    L = orc()
+    L.orc_render_gi.restype = C.c_int
+    L.orc_render_gi.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 7 + [C.POINTER(ShadeParams), C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+
+    def one(r):
+        n = C.c_uint64(0)
+        L.orc_render_gi(w, h, r[0], r[1], _p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(b["triEx"]), _p(b["mat"]),
+                        _p(b["tex"]), C.byref(params), seed, _p(px), _p(col), C.byref(n))
+        return int(n.value)
+
+    with cf.ThreadPoolExecutor(_threads(threads)) as ex:
+        total = sum(ex.map(one, _row_chunks(y0, y1, ranges)))
+    return px, col.reshape(h, w, 3), total
+
+
+def render_ao_mt(scene, w, h, params=None, spp=4, radius=10.0, seed=0, y0=0, y1=None, threads=None, ranges=None):
+    """render_ao over rows [y0, y1) from a thread pool (see render_ex_mt)."""
+    import concurrent.futures as cf
+    y1 = h if y1 is None else y1
+    params = params or shade_params()
+    px = np.zeros((h, w), np.uint32)
+    col = np.zeros((h * w, 3), np.float32)
+    cnt = np.zeros((h, w), np.uint32)
+    b = {k: np.ascontiguousarray(scene[k], np.uint8) for k in ("tlas", "blas", "bvh", "tri", "triEx", "mat", "tex")}
+    L = orc()
+
+    def one(r):
+        n = C.c_uint64(0)
+        L.orc_render_ao(w, h, r[0], r[1], _p(b["tlas"]), _p(b["blas"]), _p(b["bvh"]), _p(b["tri"]), _p(b["triEx"]), _p(b["mat"]),
+                        _p(b["tex"]), C.byref(params), spp, radius, seed, _p(px), _p(col), _p(cnt), C.byref(n))
+        return int(n.value)
+
+    with cf.ThreadPoolExecutor(_threads(threads)) as ex:
+        total = sum(ex.map(one, _row_chunks(y0, y1, ranges, 1)))
+    return px, col.reshape(h, w, 3), cnt, total
 
 
 def shade(scene, rays, hits, params=None):

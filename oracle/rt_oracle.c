@@ -442,6 +442,13 @@ void orc_generate_ray(uint32_t x, uint32_t y, uint32_t w, uint32_t h, float out6
   out6[3] = dir.x; out6[4] = dir.y; out6[5] = dir.z;
 }
 
+/* the camera rays of rows [y0, y1), ray (x, y) at 6 * (x + (y - y0) * w): orc_generate_ray per pixel (checker convenience: whole
+ * frames of rays without one foreign call per pixel) */
+void orc_camera_rays(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, float* out) {
+  for (uint32_t y = y0; y < y1; ++y)
+    for (uint32_t x = 0; x < w; ++x) orc_generate_ray(x, y, w, h, out + 6 * ((uint64_t)x + (uint64_t)(y - y0) * w));
+}
+
 /* common.h:156-162 */
 static f3 rgb8_to_f3(uint32_t c) {
   float s = 1 / 256.0f;

@@ -103,6 +103,7 @@ int orc_trace_canonical(const orc_node_t* tlas, const orc_blas_t* blas, const or
 
 /* --- ray generation, shading, pixel packing --- */
 void orc_generate_ray(uint32_t x, uint32_t y, uint32_t w, uint32_t h, float out6[6]); /* kernel.cpp:28-39 */
+void orc_camera_rays(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, float* out);       /* the same, rows [y0, y1) */
 
 typedef struct {
   float ambient[3], light_color[3], light_pos[3], background[3];

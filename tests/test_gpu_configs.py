@@ -1,14 +1,17 @@
-"""GPU parity at BASELINE.json's FULL sizes: the frames bench.py and tools/config_bench.py time, compared with the oracle on
-bands of rows (the CPU restatement finishes a band of a 1080p frame in seconds; the whole frame would take minutes).
+"""GPU parity at BASELINE.json's FULL sizes: the frames bench.py and tools/config_bench.py time, compared with the oracle over
+WHOLE frames.  The checker runs from a thread pool (oracle/pyoracle.py: render_ex_mt and friends -- the foreign calls release the
+GIL, row ranges are disjoint), so a 1080p primary + shadow frame of the 1,048,576-triangle scene costs it about a second on the
+box's 16 cores; only the 10M-triangle hairball (16 occlusion rays per hit) and the 3840x2160 frame are sampled, on rows spread
+over the whole frame (>= 64 rows / >= 25 % of the rows).
 
-  configs[2] headline  1,048,576-triangle atrium, 1920x1080, primary + shadow, 4 frames in flight  -> two 8-row bands
-  configs[2] as worded same scene, primary + one diffuse bounce                                     -> one band vs render_gi
-  configs[1]           bunny-class blob framed to fill the view, 1024x1024, primary + shadow        -> one band
-  configs[4]           10M-triangle hairball framed to fill the view, 1920x1080, 16 spp AO          -> one band vs render_ao
+  configs[2] headline  1,048,576-triangle atrium, 1920x1080, primary + shadow, 4 frames in flight  -> every pixel, hit record, colour
+  the timed call       vxrt_render_batch, 5 frames per set, sets alternating on two streams       -> every pixel of two frames
+  a rank's batches     interleaved tile rows with the learned tile order                          -> every row of the share
+  configs[2] as worded same scene, primary + one diffuse bounce                                     -> every pixel vs render_gi
+  configs[1]           bunny-class blob framed to fill the view, 1024x1024, primary + shadow        -> every pixel
+  configs[4]           10M-triangle hairball framed to fill the view, 1920x1080, 16 spp AO          -> 64 rows spread over the frame
   configs[3]           the atrium at 3840x2160 as N interleaved tile-row sets (the 8-GPU split of bench.py), assembled
-                       with sharding.assemble_interleaved, equals the one-shot frame and a band of the oracle's frame
-
-Bands are chosen so that they contain the a-priori EXACT pixels (the frame's centre row v == 0 and centre column u == 0)."""
+                       with sharding.assemble_interleaved, equals the one-shot frame; 25 % of its rows equal the oracle's frame"""
 import numpy as np
 import pytest
 
@@ -60,7 +63,7 @@ def _render(vrt, ds, w, h, shadow, light, streams=None, frames=1, y0=0, y1=None)
 
 def _occluded_ref(po, sc, w, h, pp, rhits, y0, y1):
     """Occluded pixels of rows [y0,y1) by the FAITHFUL traversal restatement in any-hit mode (same construction of the
-    occlusion ray as shadow_ray in csrc/rt_kernels.hip / occluded_toward_light in oracle/rt_oracle.c)."""
+    occlusion ray as shadow_ray in csrc/rt_kernels.hip / occluded_toward_light in oracle/rt_oracle.c), from a thread pool."""
     f = np.float32
     rh = rhits[y0:y1].reshape(-1)
     hit_mask = rh["dist"] < 1e29
@@ -70,14 +73,23 @@ def _occluded_ref(po, sc, w, h, pp, rhits, y0, y1):
     dist = np.sqrt((L[:, 0] * L[:, 0] + L[:, 1] * L[:, 1]).astype(f) + (L[:, 2] * L[:, 2]).astype(f)).astype(f)
     Ln = (L * (f(1.0) / dist)[:, None]).astype(f)
     srays = np.concatenate([(I + (Ln * f(0.001)).astype(f)).astype(f), Ln], 1).astype(f)[hit_mask]
-    occ, _ = po.trace_faithful(sc, srays, tmax=dist[hit_mask], any_hit=True)
+    occ = po.trace_mt(po.trace_faithful, sc, srays, tmax=dist[hit_mask], any_hit=True)
     out = np.zeros(len(rh), bool)
     out[hit_mask] = occ["dist"] < 1e29
     return out.reshape(y1 - y0, w)
 
 
-def test_headline_frame_bands_match_oracle(vrt, po, gpu_device, atrium):
-    """The frame bench.py times (1,048,576 triangles, 1920x1080, primary + shadow, 4 frames in flight on 4 streams)."""
+def _spread_rows(h, n_chunks, rows_per_chunk):
+    """n_chunks row ranges of rows_per_chunk rows spread evenly over [0, h), the one around the centre row (v == 0: the a-priori
+    EXACT launch's pixels) among them."""
+    starts = sorted(set(int(round(k * (h - rows_per_chunk) / (n_chunks - 1))) for k in range(n_chunks)) | {h // 2 - rows_per_chunk // 2})
+    return [(y, y + rows_per_chunk) for y in starts]
+
+
+def test_headline_frame_matches_oracle_everywhere(vrt, po, gpu_device, atrium):
+    """The frame bench.py times (1,048,576 triangles, 1920x1080, primary + shadow, 4 frames in flight on 4 streams): ALL 2,073,600
+    hit records (index, distance bits, barycentrics), the occluded set two-sided against the faithful restatement in any-hit
+    mode, pixels and f32 colours of the whole frame."""
     import torch
     sc, ds = atrium
     w, h = 1920, 1080
@@ -91,17 +103,14 @@ def test_headline_frame_bands_match_oracle(vrt, po, gpu_device, atrium):
         np.testing.assert_array_equal(f, frames[0])
     pp = po.shade_params(light_pos=LIGHT)
     assert nrays == w * h + int((hits["dist"] < 1e29).sum())
-    checked = 0
-    for y0, y1 in ((536, 544), (200, 208)):     # the first holds the v == 0 row (EXACT launch); both hold the u == 0 column
-        rpx, rhits, rcol, rn = po.render_ex(sc, w, h, pp, 1, y0, y1)
-        assert np.array_equal(_bits(hits[y0:y1]), _bits(rhits[y0:y1])), "hit records (index, distance bits, barycentrics)"
-        occ_ref = _occluded_ref(po, sc, w, h, pp, rhits, y0, y1)
-        np.testing.assert_array_equal(occ[y0:y1], occ_ref)
-        np.testing.assert_array_equal(frames[-1][y0:y1], rpx[y0:y1])
-        np.testing.assert_allclose(col[y0:y1], rcol[y0:y1], rtol=COLOR_RTOL, atol=0)
-        assert occ_ref.any() and not occ_ref.all()
-        checked += (y1 - y0) * w + int((rhits[y0:y1]["dist"] < 1e29).sum())
-    assert checked > 50000   # rays compared
+    rpx, rhits, rcol, rn = po.render_ex_mt(sc, w, h, pp, 1)
+    assert rn == nrays
+    assert np.array_equal(_bits(hits), _bits(rhits)), "hit records (index, distance bits, barycentrics)"
+    occ_ref = _occluded_ref(po, sc, w, h, pp, rhits, 0, h)
+    np.testing.assert_array_equal(occ, occ_ref)
+    assert occ_ref.any() and not occ_ref.all()
+    np.testing.assert_array_equal(frames[-1], rpx)
+    np.testing.assert_allclose(col, rcol, rtol=COLOR_RTOL, atol=0)
 
 
 def test_the_timed_call_itself_matches_oracle(vrt, po, gpu_device, atrium):
@@ -136,13 +145,11 @@ def test_the_timed_call_itself_matches_oracle(vrt, po, gpu_device, atrium):
     assert not torch.equal(bufs[0][0], bufs[0][4])
     last = bufs[-1].cpu().numpy().view(np.uint32)
     rays = 0
-    for f in (0, 4):
-        pp = po.shade_params(light_pos=lights[f])
-        for y0, y1 in ((536, 544), (904, 912)):
-            rpx, rhits, _, rn = po.render_ex(sc, w, h, pp, 1, y0, y1)
-            np.testing.assert_array_equal(last[f][y0:y1], rpx[y0:y1])
-            rays += rn
-    assert rays > 100000
+    for f in (0, 4):            # every pixel of two frames of the LAST set
+        rpx, _, _, rn = po.render_ex_mt(sc, w, h, po.shade_params(light_pos=lights[f]), 1)
+        np.testing.assert_array_equal(last[f], rpx)
+        rays += rn
+    assert rays > 2 * w * h
     # rays counted by the last set's launch: 5 frames, primary + one occlusion ray per hit
     assert 5 * w * h < int(cnt.item()) <= 10 * w * h
     # single frames, with the optional hit-record output: same pixels
@@ -159,7 +166,7 @@ def test_a_ranks_batches_with_the_learned_tile_order_match_oracle(vrt, po, gpu_d
     """What rank 1 of 4 does in a multi-GPU run of bench.py: batches of 10 frames' shares (interleaved tile rows, 81,600 tiles per
     batch), on two streams.  From a context's second batch on, the tiles are traced longest first in the order learned from the
     batch before (vxrt's LPT for batches of <= 100 K tiles) -- the pixels cannot depend on it: every batch equals the first,
-    frame 3's rows equal the same share rendered alone, and a band of its rows equals the oracle's frame."""
+    frame 3's rows equal the same share rendered alone, and ALL of its rows equal the oracle's frame."""
     import torch
     sc, ds = atrium
     w, h, rank, world, n = 1920, 1080, 1, 4, 10
@@ -189,11 +196,10 @@ def test_a_ranks_batches_with_the_learned_tile_order_match_oracle(vrt, po, gpu_d
     vrt.rtapi.render_interleaved(ds.accel, w, h, rank, world, plist[3], one.data_ptr(), 1, None, None, None, s0)
     torch.cuda.synchronize()
     assert torch.equal(bufs[-1][3], one)
-    y0, y1 = 520, 552          # holds this rank's tile row 65 (rows 520-527) and the v == 0 row of the frame is next to it
-    mine = rows[(rows >= y0) & (rows < y1)]
-    assert len(mine) == 8
-    want, _, _, _ = po.render_ex(sc, w, h, po.shade_params(light_pos=lights[3]), 1, int(mine[0]), int(mine[-1]) + 1)
-    np.testing.assert_array_equal(bufs[-1][3].cpu().numpy().view(np.uint32)[mine], want[mine])
+    # every row of this rank's share of frame 3 against the oracle's frame
+    want, _, _, _ = po.render_ex_mt(sc, w, h, po.shade_params(light_pos=lights[3]), 1)
+    assert len(rows) >= h // world - 8
+    np.testing.assert_array_equal(bufs[-1][3].cpu().numpy().view(np.uint32)[rows], want[rows])
 
 
 def test_serial_frames_with_learned_tile_order_match_pipelined(vrt, po, gpu_device, atrium):
@@ -204,14 +210,13 @@ def test_serial_frames_with_learned_tile_order_match_pipelined(vrt, po, gpu_devi
     np.testing.assert_array_equal(frames[0], frames[1])
     np.testing.assert_array_equal(frames[0], frames[2])
     pp = po.shade_params(light_pos=LIGHT)
-    y0, y1 = 880, 888
-    rpx, rhits, rcol, _ = po.render_ex(sc, w, h, pp, 1, y0, y1)
-    np.testing.assert_array_equal(frames[2][y0:y1], rpx[y0:y1])
-    assert np.array_equal(_bits(hits[y0:y1]), _bits(rhits[y0:y1]))
+    rpx, rhits, rcol, _ = po.render_ex_mt(sc, w, h, pp, 1)
+    np.testing.assert_array_equal(frames[2], rpx)
+    assert np.array_equal(_bits(hits), _bits(rhits))
 
 
 def test_diffuse_bounce_on_the_atrium_matches_oracle(vrt, po, gpu_device, atrium):
-    """configs[2] as worded (1 bounce diffuse) at full size: one band against orc_render_gi."""
+    """configs[2] as worded (1 bounce diffuse) at full size: every pixel and f32 colour against orc_render_gi."""
     import torch
     sc, ds = atrium
     w, h = 1920, 1080
@@ -223,11 +228,10 @@ def test_diffuse_bounce_on_the_atrium_matches_oracle(vrt, po, gpu_device, atrium
     s = torch.cuda.current_stream().cuda_stream
     vrt.rtapi.render_diffuse_bounce(ds.accel, w, h, 0, h, p, px.data_ptr(), seed=3, colors_ptr=col.data_ptr(), rays_ptr=nr.data_ptr(), stream=s)
     assert vrt.rtapi.status(s) == 0
-    y0, y1 = 536, 544
-    rpx, rcol, rn = po.render_gi(sc, w, h, po.shade_params(light_pos=LIGHT), seed=3, y0=y0, y1=y1)
-    assert int(nr.item()) > w * h
-    np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3)[y0:y1], rcol[y0:y1], rtol=COLOR_RTOL, atol=0)
-    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32)[y0:y1], rpx[y0:y1])
+    rpx, rcol, rn = po.render_gi_mt(sc, w, h, po.shade_params(light_pos=LIGHT), seed=3)
+    assert int(nr.item()) == rn > w * h
+    np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3), rcol, rtol=COLOR_RTOL, atol=0)
+    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), rpx)
 
 
 def test_bunny_class_frame_matches_oracle(vrt, po, gpu_device):
@@ -242,18 +246,18 @@ def test_bunny_class_frame_matches_oracle(vrt, po, gpu_device):
     assert cover > 0.45, cover                                   # the object fills the view (it was 14 % in round 1)
     assert nrays == w * h + int((hits["dist"] < 1e29).sum())
     pp = po.shade_params(light_pos=light)
-    y0, y1 = 508, 524
-    rpx, rhits, rcol, _ = po.render_ex(sc, w, h, pp, 1, y0, y1)
-    assert np.array_equal(_bits(hits[y0:y1]), _bits(rhits[y0:y1]))
-    np.testing.assert_array_equal(occ[y0:y1], _occluded_ref(po, sc, w, h, pp, rhits, y0, y1))
-    np.testing.assert_array_equal(frames[0][y0:y1], rpx[y0:y1])
-    np.testing.assert_allclose(col[y0:y1], rcol[y0:y1], rtol=COLOR_RTOL, atol=0)
+    rpx, rhits, rcol, rn = po.render_ex_mt(sc, w, h, pp, 1)
+    assert rn == nrays
+    assert np.array_equal(_bits(hits), _bits(rhits))
+    np.testing.assert_array_equal(occ, _occluded_ref(po, sc, w, h, pp, rhits, 0, h))
+    np.testing.assert_array_equal(frames[0], rpx)
+    np.testing.assert_allclose(col, rcol, rtol=COLOR_RTOL, atol=0)
     ds.close()
 
 
 def test_hairball_ao_frame_matches_oracle(vrt, po, gpu_device):
-    """configs[4]: 10M-triangle hairball framed to fill the view, 1920x1080, 16 spp ambient occlusion: one band of
-    unoccluded counts, colours and pixels against orc_render_ao (same RNG, same IEEE-only sampling recipe)."""
+    """configs[4]: 10M-triangle hairball framed to fill the view, 1920x1080, 16 spp ambient occlusion: unoccluded counts,
+    colours and pixels of 68 rows spread over the whole frame against orc_render_ao (same RNG, same IEEE-only sampling recipe)."""
     import torch
     sc = vrt.scene.procedural("hairball_fill", 20000, 250, 7)
     assert sc.n_tris == 10000000
@@ -274,13 +278,20 @@ def test_hairball_ao_frame_matches_oracle(vrt, po, gpu_device):
     rays = int(nr.item())
     hit_px = (rays - w * h) // spp
     assert hit_px > 0.6 * w * h, hit_px / (w * h)                # SURVEY s8d's ray count needs the ball to fill the view
-    y0, y1 = 538, 542
-    rpx, rcol, rcnt, rn = po.render_ao(sc, w, h, po.shade_params(light_pos=(0.0, 400.0, 0.0)), spp=spp, radius=radius, seed=7, y0=y0, y1=y1)
-    np.testing.assert_array_equal(cnt.cpu().numpy().view(np.uint32)[y0:y1], rcnt[y0:y1])
-    np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3)[y0:y1], rcol[y0:y1], rtol=COLOR_RTOL, atol=0)
-    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32)[y0:y1], rpx[y0:y1])
-    band = rcnt[y0:y1]
-    assert (band < spp).any() and (band > 0).any()
+    gcnt, gcol, gpx = cnt.cpu().numpy().view(np.uint32), col.cpu().numpy().reshape(h, w, 3), px.cpu().numpy().view(np.uint32)
+    pp = po.shade_params(light_pos=(0.0, 400.0, 0.0))
+    ranges = _spread_rows(h, 16, 4)                # 17 ranges of 4 rows over the whole frame (68 rows, ~1.7 M occlusion rays)
+    rpx, rcol, rcnt, rn = po.render_ao_mt(sc, w, h, pp, spp=spp, radius=radius, seed=7, ranges=ranges)
+    checked = 0
+    for y0, y1 in ranges:
+        np.testing.assert_array_equal(gcnt[y0:y1], rcnt[y0:y1])
+        np.testing.assert_allclose(gcol[y0:y1], rcol[y0:y1], rtol=COLOR_RTOL, atol=0)
+        np.testing.assert_array_equal(gpx[y0:y1], rpx[y0:y1])
+        checked += y1 - y0
+        if y0 <= h // 2 < y1:
+            band = rcnt[y0:y1]
+            assert (band < spp).any() and (band > 0).any()
+    assert checked >= 64
     ds.close()
 
 
@@ -288,7 +299,7 @@ def test_hairball_ao_frame_matches_oracle(vrt, po, gpu_device):
 def test_4k_frame_as_interleaved_tile_rows_equals_one_shot(vrt, po, gpu_device, atrium, world):
     """configs[3]: 3840x2160 split over `world` ranks the way bench.py --gpus N splits it -- rank r renders the tile rows
     r, r + world, ... (vxrt_render_interleaved) -- here all on one GPU, then assembled with the function the RCCL gather
-    path uses.  The assembled frame equals the one-shot frame bit for bit, and a band of it equals the oracle's."""
+    path uses.  The assembled frame equals the one-shot frame bit for bit, and a quarter of its rows, spread over the frame, equal the oracle's."""
     import torch
     sc, ds = atrium
     w, h = 3840, 2160
@@ -314,9 +325,15 @@ def test_4k_frame_as_interleaved_tile_rows_equals_one_shot(vrt, po, gpu_device, 
     assert total == int(cnt.item())
     frame = vrt.sharding.assemble_interleaved(parts, h, w, world)
     assert torch.equal(frame, one)
-    y0, y1 = 1076, 1084
-    rpx, _, _, _ = po.render_ex(sc, w, h, po.shade_params(light_pos=LIGHT), 1, y0, y1)
-    np.testing.assert_array_equal(frame.cpu().numpy().view(np.uint32)[y0:y1], rpx[y0:y1])
+    fr = frame.cpu().numpy().view(np.uint32)
+    pp = po.shade_params(light_pos=LIGHT)
+    ranges = _spread_rows(h, 34, 16)               # 35 ranges of 16 rows: 26 % of the frame's rows, every rank's rows among them
+    rpx, _, _, _ = po.render_ex_mt(sc, w, h, pp, 1, ranges=ranges)
+    checked = 0
+    for y0, y1 in ranges:
+        np.testing.assert_array_equal(fr[y0:y1], rpx[y0:y1])
+        checked += y1 - y0
+    assert checked >= h // 4
 
 
 def test_batch_of_frames_equals_the_frames_one_by_one(vrt, po, gpu_device, atrium):

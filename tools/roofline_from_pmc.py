@@ -12,13 +12,28 @@ cycles per SIMD; the class counters (ADD/MUL/FMA/TRANS/INT32/CVT, the unclassifi
 slow class from above by  CVT + INT32 + rest.
 HBM traffic: FETCH_SIZE / WRITE_SIZE (KiB, separate passes); reads x2 (gfx950 FETCH_SIZE counts 64 B per 128-B request of a
 wide read stream: MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact.
-usage: tools/roofline_from_pmc.py <summary.txt> <out.json> [source label]"""
+The file also records the IDENTITY of the run the counters describe -- frame size, tree hash + node count, kernel source id, the
+traversal counts of the counting build -- copied from the `roofline.identity` block of a bench line of the same session; bench.py
+reports `frac: null` with the reason when its own run differs in any of them (a changed tree or kernel would otherwise leave a
+stale numerator under a confident fraction).
+usage: tools/roofline_from_pmc.py <summary.txt> <out.json> [source label] [bench_line.json] [bench_line_random_rays.json summary_rr.txt]"""
 import json
 import re
 import sys
 
 summary, out = sys.argv[1], sys.argv[2]
 label = sys.argv[3] if len(sys.argv) > 3 else summary
+identity = None
+if len(sys.argv) > 4:
+    for line in open(sys.argv[4]):
+        if line.lstrip().startswith("{"):
+            identity = json.loads(line).get("roofline", {}).get("identity")
+# optional: the bench line of the counter pass that ran WITH the random-ray leg (its extras.random_rays block identifies the ray buffer)
+rr_line = None
+if len(sys.argv) > 5:
+    for line in open(sys.argv[5]):
+        if line.lstrip().startswith("{"):
+            rr_line = json.loads(line).get("extras", {}).get("random_rays")
 cur, data = None, {}
 for line in open(summary):
     if line.startswith("void ") or line.startswith("accel_"):
@@ -60,6 +75,7 @@ rd = 2.0 * per_frame("FETCH_SIZE") * 1024
 wr = per_frame("WRITE_SIZE") * 1024
 res = {
     "source": label,
+    "identity": identity,
     "valu_instr_per_frame": int(total),
     "valu_instr_classes": {k: int(v) for k, v in cls.items()} | {"unclassified": int(rest)},
     # the slow class is under half of the stream (static mix of the hot loop: ~35 %; the counter bound below counts every v_mov and
@@ -73,5 +89,22 @@ res = {
     "hbm_source": label + " (FETCH_SIZE x2 + WRITE_SIZE, separate passes, serial frames)",
     "main_kernel": {k: v for k, v in step[main].items() if not k.startswith("_n_")},
 }
+# the ray-buffer kernel (rt_persistent_kernel<JOB_TRACE = 2, STATS = 0, ...>): instructions per launch of the random-ray leg
+data_rr, cur = {}, None
+if len(sys.argv) > 6:
+    for line in open(sys.argv[6]):
+        if line.startswith("void ") or line.startswith("accel_"):
+            cur = line.strip()
+            data_rr.setdefault(cur, {})
+        else:
+            m = re.match(r"\s+(\S+)\s+n=(\d+)\s+mean=(\S+)", line)
+            if m and cur:
+                data_rr[cur][m.group(1)] = float(m.group(3))
+tr = {k: v for k, v in data_rr.items() if re.search(r"rt_persistent_kernel<2, (0|false), ", k) and "SQ_INSTS_VALU" in v}
+if tr and rr_line:
+    # main + EXACT instantiation of one vxrt_trace call: both are launched once per call
+    per_launch = sum(v["SQ_INSTS_VALU"] for v in tr.values())
+    res["random_rays"] = {"n": rr_line["rays_per_gpu"], "node_fetches": rr_line["node_fetches"], "tri_fetches": rr_line["tri_fetches"],
+                          "valu_instr_per_launch": int(per_launch), "source": label + " (pass with the random-ray leg: SQ_INSTS_VALU, mean over its launches)"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("valu_instr_per_frame", "valu_instr_classes", "valu_simd_cycles_per_frame", "valu_simd_cycles_all_x2.2", "valu_simd_cycles_slow_class_upper_bound_x4.1", "hbm_bytes_per_frame")}))

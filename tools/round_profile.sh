@@ -13,8 +13,9 @@ python -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.txt" 2>&1 || { tail -5 "$
 tail -1 "$OUT/pytest_gpu.txt"
 "$ROOT/tools/pmc_passes.sh" "$OUT/pmc" > "$OUT/pmc.log" 2>&1
 tail -3 "$OUT/pmc.log"
-cp "$OUT/pmc/summary.txt" "$OUT/pmc_summary.txt"; rm -rf "$OUT"/pmc/pass*/
-python tools/roofline_from_pmc.py "$OUT/pmc_summary.txt" "$ROOT/profiles/valu_profile.json" "profiles/${TAG}_pmc.txt" > "$OUT/valu_profile.log" 2>&1
+cp "$OUT/pmc/summary.txt" "$OUT/pmc_summary.txt"; cp "$OUT/pmc/summary_rr.txt" "$OUT/pmc_summary_random_rays.txt"; rm -rf "$OUT"/pmc/pass*/
+# (the 4th argument: a bench line of the counter passes' own session -- its roofline.identity block ties the constants to the tree and the kernel source)
+python tools/roofline_from_pmc.py "$OUT/pmc_summary.txt" "$ROOT/profiles/valu_profile.json" "profiles/${TAG}_pmc.txt" "$OUT/pmc/pass1.log" "$OUT/pmc/pass_rr.log" "$OUT/pmc/summary_rr.txt" > "$OUT/valu_profile.log" 2>&1
 cp "$ROOT/profiles/valu_profile.json" "$OUT/valu_profile.json"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
 cut -c1-600 "$OUT/bench.json"

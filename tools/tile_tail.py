@@ -1,0 +1,69 @@
+"""Diagnostic: which tiles is a set's traversal launch still working on after its queue ran dry?  Per-tile start clock and duration of the
+last of three sets (wave-log build), against the cost the order was learned from.  usage: tools/tile_tail.py [world=8] [frames=10]"""
+import ctypes as C, importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+vrt = importlib.import_module("vortex-raytracing_amd")
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+nf = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+W, H = 1920, 1080
+sc = vrt.scene.procedural("atrium", 8, 0, 3)
+ds = vrt.tracer.DeviceScene(sc, "cuda:0")
+p = vrt.rtapi.default_shade_params(); p.light_pos[:] = (300.0, 480.0, 60.0)
+ig = vrt.sharding.InterleavedGather(H, W, 0, world, "cuda:0", slots=1, collective=False, batch=nf)
+buf = ig.new_frame_buffer("cuda:0")
+L = vrt.rtapi._lib()
+fn = L.vxrt_render_interleaved_batch_wave_log
+fn.restype = C.c_int
+fn.argtypes = [C.c_void_p] + [C.c_uint32] * 5 + [C.POINTER(vrt.rtapi.ShadeParams), C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+rd = L.vxrt_debug_read_lpt
+rd.restype = C.c_int
+rd.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+arr = (vrt.rtapi.ShadeParams * nf)(*([p] * nf))
+vrt.rtapi.accel_frames_in_flight(ds.accel, 2)
+prev = prevd = None
+for it in range(3):
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+    log = torch.zeros((4 * 8 * 256, 16), dtype=torch.int64, device="cuda:0")
+    assert fn(ds.accel, W, H, 0, world, nf, arr, 1, buf.data_ptr(), ig.frame_stride, cnt.data_ptr(), log.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    cost = np.zeros(800000, np.uint32); order = np.zeros(400000, np.uint32); tab = np.zeros(32, np.uint32)
+    n = rd(ds.accel, 0, nf, cost.ctypes.data, cost.size, order.ctypes.data, order.size, tab.ctypes.data, None)
+    assert n > 0
+    # the number of tiles of THIS launch: from the table's ranges
+    nt = int(sum(tab[2 * k + 1] for k in range(16)))
+    work = cost[:nt].astype(np.float64)                     # what the order is learned from: loop iterations (+2 per leaf-body run)
+    dur = cost[2 * nt:3 * nt].astype(np.float64) / 100.0    # how long the tile occupied its wavefront, us
+    lg = log.cpu().numpy().astype(np.float64); lg = lg[lg[:, 1] > 0]
+    t0w = lg[:, 0].min()
+    st = cost[nt:2 * nt].astype(np.int64)
+    t0 = int(st.min())
+    start = ((st - t0) & 0xFFFFFFFF).astype(np.float64) / 100.0
+    if it == 2:
+        print("tiles %d; duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (nt, dur.mean(), *np.percentile(dur, (50, 90, 99, 100))))
+        q_empty = (lg[:, 15][lg[:, 15] > 0].min() - t0w) / 100.0
+        span = (lg[:, 1].max() - t0w) / 100.0
+        print("queue first found empty at %.1f us, span %.1f us" % (q_empty, span))
+        late = start > q_empty - 150
+        print("tiles started in the last 150 us before the queue ran dry: %d; their duration mean %.1f p50 %.1f p90 %.1f max %.1f" % (late.sum(), dur[late].mean(), *np.percentile(dur[late], (50, 90, 100))))
+        endt = start + dur
+        tail = endt > q_empty + 100
+        print("tiles that END more than 100 us after the queue ran dry: %d; start: min %.1f p50 %.1f max %.1f; duration mean %.1f p50 %.1f max %.1f" %
+              (tail.sum(), start[tail].min(), np.percentile(start[tail], 50), start[tail].max(), dur[tail].mean(), np.percentile(dur[tail], 50), dur[tail].max()))
+        if prev is not None:
+            print("duration of a tile in this set vs the set before: correlation %.3f; WORK of a tile vs the set before: correlation %.4f; work vs duration in this set: %.3f" %
+                  (np.corrcoef(prevd, dur)[0, 1], np.corrcoef(prev, work)[0, 1], np.corrcoef(work, dur)[0, 1]))
+            print("work: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f; learned work of the tail tiles: mean %.1f" % (work.mean(), *np.percentile(work, (50, 90, 99, 100)), prev[tail].mean()))
+        # duration by start time decile
+        idx = np.argsort(start)
+        for d in range(10):
+            sel = idx[d * nt // 10:(d + 1) * nt // 10]
+            print("   start decile %d: start %.0f..%.0f us, duration mean %.1f p90 %.1f; work mean %.1f; us per unit of work %.2f" % (d, start[sel].min(), start[sel].max(), dur[sel].mean(), np.percentile(dur[sel], 90), work[sel].mean(), dur[sel].sum() / work[sel].sum()))
+        stolen = cost[3 * nt:4 * nt]
+        for lo_, hi_ in ((0, 300), (300, 500), (500, 560), (560, 600), (600, 640), (640, 700)):
+            w_ = (start >= lo_) & (start < hi_)
+            for name, m_ in (("home", w_ & (stolen == 0)), ("stolen", w_ & (stolen > 0))):
+                if m_.sum():
+                    print("   started %3d..%3d us, %-6s: %5d tiles, us per unit of work %.2f (duration mean %.1f, work mean %.1f)" % (lo_, hi_, name, m_.sum(), dur[m_].sum() / work[m_].sum(), dur[m_].mean(), work[m_].mean()))
+        print("ranges (first, tiles):", [(int(tab[2 * k]), int(tab[2 * k + 1])) for k in range(16)])
+    prev, prevd = work, dur

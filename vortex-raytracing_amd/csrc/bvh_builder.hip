@@ -284,7 +284,7 @@ __device__ __forceinline__ int bb_nearest(const float (*sb)[6], int k, int g, in
     if (j < 0 || j >= m) continue;
     const float* o = sb[j - s0];
     const float a = box_area(fminf(lx, o[0]), fminf(ly, o[1]), fminf(lz, o[2]), fmaxf(hx, o[3]), fmaxf(hy, o[4]), fmaxf(hz, o[5]));
-    if (a < best || bj < 0) { best = a; bj = j; }   // (ascending j, strict <: ties go to the lower position; a NaN area never wins over a number)
+    if (bj < 0 || a < best || (best != best && a == a)) { best = a; bj = j; }   // (ascending j, strict <: ties go to the lower position; a NaN area never wins over a number, first candidate or not)
   }
   return bj;
 }

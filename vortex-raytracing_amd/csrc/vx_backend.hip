@@ -91,8 +91,9 @@ struct vx_device {
   vxrc_accel_t* rc_accel = nullptr;   // layout of the raycast twin's scene, rebuilt when one of its buffers is re-uploaded
   uint64_t rc_key[16] = {0};
   // reference-quirks mode (DCR 0x7F4): flat image of the address space, camera rays and hit records of the frame
-  void* q_image = nullptr; uint64_t q_image_size = 0, q_image_ver = ~0ull; void* q_rays = nullptr; void* q_hits = nullptr; uint64_t q_rays_cap = 0;
+  void* q_image = nullptr; uint64_t q_image_size = 0; struct QKey { uint64_t va, size, version; bool operator<(const QKey& o) const { return va < o.va; } }; std::vector<QKey> q_image_key; void* q_rays = nullptr; void* q_hits = nullptr; uint64_t q_rays_cap = 0;
   uint64_t accel_key[14] = {0};
+  uint64_t upload_seq = 0;
 
   int init() {
     const char* e = std::getenv("VORTEX_HIP_DEVICE");
@@ -282,7 +283,7 @@ struct vx_device {
       if (hipMemcpy((char*)a->dptr + off, src, size, hipMemcpyHostToDevice) != hipSuccess) return -1;
     }
     if (!a->shadow.empty() && off + size <= a->shadow.size()) std::memcpy(a->shadow.data() + off, src, size);
-    a->version++;
+    a->version = ++upload_seq;   // unique per device: a buffer freed and allocated again at the same address never repeats a version
     return 0;
   }
 
@@ -413,24 +414,37 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   if (quirks) {
     // reference-quirks mode: the frame's camera rays through the literal restatement of the RTU on a flat image of the address space
     if (shadow || row_stride > 1 || ka.max_depth > 1) { VXLOG("start: reference-quirks mode renders closest-hit frames only (no shadow extension, row stride or mirror bounce)"); return -1; }
-    uint64_t hi = 0, ver = 0;
-    for (auto& kv : allocs) if (!kv.second.reserved && kv.first < 0x80000000ull) { hi = std::max(hi, kv.second.va + kv.second.span); ver = ver * 1315423911ull + kv.second.version + kv.first; }
+    // the image mirrors the address space: every allocation at the address vx_mem_address reported.  It is kept between runs and only
+    // what changed is copied again -- the list of (address, size, upload version) entries, in address order, is compared entry by entry (no
+    // rolling hash that could alias): the same set of allocations -> only the re-uploaded ones are copied (every frame re-uploads its
+    // kernel arguments: 216 bytes, not the 4 GiB the whole image may span); another set -> cleared and rebuilt.
+    uint64_t hi = 0;
+    std::vector<QKey> ver;
+    for (auto& kv : allocs) if (!kv.second.reserved && kv.first < 0x80000000ull) {
+      hi = std::max(hi, kv.second.va + kv.second.span);
+      ver.push_back(QKey{kv.first, kv.second.size, kv.second.version});
+    }
+    std::sort(ver.begin(), ver.end());
     if (hi == 0 || hi > 0xFFFFFFFFull) { VXLOG("start: reference-quirks mode needs the scene below 4 GiB of device address space"); return -1; }
     if (q_image_size < hi) {
       if (q_image) (void)hipFree(q_image);
-      q_image = nullptr; q_image_size = 0; q_image_ver = ~0ull;
+      q_image = nullptr; q_image_size = 0; q_image_key.clear();
       if (hipMalloc(&q_image, hi) != hipSuccess) return -1;
       q_image_size = hi;
     }
-    if (q_image_ver != ver) {
+    bool same_set = q_image_key.size() == ver.size();
+    for (size_t i = 0; same_set && i < ver.size(); ++i) same_set = q_image_key[i].va == ver[i].va && q_image_key[i].size == ver[i].size;
+    if (!same_set) {
+      q_image_key.clear();
       if (hipMemsetAsync(q_image, 0, q_image_size, stream) != hipSuccess) return -1;
-      for (auto& kv : allocs) {
-        const Alloc& al = kv.second;
-        if (al.reserved || kv.first >= 0x80000000ull || !al.dptr) continue;
-        if (hipMemcpyAsync((char*)q_image + al.va, al.dptr, al.size, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
-      }
-      q_image_ver = ver;
     }
+    for (size_t i = 0; i < ver.size(); ++i) {
+      if (same_set && q_image_key[i].version == ver[i].version) continue;
+      const Alloc& al = allocs[ver[i].va];
+      if (!al.dptr) continue;
+      if (hipMemcpyAsync((char*)q_image + al.va, al.dptr, al.size, hipMemcpyDeviceToDevice, stream) != hipSuccess) { q_image_key.clear(); return -1; }
+    }
+    q_image_key = ver;
     const uint64_t nr = (uint64_t)ka.dst_width * (y1 - y0);
     if (q_rays_cap < nr) {
       if (q_rays) (void)hipFree(q_rays);

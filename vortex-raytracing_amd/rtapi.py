@@ -277,6 +277,19 @@ def render_interleaved_batch(accel, width, height, phase, stride, params_list, d
           "vxrt_render_interleaved_batch")
 
 
+def render_rows_batch(accel, width, height, y0, y1, params_list, dst_ptr, dst_frame_stride, shadow=0, rays_ptr=None, stream=None):
+    """vxrt_render_rows_batch: len(params_list) frames of the row band [y0, y1) in one set of launches.  dst_ptr addresses a full
+    frame (pixel (x, y) of frame f at dst + f * dst_frame_stride + x + y * width, in pixels): a caller that keeps only its band
+    passes band_ptr - 4 * y0 * width and a frame stride of (y1 - y0) * width."""
+    L = _lib()
+    L.vxrt_render_rows_batch.restype = C.c_int
+    L.vxrt_render_rows_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ShadeParams), C.c_int,
+                                         C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    arr = (ShadeParams * len(params_list))(*params_list)
+    check(L.vxrt_render_rows_batch(accel, width, height, y0, y1, len(params_list), arr, int(shadow), dst_ptr, dst_frame_stride, rays_ptr, stream),
+          "vxrt_render_rows_batch")
+
+
 def render_batch(accel, width, height, params_list, dst_ptr, dst_frame_stride, shadow=0, rays_ptr=None, stream=None):
     """vxrt_render_batch: len(params_list) whole frames in one set of launches; frame f -> dst + f * dst_frame_stride pixels."""
     L = _lib()

@@ -173,3 +173,127 @@ class InterleavedGather:
         torch.stack([p.view(self.batch, self.per, TILE, self.w) for p in self.recv[slot]], dim=2, out=self.full[slot])
         out = self.full[slot].view(self.batch, self.padded_height, self.w)[:, : self.h]
         return out[0] if self.batch == 1 else out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Contiguous bands balanced by cost (bench.py --shard bands, the default with several GPUs).
+#
+# Why bands after all: with interleaved tile rows every rank's share is scattered over the image, so rank 0 needs one strided
+# extraction on every rank + one interleaving copy of the WHOLE batch of frames on rank 0 before an image exists -- measured
+# (profiles/r04_*): 65 us per 10 frames on rank 0 of 8, a tenth of its run, and serial after the last traversal.  A contiguous band
+# lies in the final image as one block: rank 0 receives every band straight into its place (grouped ncclSend / ncclRecv = a gather with
+# per-rank sizes), renders its own band in place, and no copy kernel runs at all.  What interleaving bought -- balance: the cost
+# of a tile varies 4x over the frame -- comes from the band HEIGHTS instead: plan_bands() cuts the rows at equal measured cost
+# and bench.py refines the cut with the ranks' own frame times during the untimed settle phase (rebalance_bands).
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def equal_bands(height, world, align=TILE):
+    """[b_0 = 0, b_1, ..., b_world = height]: `world` contiguous bands of (nearly) equal height, cuts on multiples of `align`."""
+    units = (height + align - 1) // align
+    base, extra = divmod(units, world)
+    b, t = [0], 0
+    for r in range(world):
+        t += base + (1 if r < extra else 0)
+        b.append(min(t * align, height))
+    b[-1] = height
+    return b
+
+
+def rebalance_bands(bounds, times, height, align=TILE, damping=1.0, min_rows=TILE):
+    """New band boundaries from the time each rank needed for its band: the cost of a row is taken as constant inside a band
+    (time / rows), the cumulative cost is cut into equal parts, cuts are rounded to multiples of `align` and every band keeps at
+    least `min_rows` rows.  damping < 1 moves the cuts only part of the way (the measured time of a band includes what does not
+    scale with its rows).  Deterministic in its inputs: every rank computes the same plan from the gathered times."""
+    world = len(bounds) - 1
+    rows = [bounds[r + 1] - bounds[r] for r in range(world)]
+    if world == 1 or min(rows) <= 0 or min(times) <= 0:
+        return list(bounds)
+    dens = [times[r] / rows[r] for r in range(world)]          # cost per row inside band r
+    cum = [0.0]
+    for r in range(world):
+        cum.append(cum[-1] + times[r])
+    total = cum[-1]
+    new = [0]
+    for k in range(1, world):
+        target = total * k / world
+        r = max(i for i in range(world) if cum[i] <= target)   # band the k-th cut falls into
+        y = bounds[r] + (target - cum[r]) / dens[r]
+        y = bounds[k] + damping * (y - bounds[k])
+        new.append(int(round(y / align)) * align)
+    new.append(height)
+    for k in range(1, world):                                  # monotone, every band at least min_rows
+        new[k] = max(new[k], new[k - 1] + min_rows)
+    for k in range(world - 1, 0, -1):
+        new[k] = min(new[k], new[k + 1] - min_rows)
+    return new
+
+
+def taper(steps, first_max=16, last=1, ratio=0.5):
+    """Sizes of the sets of frames a run of `steps` frames is issued in when every set ends with a collective: large sets first
+    (a rank's share of a frame is small against its GPU, many frames per launch keep it full), geometrically smaller ones towards
+    the end, so that what nothing overlaps any more -- the shading and the gather of the LAST set -- is small.  sum == steps."""
+    out, left = [], int(steps)
+    while left > 0:
+        s = left if left <= last else min(first_max, max(last, int(round(left * ratio))))
+        out.append(s)
+        left -= s
+    return out
+
+
+class BandGather:
+    """Image assembly of an N-rank run with contiguous bands: rank r renders rows [bounds[r], bounds[r+1]) of every frame of a set.
+    Rank 0 owns the final images ([frames, height, width] per slot) and renders its own band IN PLACE; every other rank renders
+    into a compact [frames, rows_r, width] buffer (render target = buffer - bounds[r] * width, see vxrt_render_rows_batch) and
+    sends frame f's band with one ncclSend; rank 0 posts the matching ncclRecv straight into final[f, b_r:b_{r+1}] -- all of a
+    set's transfers in ONE group call (a gather with per-rank sizes).  No extraction, no staging, no interleaving copy.
+    collective=False: rehearsal of one rank without the network (nothing is moved: rank 0's own band is already in place)."""
+
+    def __init__(self, height, width, rank, world, bounds, device, set_sizes, dtype=None, group=None, collective=True, via_cpu=False):
+        import torch
+        self.h, self.w, self.rank, self.world, self.group = height, width, rank, world, group
+        self.bounds = list(bounds)
+        self.y0, self.y1 = self.bounds[rank], self.bounds[rank + 1]
+        self.collective, self.via_cpu = collective, via_cpu
+        self.dtype = dtype or torch.int32
+        self.bufs = []
+        for k in set_sizes:       # one buffer per slot, sized for the largest set that uses it
+            shape = (k, height, width) if rank == 0 else (k, self.y1 - self.y0, width)
+            self.bufs.append(torch.zeros(shape, dtype=self.dtype, device=device))
+
+    def target(self, slot):
+        """(dst pointer, frame stride in pixels) for vxrt_render_rows_batch(y0 = self.y0, y1 = self.y1) into slot `slot`."""
+        b = self.bufs[slot]
+        if self.rank == 0:
+            return b.data_ptr(), self.h * self.w
+        return b.data_ptr() - b.element_size() * self.y0 * self.w, (self.y1 - self.y0) * self.w
+
+    def gather(self, slot, k):
+        """Assemble the first k frames of slot `slot` on rank 0 (called on the stream the collective is to be ordered on).
+        Returns the [k, height, width] images on rank 0, None elsewhere."""
+        import torch
+        import torch.distributed as dist
+        buf = self.bufs[slot]
+        if self.collective and self.world > 1:
+            if self.via_cpu:      # gloo rehearsal: host tensors, placed the same way
+                if self.rank == 0:
+                    stage = [[torch.empty((self.bounds[r + 1] - self.bounds[r], self.w), dtype=self.dtype) for _ in range(k)] for r in range(1, self.world)]
+                    reqs = [dist.irecv(stage[r - 1][f], src=r, group=self.group, tag=f) for r in range(1, self.world) for f in range(k)]
+                    for q in reqs:
+                        q.wait()
+                    for r in range(1, self.world):
+                        for f in range(k):
+                            buf[f, self.bounds[r]:self.bounds[r + 1]].copy_(stage[r - 1][f])
+                else:
+                    host = buf[:k].cpu()
+                    for q in [dist.isend(host[f], dst=0, group=self.group, tag=f) for f in range(k)]:
+                        q.wait()
+            else:
+                if self.rank == 0:
+                    ops = [dist.P2POp(dist.irecv, buf[f, self.bounds[r]:self.bounds[r + 1]], r, self.group)
+                           for r in range(1, self.world) for f in range(k) if self.bounds[r + 1] > self.bounds[r]]
+                else:
+                    ops = [dist.P2POp(dist.isend, buf[f], 0, self.group) for f in range(k)] if self.y1 > self.y0 else []
+                if ops:
+                    for q in dist.batch_isend_irecv(ops):
+                        q.wait()          # (NCCL: orders the current stream behind the transfer; does not block the host)
+        return buf[:k] if self.rank == 0 else None
