@@ -414,10 +414,11 @@ int vxrt_trace_reference_quirks(const void* image, uint64_t image_size, uint32_t
  * [288 + 32 k] of the EXACT launch over the deferred list, [544 + 32 k] of the a-priori EXACT launch.  A vxrt_trace call leaves the
  * block as its launches left it (the next call clears it). */
 int vxrt_debug_read_control(vxrt_accel_t* accel, uint32_t ctx, uint32_t* out, uint32_t n_dwords, void* stream);
-/* diagnostic (tools/tile_tail.py): what frame context `ctx` learned for sets of `batch` frames -- per-tile cost (100 MHz clocks a tile
- * occupied its wavefront in the last launch; start clocks behind them after a wave-log launch), the tile order and its 2 x 8 ranges */
+/* diagnostic (tools/tile_tail.py): what frame context `ctx` learned for sets of `batch` frames -- per-tile cost (loop iterations of the
+ * wavefront that traced it in the last launch; start clocks, durations and steal distances behind them after a wave-log launch) and the
+ * tile order derived from it.  Returns the capacity in tiles. */
 int vxrt_debug_read_lpt(vxrt_accel_t* accel, uint32_t ctx, uint32_t batch, uint32_t* cost, uint32_t cost_cap, uint32_t* order, uint32_t order_cap,
-                        uint32_t* tab32, void* stream);
+                        void* stream);
 
 /* Status word of the launches on this device since the last call: 0 = ok, bit0 = traversal stack overflow
  * (tree deeper than the 32 levels the reference's own trail supports; the twin: deeper than BVH_STACK_SIZE),

@@ -18,7 +18,7 @@ fn.restype = C.c_int
 fn.argtypes = [C.c_void_p] + [C.c_uint32] * 5 + [C.POINTER(vrt.rtapi.ShadeParams), C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
 rd = L.vxrt_debug_read_lpt
 rd.restype = C.c_int
-rd.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+rd.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
 arr = (vrt.rtapi.ShadeParams * nf)(*([p] * nf))
 vrt.rtapi.accel_frames_in_flight(ds.accel, 2)
 prev = prevd = None
@@ -27,11 +27,10 @@ for it in range(3):
     log = torch.zeros((4 * 8 * 256, 16), dtype=torch.int64, device="cuda:0")
     assert fn(ds.accel, W, H, 0, world, nf, arr, 1, buf.data_ptr(), ig.frame_stride, cnt.data_ptr(), log.data_ptr(), None) == 0
     torch.cuda.synchronize()
-    cost = np.zeros(800000, np.uint32); order = np.zeros(400000, np.uint32); tab = np.zeros(32, np.uint32)
-    n = rd(ds.accel, 0, nf, cost.ctypes.data, cost.size, order.ctypes.data, order.size, tab.ctypes.data, None)
+    cost = np.zeros(800000, np.uint32); order = np.zeros(400000, np.uint32)
+    n = rd(ds.accel, 0, nf, cost.ctypes.data, cost.size, order.ctypes.data, order.size, None)
     assert n > 0
-    # the number of tiles of THIS launch: from the table's ranges
-    nt = int(sum(tab[2 * k + 1] for k in range(16)))
+    nt = n        # (the capacity is this launch's tile count: the context has seen no larger set)
     work = cost[:nt].astype(np.float64)                     # what the order is learned from: loop iterations (+2 per leaf-body run)
     dur = cost[2 * nt:3 * nt].astype(np.float64) / 100.0    # how long the tile occupied its wavefront, us
     lg = log.cpu().numpy().astype(np.float64); lg = lg[lg[:, 1] > 0]
@@ -65,5 +64,4 @@ for it in range(3):
             for name, m_ in (("home", w_ & (stolen == 0)), ("stolen", w_ & (stolen > 0))):
                 if m_.sum():
                     print("   started %3d..%3d us, %-6s: %5d tiles, us per unit of work %.2f (duration mean %.1f, work mean %.1f)" % (lo_, hi_, name, m_.sum(), dur[m_].sum() / work[m_].sum(), dur[m_].mean(), work[m_].mean()))
-        print("ranges (first, tiles):", [(int(tab[2 * k]), int(tab[2 * k + 1])) for k in range(16)])
     prev, prevd = work, dur

@@ -17,7 +17,8 @@ for shadow in (1,):
         log = torch.zeros((4 * 8 * 256, 16), dtype=torch.int64, device="cuda:0")
         assert L.vxrt_render_wave_log(ds.accel, W, H, 0, H, C.byref(p), shadow, px.data_ptr(), cnt.data_ptr(), log.data_ptr(), None) == 0
         torch.cuda.synchronize()
-    lg = log.cpu().numpy().astype(np.float64)
+    raw = log.cpu().numpy(); raw[:, 9] &= (1 << 56) - 1      # ([63:56] of entry 9: physical XCD)
+    lg = raw.astype(np.float64)
     lg = lg[lg[:, 1] > 0]
     t0 = lg[:, 0].min()
     start, end, rays = (lg[:, 0] - t0) / 100.0, (lg[:, 1] - t0) / 100.0, lg[:, 2]

@@ -24,8 +24,14 @@ for it in range(3):      # the third set runs with the tile order learned from t
     log = torch.zeros((4 * 8 * 256, 16), dtype=torch.int64, device="cuda:0")
     assert fn(ds.accel, W, H, rank, world, nf, arr, 1, buf.data_ptr(), ig.frame_stride, cnt.data_ptr(), log.data_ptr(), None) == 0
     torch.cuda.synchronize()
-    lg = log.cpu().numpy().astype(np.float64)
-    lg = lg[lg[:, 1] > 0]
+    raw = log.cpu().numpy()
+    live = raw[:, 1] > 0
+    xcd = ((raw[:, 9].astype(np.uint64) >> np.uint64(56)) & np.uint64(15)).astype(np.int64)[live]     # physical XCD of the wavefront (HW_REG_XCC_ID)
+    grp = ((np.arange(raw.shape[0]) // 4) % 8)[live]                                                  # blockIdx % 8 of the wavefront's block
+    raw[:, 9] &= (1 << 56) - 1
+    lg = raw.astype(np.float64)[live]
+    if it == 2:
+        print("   blockIdx %% 8 -> physical XCD of its wavefronts:", {int(g): sorted(set(xcd[grp == g].tolist())) for g in range(8)})
     t0 = lg[:, 0].min()
     start, end, rays, tq = (lg[:, 0] - t0) / 100.0, (lg[:, 1] - t0) / 100.0, lg[:, 2], (lg[:, 15] - t0) / 100.0
     span = end.max()
@@ -43,6 +49,16 @@ for it in range(3):      # the third set runs with the tile order learned from t
     for name, m_ in (("first 10 % to end", early), ("last 10 % to end", late)):
         print("   %-18s: shader clock %.3f GHz; shader clocks per iteration %.0f; fetch section %.3f, finish section %.3f of the lifetime; iterations %.0f, tiles %.1f" %
               (name, ghz[m_].mean(), lg[m_, 12].sum() / max(lg[m_, 3].sum(), 1), lg[m_, 13].sum() / lg[m_, 12].sum(), lg[m_, 14].sum() / lg[m_, 12].sum(), lg[m_, 3].mean(), tiles[m_].mean() / 2))
+        print("   %-18s  clocks per node-body run %.0f, per leaf-body run %.0f; per wavefront: node+leaf bodies %.0f us, fetch %.0f us, finish %.0f us, rest %.0f us, dry polls %.0f us" %
+              ("", lg[m_, 10].sum() / max(lg[m_, 4].sum(), 1), lg[m_, 11].sum() / max(lg[m_, 6].sum(), 1),
+               ((lg[m_, 10] + lg[m_, 11]) / ghz[m_] / 1e3).mean(), (lg[m_, 13] / ghz[m_] / 1e3).mean(), (lg[m_, 14] / ghz[m_] / 1e3).mean(),
+               ((lg[m_, 12] - lg[m_, 10] - lg[m_, 11] - lg[m_, 13] - lg[m_, 14]) / ghz[m_] / 1e3).mean(), (lg[m_, 8] / ghz[m_] / 1e3).mean()))
+    print("   reservations that met a dry shard: %.1f us per wavefront on average, p90 %.1f, max %.1f (shader clocks at the wavefront's clock)" %
+          ((lg[:, 8] / np.maximum(ghz, 0.1) / 1e3).mean(), np.percentile(lg[:, 8] / np.maximum(ghz, 0.1) / 1e3, 90), (lg[:, 8] / np.maximum(ghz, 0.1) / 1e3).max()))
+    for x in range(8):
+        m_ = xcd == x
+        print("   physical XCD %d (home band %d): end p10 %.0f p50 %.0f p90 %.0f us; iterations %.0f; clocks per iteration %.0f; node-body run %.0f clocks; tiles %.1f" %
+              (x, x, *np.percentile(end[m_], (10, 50, 90)), lg[m_, 3].mean(), lg[m_, 12].sum() / max(lg[m_, 3].sum(), 1), lg[m_, 10].sum() / max(lg[m_, 4].sum(), 1), tiles[m_].mean() / 2))
     # how the tail is populated: wavefronts still alive at fractions of the span
     for f in (0.5, 0.6, 0.7, 0.8, 0.9, 0.95):
         print("   alive at %.2f of the span: %d wavefronts" % (f, int(((start <= f * span) & (end > f * span)).sum())), end=";")

@@ -473,11 +473,15 @@ __device__ __forceinline__ void ao_sample_ray(uint32_t x, uint32_t y, uint32_t W
 #ifndef RT_CHUNK
 #define RT_CHUNK 64         // jobs reserved per global atomic (one 8x8 tile)
 #endif
+#ifndef RT_XCC_HOME
+#define RT_XCC_HOME 1         // a wavefront's home queue shard is its physical XCD (0 = blockIdx % 8, which names a group of blocks that share an XCD, not the XCD)
+#endif
 #ifndef RT_QUEUE_DRY_MASK
 #define RT_QUEUE_DRY_MASK 1   // shards a wavefront found handed out are not polled again by the other wavefronts of its workgroup (LDS mask)
 #endif
-#ifndef RT_QUEUE_PEEK
-#define RT_QUEUE_PEEK 0     // 1: load a shard's counter (agent scope) before the atomic that reserves from it; 2: non-temporal load.  Measured, off: -20 % / -47 % (see the fetch section)
+#ifndef RT_STEAL_SPREAD
+#define RT_STEAL_SPREAD 0     // order in which a wavefront visits the other shards once its home shard is handed out: +1, +2, ... (0) or bit-reversed distance (1:
+                              // the helpers of a drained band spread over the remaining ones; measured -1.4 % serial, +-0 elsewhere: profiles/r04_m_steal_spread_ab.txt)
 #endif
 #ifndef QUEUE_SHARDS
 #define QUEUE_SHARDS 8u     // one device-scope counter saturates near 90 dequeues/us
@@ -486,12 +490,7 @@ __device__ __forceinline__ void ao_sample_ray(uint32_t x, uint32_t y, uint32_t W
 // per-frame control block: [0] deferral count (own 128-byte line), then the queue counters of the main
 // launch, of the EXACT launch over the deferred list and of the a-priori EXACT launch
 #define CTL_QUEUE_DWORDS (QUEUE_SHARDS * QUEUE_STRIDE)
-// ... and, behind them, the counters of the main launch's POOL shards (the cheap tiles every band keeps for the end of the launch: see
-// lpt_order_block)
-#define CTL_POOL_OFFSET (32u + 3u * CTL_QUEUE_DWORDS)
-// ... and a last line with the three launches' dry-shard masks (PersistArgs::queue_dry)
-#define CTL_DRY_OFFSET (CTL_POOL_OFFSET + CTL_QUEUE_DWORDS)
-#define CTL_DWORDS (CTL_DRY_OFFSET + 32u)
+#define CTL_DWORDS (32u + 3u * CTL_QUEUE_DWORDS)
 // Frames (camera tiles + their occlusion rays): 7 wavefronts per SIMD (72 VGPRs, 6 stack levels in LDS).  With frames traced in
 // batches -- many tiles per wavefront, so ramp and tail of a launch no longer decide -- occupancy pays: 7 / 8 wavefronts are +5.3 /
 // +5.6 % on the headline frame (one frame per launch: +-1 %, measured in round 2), 8 loses 3 % on serial frames, 7 gains 2 %
@@ -587,11 +586,7 @@ struct PersistArgs {
   // render jobs, optional: longest-processing-time-first order learned from the previous frame of this context
   // (tile_order[queue position] = tile, sorted by cost within each shard's band) and where this frame's cost goes
   const uint32_t* tile_order; uint32_t* tile_cost;
-  // with a learned order: 2 * QUEUE_SHARDS ranges of queue positions, (first tile position, tiles) each -- entry s < QUEUE_SHARDS = the
-  // expensive tiles of band s, most expensive first; entry QUEUE_SHARDS + s = the band's cheap tiles, handed out only when every
-  // band's expensive tiles are gone (counters at queue_pool); nullptr = QUEUE_SHARDS equal ranges of per_shard jobs
-  const uint32_t* shard_tab; uint32_t* queue_pool;
-  uint32_t* queue_dry;            // (unused: the dry-shard mask lives in LDS, per workgroup; see the fetch section)
+  uint32_t shard_rot;             // diagnostic (VXRT_SHARD_ROT): home shard of block b = (b + shard_rot) % QUEUE_SHARDS
   unsigned long long* wave_log;   // STATS only, optional: 16 u64 per wavefront (see vxrt_render_wave_log in the header)
   // batch of frames in one launch (vxrt_render_interleaved_batch): the window's tiles repeat `frame_tiles` apart, frame f = tile /
   // frame_tiles is shaded and lit with pbatch[f]; nullptr = one frame
@@ -690,7 +685,13 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   float ovf_m[RT_STACK_ENTRIES];
   // wave-uniform job-queue state
   bool queue_empty = false;
-  uint32_t shard = blockIdx.x % QUEUE_SHARDS;   // blocks b and b+8 share an XCD (observed dispatch order; speed only)
+  // Home shard = the PHYSICAL XCD the wavefront runs on (HW_REG_XCC_ID, 0..7), so that band s of the frame is traced by the same XCD in every
+  // launch and finds its part of the BVH in that XCD's L2 from the frame before.  Rounds 1-3 took blockIdx % 8: blocks b and b + 8 do share an
+  // XCD, but WHICH one block 0 lands on changes from launch to launch (per-wavefront logs: the group of XCDs a band's wavefronts run on moves
+  // by four between consecutive launches, profiles/r04_l_xcd.txt), so an XCD met another band's working set at every launch.  Speed only:
+  // any wavefront may take any shard's jobs.  (shard_rot: diagnostic rotation of the XCD -> band map.)
+  const uint32_t xcc_id = RT_XCC_HOME ? (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) : blockIdx.x;   // XCC_ID[3:0]
+  const uint32_t shard = (xcc_id + A.shard_rot) % QUEUE_SHARDS;
   uint32_t tries = 0, loc_next = 0, loc_end = 0;
   uint32_t loc_off = 0;           // job id = queue position + loc_off (tile order indirection of render jobs)
   // tile whose cost is being taken for A.tile_cost.  The cost is WORK, not time: loop iterations of the wavefront while it held the tile (a leaf-body
@@ -840,30 +841,24 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     {
       const unsigned long long idle = __ballot(cur == DESC_IDLE);
       if (!queue_empty && idle != 0ull && (JOB == JOB_TRACE || FINISH_MIN > 64u || idle == ~0ull || RT_DEAD_MAX < 64)) {
+        const uint32_t wl_tries0 = tries; const unsigned long long wl_tpoll0 = (STATS && A.wave_log) ? __builtin_readcyclecounter() : 0ull;
         if (loc_next == loc_end) {   // wave-uniform: reserve the next chunk, stealing from other shards when the home shard is dry
-          // the sequence of shards a wavefront works through: its home shard (= its XCD's band), the other bands' shards, then -- render jobs
-          // with a learned order -- the POOL shards in the same rotation: every band's cheap tiles, kept for the end of the launch so that what
-          // the wavefronts hold when the queue runs dry is short (a launch ends a whole expensive tile -- 4x the mean -- after its queue is
-          // empty otherwise: profiles/r04_d_wave_balance_batch.txt)
-          const bool tabbed = JOB != JOB_TRACE && !EXACT && A.shard_tab != nullptr;
-          const uint32_t n_seq = tabbed ? 2u * QUEUE_SHARDS : QUEUE_SHARDS;
           // shards a wavefront of this WORKGROUP has found handed out (LDS: no memory traffic): not polled again by its other three.  Every
           // wavefront used to poll every shard once before it ends -- 8 failing read-modify-writes each on the eight hottest lines of the
-          // system, more than the launch's successful ones, all within its last third.  (Published through memory instead -- a mask word the
-          // wavefronts read with agent scope and OR into -- the frame is 30 % SLOWER: the OR's of a whole machine land on one line:
-          // profiles/r04_h_global_dry_mask_ab.txt.  Anything that adds traffic next to these counters loses.)
+          // system, more than the launch's successful ones, all within its last third: serial frames +6 %, ray buffers +4 %
+          // (profiles/r04_h_dry_mask_ab.txt).  Anything that ADDS traffic next to these counters loses, whatever it saves: the same mask
+          // published through memory (a word read with agent scope and OR-ed into) -30 %, a look at the counter before the read-modify-write
+          // -20 % (agent-scope load) / -47 % (non-temporal load, which turns every queue atomic into a round trip to memory), several tiles per
+          // reservation -7 % (neighbouring tiles traced one after the other by ONE wavefront share less than the same tiles traced at the same
+          // time by four: the queue's order is what keeps a CU's L1 warm) -- profiles/r04_h_*.txt.
           uint32_t dry = RT_QUEUE_DRY_MASK ? *(volatile uint32_t*)&s_dry : 0u;
-          while (tries < n_seq) {
-            const uint32_t sid = tries < QUEUE_SHARDS ? shard : QUEUE_SHARDS + shard;
-            if (RT_QUEUE_DRY_MASK && ((dry >> sid) & 1u)) { shard = (shard + 1u) % QUEUE_SHARDS; ++tries; continue; }
-            uint32_t s_lo, s_n, chk_a, chk_b;
-            if (tabbed) {
-              s_lo = A.shard_tab[2u * sid] << 6; s_n = A.shard_tab[2u * sid + 1u] << 6;
-              chk_a = 0u; chk_b = s_n;                    // in range <=> the shard holds a tile
-            } else {
-              s_lo = shard * per_shard; s_n = 0u;
-              chk_a = s_lo; chk_b = n_jobs;               // in range <=> the shard starts inside the job range
-            }
+          while (tries < QUEUE_SHARDS) {
+            // the shards in the order this wavefront visits them: its home shard (its XCD's band), then RT_STEAL_SPREAD ? the others in
+            // bit-reversed distance (+4, +2, +6, +1, +5, +3, +7: the helpers of a drained band spread over the remaining ones) : +1, +2, ...
+            const uint32_t step = RT_STEAL_SPREAD ? (((tries & 1u) << 2) | (tries & 2u) | ((tries >> 2) & 1u)) : tries;
+            const uint32_t sid = (shard + step) % QUEUE_SHARDS;
+            if (RT_QUEUE_DRY_MASK && ((dry >> sid) & 1u)) { ++tries; continue; }
+            const uint32_t s_lo = sid * per_shard;
             // a shard past the end of the job range costs no atomic (an EXACT launch with nothing deferred used to pay eight per
             // wavefront to find eight empty shards).  Written as an explicit range test: folded into `s_n == 0` on a select, this
             // compiler dropped the `s_lo < n_jobs` half of the condition and the wavefronts ran past the end of the job list.
@@ -871,24 +866,12 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             // in every instantiation's listing (tests/test_build_guards.py: one RTGUARD before the kernel's first queue atomic).
             uint32_t in_range;
             asm volatile("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0 ; RTGUARD shard_range" : "=s"(in_range)
-                         : "s"(__builtin_amdgcn_readfirstlane(chk_a)), "s"(__builtin_amdgcn_readfirstlane(chk_b)) : "scc");   // (both wave-uniform)
-            if (!in_range) { shard = (shard + 1u) % QUEUE_SHARDS; ++tries; continue; }
-            if (!tabbed) s_n = min(per_shard, n_jobs - s_lo);
-            uint32_t* const qc = (sid < QUEUE_SHARDS ? A.queue : A.queue_pool - QUEUE_SHARDS * QUEUE_STRIDE) + sid * QUEUE_STRIDE;
-            // (RT_QUEUE_PEEK, off) Look before the read-modify-write: a counter only grows, so a load that already shows the shard handed out
-            // is final, and the failing atomics of a launch's end (every wavefront polls every dry shard once) would go away.  Measured: ANY
-            // extra access to a counter's cache line per tile fetch costs far more than those atomics -- an agent-scope load -20 % on the
-            // headline frame, a non-temporal one -47 % (profiles/r04_h_queue_peek_ab.txt): the line is the hottest in the system.
-            // (agent-scope relaxed load: served by the L2, where the atomics execute.  A non-temporal load here -- which bypasses the L2 --
-            // made every queue atomic a round trip to memory and the whole frame 1.9x slower: profiles/r04_h_queue_peek_ab.txt)
-            uint32_t base = RT_QUEUE_PEEK == 2 ? __builtin_nontemporal_load(qc) : (RT_QUEUE_PEEK == 1 ? __hip_atomic_load(qc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
-            // (One tile per reservation.  Several per atomic -- "guided" chunks of 4 or 2 tiles while a shard holds plenty -- measured -7 % on
-            // serial frames and -4 % pipelined, profiles/r04_h_guided_ab.txt: neighbouring tiles traced one after the other by ONE wavefront
-            // share less than the same tiles traced at the same time by four; the queue's order is what keeps a CU's L1 warm.)
-            if (base < s_n) {
-              if (lane == 0) base = atomicAdd(qc, (uint32_t)RT_CHUNK);
-              base = __shfl(base, 0);
-            }
+                         : "s"(__builtin_amdgcn_readfirstlane(s_lo)), "s"(__builtin_amdgcn_readfirstlane(n_jobs)) : "scc");   // (both wave-uniform)
+            if (!in_range) { ++tries; continue; }
+            const uint32_t s_n = min(per_shard, n_jobs - s_lo);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(A.queue + sid * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
+            base = __shfl(base, 0);
             if (base < s_n) {
               loc_next = s_lo + base; loc_end = s_lo + min(base + (uint32_t)RT_CHUNK, s_n);
               break;
@@ -898,10 +881,10 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
               if (lane == 0) atomicOr(&s_dry, 1u << sid);
               dry |= 1u << sid;
             }
-            shard = (shard + 1u) % QUEUE_SHARDS;
             ++tries;
           }
-          if (tries >= n_seq) { queue_empty = true; if (STATS && A.wave_log && !wl_tq) wl_tq = wall_clock64(); }
+          if (tries >= QUEUE_SHARDS) { queue_empty = true; if (STATS && A.wave_log && !wl_tq) wl_tq = wall_clock64(); }
+          if (STATS && A.wave_log && !USE_TOP && tries != wl_tries0 && lane == 0) wl_no23 += (unsigned)(__builtin_readcyclecounter() - wl_tpoll0);   // (diagnostic: shader clocks of the reservations that met a dry shard)
         }
         uint32_t avail = loc_end - loc_next;
         if (JOB != JOB_TRACE && !EXACT) {
@@ -1242,7 +1225,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     if (lane == 0) {
       unsigned long long* w = A.wave_log + 16ull * (blockIdx.x * (uint32_t)WG_WAVES + (threadIdx.x >> 6));
       w[13] = wl_tf; w[14] = wl_tfin; w[15] = wl_tq;
-      w[0] = t_first; w[1] = wall_clock64(); w[2] = s; w[8] = wl_no23; w[9] = wl_no3; w[10] = wl_tn; w[11] = wl_tl; w[12] = __builtin_readcyclecounter() - wl_tstart;
+      w[0] = t_first; w[1] = wall_clock64(); w[2] = s; w[8] = wl_no23; w[9] = (unsigned long long)wl_no3 | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 56);   // [63:56] physical XCD w[10] = wl_tn; w[11] = wl_tl; w[12] = __builtin_readcyclecounter() - wl_tstart;
       w[3] = wl_iter; w[4] = wl_node_x; w[5] = wl_node_l; w[6] = wl_leaf_x; w[7] = wl_leaf_l;
     }
   }
@@ -1270,70 +1253,23 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
 // `base_order` (optional): the static order the queue positions have without learning (the band-major order of a batch of frames); the
 // tiles of queue positions [lo, hi) are then base_order[lo..hi), and it is those that are sorted into order[lo..hi).
 //
-// Cheap tiles last (round 4).  Sorting inside a band leaves the END of a launch to whatever band drains last -- the expensive one, whose
-// cheapest tiles still cost several times the frame's mean -- and a launch then ends one such tile after its queue ran dry: per-wavefront
-// logs of a rank's set of ten frames show the wavefronts ending uniformly over the last 470 of 1,800 us (profiles/r04_d_wave_balance_batch.txt).
-// So each band's tiles are split at ONE cost threshold, the same for all bands: the expensive ones stay the band's shard (most expensive
-// first, band -> XCD locality kept), the cheap ones -- `pool_permille` of the frame's total cost, 0 = none -- form the band's POOL shard, and
-// the kernel hands out pool shards only when every band's expensive tiles are gone: what the wavefronts hold when the queue runs dry is a
-// cheap tile.  Every sort block computes the threshold itself from the histogram of ALL tiles (same integer arithmetic, same result).
-// Output: order[lo .. lo + n_heavy) and order[pool_base + lo .. + n_light), and the two ranges in tab[2 * shard], tab[2 * (QUEUE_SHARDS + shard)].
+// Measured and rejected in round 4 (profiles/r04_k_pool_lpt_ab.txt): "cheap tiles last" -- each band's tiles split at one cost threshold, the
+// cheap ones (a quarter of the frame's cost) handed out only when every band's expensive tiles are gone, so that what the wavefronts hold
+// when the queue runs dry is a cheap tile: serial frames -9 %, a rank's sets of frames -2 .. -5 %.  The end of a launch is not long because of
+// WHICH tiles are last: per-wavefront logs show every XCD doing the same number of loop iterations, and one half of the XCDs taking 20 % more
+// clocks for each -- whatever band it traces (tools/wave_balance_batch.py, profiles/r04_l_xcd.txt).
 __device__ __forceinline__ uint32_t lpt_cls(uint32_t c) {       // monotone cost class: 5-bit exponent, 6-bit mantissa
   if (c < 64u) return c;                                  // exponents 0..5 collapse onto the small values
   const uint32_t e = 31u - (uint32_t)__clz((int)c);       // 6..31
   return ((e - 5u) << 6) | ((c >> (e - 6u)) & 63u);       // 64 .. 1727
 }
-__device__ __forceinline__ unsigned long long lpt_cls_value(uint32_t k) {   // smallest cost of class k
-  if (k < 64u) return k;
-  const uint32_t e = (k >> 6) + 5u;
-  return (unsigned long long)(64u + (k & 63u)) << (e - 6u);
-}
 __device__ void lpt_order_block(uint32_t shard, const uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
-                                uint32_t n_tiles, uint32_t tiles_per_shard, uint32_t* hist /* LDS, 2048 + 16 words */,
-                                const uint32_t* __restrict__ base_order = nullptr, uint32_t* __restrict__ tab = nullptr,
-                                uint32_t pool_permille = 0u) {
+                                uint32_t n_tiles, uint32_t tiles_per_shard, uint32_t* hist /* LDS, 2048 + 8 words */,
+                                const uint32_t* __restrict__ base_order = nullptr) {
   const uint32_t lo = shard * tiles_per_shard;
   const uint32_t hi = min(lo + tiles_per_shard, n_tiles);
-  const uint32_t pool_base = QUEUE_SHARDS * tiles_per_shard;
+  if (lo >= hi) return;   // (block-uniform)
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (lo >= hi) {   // (block-uniform) an empty band: both of its ranges are empty
-    if (tab && threadIdx.x == 0) { tab[2u * shard] = lo; tab[2u * shard + 1u] = 0u; tab[2u * (QUEUE_SHARDS + shard)] = pool_base + lo; tab[2u * (QUEUE_SHARDS + shard) + 1u] = 0u; }
-    return;
-  }
-  // ---- the threshold class: the cheapest classes that together hold pool_permille / 1000 of the total cost (class value x count)
-  uint32_t c_star = 0u;       // classes below it go to the pool
-  if (tab && pool_permille) {
-    for (uint32_t i = threadIdx.x; i < 2048u; i += 256u) hist[i] = 0u;
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < n_tiles; t += 256u) atomicAdd(&hist[lpt_cls(cost[t])], 1u);   // ascending classes here
-    __syncthreads();
-    unsigned long long w[8], sum = 0ull;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { w[k] = (unsigned long long)hist[threadIdx.x * 8u + k] * lpt_cls_value(threadIdx.x * 8u + k); sum += w[k]; }
-    unsigned long long inc = sum;
-    for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += y; }
-    unsigned long long* wsum = (unsigned long long*)(hist + 2048u);    // 4 x u64 behind the counters
-    __syncthreads();                                                     // (everyone has read its counters)
-    if (lane == 63u) wsum[wave] = inc;
-    __syncthreads();
-    unsigned long long base = inc - sum, total = 0ull;
-    for (uint32_t q = 0; q < 4u; ++q) { if (q < wave) base += wsum[q]; total += wsum[q]; }
-    const unsigned long long want = total / 1000ull * pool_permille;
-    __syncthreads();
-    if (threadIdx.x == 0) hist[2048u + 8u] = 0u;
-    __syncthreads();
-    // the first class whose inclusive prefix exceeds `want` is the threshold: exactly one thread holds it (prefixes are monotone)
-    unsigned long long run = base;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const unsigned long long before = run;
-      run += w[k];
-      if (before <= want && run > want) hist[2048u + 8u] = threadIdx.x * 8u + k;
-    }
-    __syncthreads();
-    c_star = hist[2048u + 8u];
-    __syncthreads();
-  }
   for (uint32_t i = threadIdx.x; i < 2048u; i += 256u) hist[i] = 0u;
   __syncthreads();
   for (uint32_t t = lo + threadIdx.x; t < hi; t += 256u) atomicAdd(&hist[2047u - lpt_cls(cost[base_order ? base_order[t] : t])], 1u);   // descending
@@ -1351,18 +1287,9 @@ __device__ void lpt_order_block(uint32_t shard, const uint32_t* __restrict__ cos
 #pragma unroll
   for (int k = 0; k < 8; ++k) { hist[threadIdx.x * 8u + k] = base; base += v[k]; }
   __syncthreads();
-  // tiles of class >= c_star are the band's expensive ones: descending index <= 2047 - c_star, i.e. the first n_heavy sorted positions
-  const uint32_t n_band = hi - lo;
-  const uint32_t n_heavy = c_star == 0u ? n_band : hist[2048u - c_star];
-  __syncthreads();
   for (uint32_t t = lo + threadIdx.x; t < hi; t += 256u) {
     const uint32_t tile = base_order ? base_order[t] : t;
-    const uint32_t r = atomicAdd(&hist[2047u - lpt_cls(cost[tile])], 1u);
-    order[r < n_heavy ? lo + r : pool_base + lo + (r - n_heavy)] = tile;
-  }
-  if (tab && threadIdx.x == 0) {
-    tab[2u * shard] = lo; tab[2u * shard + 1u] = n_heavy;
-    tab[2u * (QUEUE_SHARDS + shard)] = pool_base + lo; tab[2u * (QUEUE_SHARDS + shard) + 1u] = n_band - n_heavy;
+    order[lo + atomicAdd(&hist[2047u - lpt_cls(cost[tile])], 1u)] = tile;
   }
 }
 
@@ -1377,10 +1304,10 @@ __global__ __launch_bounds__(256) void rt_shade_kernel(SceneDev sc, ShadeParams 
                                                       uint32_t lpt_blocks, const uint32_t* __restrict__ lpt_cost, uint32_t* __restrict__ lpt_order,
                                                       uint32_t lpt_tiles, uint32_t lpt_per_shard,
                                                       uint32_t batch = 1, const ShadeParams* __restrict__ pbatch = nullptr, uint64_t dst_frame_stride = 0,
-                                                      const uint32_t* __restrict__ lpt_base = nullptr, uint32_t* __restrict__ lpt_tab = nullptr, uint32_t lpt_pool_permille = 0) {
+                                                      const uint32_t* __restrict__ lpt_base = nullptr) {
   // the first lpt_blocks workgroups sort the frame's tiles by cost for the context's next frame (see lpt_order_block)
-  __shared__ __attribute__((aligned(16))) uint32_t s_hist[2048 + 16];
-  if (blockIdx.x < lpt_blocks) { lpt_order_block(blockIdx.x, lpt_cost, lpt_order, lpt_tiles, lpt_per_shard, s_hist, lpt_base, lpt_tab, lpt_pool_permille); return; }
+  __shared__ uint32_t s_hist[2048 + 8];
+  if (blockIdx.x < lpt_blocks) { lpt_order_block(blockIdx.x, lpt_cost, lpt_order, lpt_tiles, lpt_per_shard, s_hist, lpt_base); return; }
   const uint32_t blk = blockIdx.x - lpt_blocks;
   // last kernel of a frame: every user of the frame's control block (queue counters, deferral count)
   // has finished, so zero it here for the context's next frame instead of paying fill launches per frame
@@ -2152,7 +2079,7 @@ struct FrameCtx {
   uint32_t* bcount = nullptr;  // device: rays appended to the level being built
   // tile cost of the last frame and the order derived from it (render jobs, see lpt_order_kernel)
   // one slot per batch size (slot 1 = single frames): a frame loop that alternates batch sizes keeps what it learned for each
-  struct Lpt { uint32_t* cost = nullptr; uint32_t* order = nullptr; uint32_t* tab = nullptr; uint32_t cap = 0; uint32_t key[6] = {0, 0, 0, 0, 0, 0}; bool valid = false; };   // tab: the 2 * QUEUE_SHARDS (first position, tiles) ranges of `order`
+  struct Lpt { uint32_t* cost = nullptr; uint32_t* order = nullptr; uint32_t cap = 0; uint32_t key[6] = {0, 0, 0, 0, 0, 0}; bool valid = false; };
   Lpt lpt[VXRT_MAX_BATCH + 1];
   // ambient-occlusion pass (allocated on first use), one entry per pixel of the window
   float4* ao_geo = nullptr; float4* ao_nrm = nullptr; float4* ao_col = nullptr; uint32_t* ao_cnt = nullptr;
@@ -2194,7 +2121,7 @@ static void accel_free(vxrt_accel* a) {
   for (uint32_t k = 0; k <= VXRT_MAX_BATCH; ++k) (void)hipFree(a->batch_order[k]);
   for (FrameCtx& c : a->ctx) {
     (void)hipFree(c.hitbuf); (void)hipFree(c.defer); (void)hipFree(c.ctl); (void)hipFree(c.bcount);
-    for (FrameCtx::Lpt& l : c.lpt) { (void)hipFree(l.cost); (void)hipFree(l.order); (void)hipFree(l.tab); }
+    for (FrameCtx::Lpt& l : c.lpt) { (void)hipFree(l.cost); (void)hipFree(l.order); }
     (void)hipFree(c.ao_geo); (void)hipFree(c.ao_nrm); (void)hipFree(c.ao_col); (void)hipFree(c.ao_cnt); (void)hipFree(c.ao_rays); (void)hipFree(c.ao_tmax); (void)hipFree(c.ao_hits); (void)hipFree(c.ao_list); (void)hipFree(c.ao_hdr);
     (void)hipFree(c.bin_hist); (void)hipFree(c.bin_keys); (void)hipFree(c.bin_order);
     for (FrameCtx::Level& l : c.lv) {
@@ -2410,9 +2337,9 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   // next use of this context clears it with one fill
   c->ctl_dirty = true;
   A.defer_count = c->ctl; A.defer_list = c->defer; A.defer_cap = A.total;
-  A.queue = c->ctl + 32; A.queue_dry = c->ctl + CTL_DRY_OFFSET;
+  A.queue = c->ctl + 32;
   PersistArgs X = A;
-  X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS; X.queue_dry = c->ctl + CTL_DRY_OFFSET + 1;
+  X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
   X.total_dev = nullptr;   // the EXACT launch takes its count from the deferral list
   X.order = nullptr;
   ShadeParams p{};
@@ -2681,8 +2608,10 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   }
   if (ensure_defer(c, A.total, s) != 0) return fail();
   A.defer_count = c->ctl; A.defer_list = c->defer; A.defer_cap = A.total;
-  A.queue = c->ctl + 32; A.queue_dry = c->ctl + CTL_DRY_OFFSET;
+  A.queue = c->ctl + 32;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
+  static const uint32_t shard_rot_env = [] { const char* e = getenv("VXRT_SHARD_ROT"); return e ? (uint32_t)atoi(e) : 0u; }();
+  A.shard_rot = shard_rot_env;
   // longest tile first, learned from this context's previous frame of the same window (VXRT_LPT=0 disables).  Only
   // with one frame in flight: overlapped frames fill each other's tails already
   static const bool lpt_on = [] { const char* e = getenv("VXRT_LPT"); return !(e && e[0] == '0'); }();
@@ -2700,25 +2629,21 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   // traced next to their screen neighbours, and there the tails are filled anyway.
   const bool lpt = lpt_on && (!stats || wave_log) && n_tiles >= LPT_MIN_TILES &&
                    (batch == 1 ? a->n_ctx == 1 : (lpt_batch_on && n_tiles <= LPT_BATCH_MAX_TILES));
-  // share of the frame's cost kept in the pool shards (cheap tiles last): VXRT_POOL_PERMILLE, 0 = none (plain longest-first inside the bands)
-  static const uint32_t pool_permille = [] { const char* e = getenv("VXRT_POOL_PERMILLE"); const int v = e ? atoi(e) : 250; return (uint32_t)(v < 0 ? 0 : (v > 900 ? 900 : v)); }();
   FrameCtx::Lpt& L = c->lpt[batch];
   if (lpt) {
     if (L.cap < n_tiles) {
       if (hipStreamSynchronize(s) != hipSuccess) return fail();
-      (void)hipFree(L.cost); (void)hipFree(L.order); (void)hipFree(L.tab);
-      L.cost = L.order = L.tab = nullptr; L.cap = 0; L.valid = false;
-      // order: the bands' expensive tiles in QUEUE_SHARDS ranges of per_shard tiles, then their cheap tiles in as many again (lpt_order_block)
+      (void)hipFree(L.cost); (void)hipFree(L.order);
+      L.cost = L.order = nullptr; L.cap = 0; L.valid = false;
       // (cost: n entries + n start clocks + n durations + n steal distances behind them, the latter three written by the wave-log build only)
-      if (hipMalloc((void**)&L.cost, (size_t)n_tiles * 4 * 4) != hipSuccess || hipMalloc((void**)&L.order, (size_t)2 * QUEUE_SHARDS * (A.per_shard >> 6) * 4) != hipSuccess ||
-          hipMalloc((void**)&L.tab, (size_t)4 * QUEUE_SHARDS * 4) != hipSuccess) return fail();
+      if (hipMalloc((void**)&L.cost, (size_t)n_tiles * 4 * 4) != hipSuccess || hipMalloc((void**)&L.order, (size_t)n_tiles * 4) != hipSuccess) return fail();
       L.cap = n_tiles;
     }
     const uint32_t key[6] = {width, height, y0, y1, (uint32_t)shadow | (stride << 1), (ao ? 1u : 0u) | (batch << 1)};
     if (memcmp(key, L.key, sizeof key) != 0) { L.valid = false; memcpy(L.key, key, sizeof key); }
-    if (!L.cost || !L.order || !L.tab) return fail();   // (whatever happened above: no launch with a missing table)
+    if (!L.cost || !L.order) return fail();   // (whatever happened above: no launch with a missing table)
     A.tile_cost = L.cost;
-    if (L.valid) { A.tile_order = L.order; A.shard_tab = L.tab; A.queue_pool = c->ctl + CTL_POOL_OFFSET; }   // else: the static order (identity, or the batch's band-major order set above)
+    if (L.valid) A.tile_order = L.order;      // else: the static order (identity, or the batch's band-major order set above)
     else if (batch == 1) A.tile_order = nullptr;
   }
   // a-priori EXACT list (camera rays with u == 0 or v == 0), rebuilt only when the window changes.  The list of a batch is the
@@ -2753,7 +2678,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   // `s`: it writes hit records the previous frame's shading pass may still be reading), concurrent with
   // the main launch; then the main launch and the EXACT launch over whatever the main one deferred
   PersistArgs X = A, X0 = A;
-  X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS; X.queue_dry = c->ctl + CTL_DRY_OFFSET + 1;
+  X.queue = c->ctl + 32 + CTL_QUEUE_DWORDS;
   c->ctl_dirty = true;   // until the shading pass that zeroes the block again is enqueued
   const bool side_launch = ap_count != 0;
   // the a-priori EXACT launch needs a few workgroups (3,000 rays of a 1080p frame = 12); the main launch leaves that many slots
@@ -2772,7 +2697,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   hipStream_t side = c->side;
   if (side_launch) {
     if (hipEventRecord(c->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, c->ev_in, 0) != hipSuccess) return fail();
-    X0.queue = c->ctl + 32 + 2 * CTL_QUEUE_DWORDS; X0.queue_dry = c->ctl + CTL_DRY_OFFSET + 2;
+    X0.queue = c->ctl + 32 + 2 * CTL_QUEUE_DWORDS;
     X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = ap_count;
   }
   // A window that is small against the machine (one rank's share of a frame split N ways: at 1080p / 8 GPUs 4,080 tiles for 6,096
@@ -2835,10 +2760,10 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   dim3 sgrid((uint32_t)((npx + 255) / 256) + lpt_blocks);
   if (stats) hipLaunchKernelGGL(rt_shade_kernel<true>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl,
                                 lpt_blocks, (const uint32_t*)L.cost, L.order, n_tiles, A.per_shard >> 6, 1u, (const ShadeParams*)nullptr, (uint64_t)0,
-                                batch > 1 ? (const uint32_t*)a->batch_order[batch] : (const uint32_t*)nullptr, L.tab, pool_permille);
+                                batch > 1 ? (const uint32_t*)a->batch_order[batch] : (const uint32_t*)nullptr);
   else       hipLaunchKernelGGL(rt_shade_kernel<false>, sgrid, block, 0, s, sc, p, width, height, y0, y1, row_step, tiles_y * 8u, A.utab, A.vtab, (const HitRec*)c->hitbuf, dst, (HitRec*)hits, colors, counters, c->ctl,
                                 lpt_blocks, (const uint32_t*)L.cost, L.order, n_tiles, A.per_shard >> 6, batch, (const ShadeParams*)c->pbatch, dst_frame_stride,
-                                batch > 1 ? (const uint32_t*)a->batch_order[batch] : (const uint32_t*)nullptr, L.tab, pool_permille);
+                                batch > 1 ? (const uint32_t*)a->batch_order[batch] : (const uint32_t*)nullptr);
   if (hipGetLastError() != hipSuccess) return fail();
   if (lpt_sort) L.valid = true;
   c->ctl_dirty = false;
@@ -3027,23 +2952,16 @@ int vxrt_debug_read_control(vxrt_accel_t* a, uint32_t ctx, uint32_t* out, uint32
   return hipMemcpy(out, a->ctx[ctx].ctl, (size_t)n_dwords * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
-// diagnostic (tools): what frame context `ctx` learned for sets of `batch` frames -- cost[n] (100 MHz clocks a tile occupied its wavefront
-// in the last launch; + n start clocks behind them when that launch was a wave-log one), order[2 * QUEUE_SHARDS * per_shard] and the
-// 2 * QUEUE_SHARDS (first position, tiles) ranges.  Returns the number of tiles, -1 on error.
-int vxrt_debug_read_lpt(vxrt_accel_t* a, uint32_t ctx, uint32_t batch, uint32_t* cost, uint32_t cost_cap, uint32_t* order, uint32_t order_cap, uint32_t* tab32, void* stream) {
+// diagnostic (tools/tile_tail.py): what frame context `ctx` learned for sets of `batch` frames -- cost[n] (loop iterations of the wavefront
+// that traced the tile in the last launch; after a wave-log launch n start clocks, n durations in 100 MHz clocks and n steal distances
+// follow) and the order[n] derived from it.  Returns the capacity in tiles, -1 on error.
+int vxrt_debug_read_lpt(vxrt_accel_t* a, uint32_t ctx, uint32_t batch, uint32_t* cost, uint32_t cost_cap, uint32_t* order, uint32_t order_cap, void* stream) {
   if (!a || ctx >= MAX_FRAMES_IN_FLIGHT || batch > VXRT_MAX_BATCH) return -1;
   FrameCtx::Lpt& L = a->ctx[ctx].lpt[batch];
-  if (!L.cost || !L.order || !L.tab) return -1;
+  if (!L.cost || !L.order) return -1;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
   if (cost && hipMemcpy(cost, L.cost, (size_t)std::min<uint32_t>(cost_cap, 4u * L.cap) * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if (tab32 && hipMemcpy(tab32, L.tab, 4u * QUEUE_SHARDS * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if (order) {
-    uint32_t t[4 * QUEUE_SHARDS];
-    if (hipMemcpy(t, L.tab, sizeof t, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    uint32_t hi = 0;
-    for (uint32_t k = 0; k < 2 * QUEUE_SHARDS; ++k) hi = std::max(hi, t[2 * k] + t[2 * k + 1]);
-    if (hipMemcpy(order, L.order, (size_t)std::min(order_cap, hi) * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  }
+  if (order && hipMemcpy(order, L.order, (size_t)std::min(order_cap, L.cap) * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int)L.cap;
 }
 
