@@ -265,6 +265,18 @@ class RefRcScene:
             out[i] = (d.value, bc[0], bc[1], bc[2], bi.value, ti.value)
         return out
 
+    def radiance(self, rays, max_depth, light12):
+        """The reference's Trace (render.h:210-277, iterative mirror bounce) on arbitrary rays: (colours [n,3] f32, rgb8 [n] u32)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        light12 = np.ascontiguousarray(light12, np.float32)
+        col = np.zeros((len(rays), 3), np.float32)
+        px = np.zeros(len(rays), np.uint32)
+        L = ref_rc()
+        L.rcref_radiance.restype = C.c_int
+        L.rcref_radiance.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rcref_radiance(self.h, _p(rays), len(rays), int(max_depth), _p(light12), _p(col), _p(px))
+        return col, px
+
     def close(self):
         if self.h:
             ref_rc().rcref_scene_destroy(self.h)

@@ -158,6 +158,36 @@ uint64_t rcref_render_buffers(const void* const* ptrs, uint32_t tlas_root, uint3
   return n;
 }
 
+// Radiance of ARBITRARY rays through the reference's Trace (render.h:210-277: the iterative mirror bounce with reflective instances,
+// reflectivity from the instance record, texSample of the instance's texture) -- e.g. for the RTU test's own camera rays.  This is what
+// pins the RTU path's mirror arm (shaders/closest.cpp:95-121, same formulas: R = normalize(d - 2 N (N.d)), origin I + R * 0.001,
+// colour = diffuse * (1 - r) + r * next) to reference object code: the RTU shaders themselves only build for RISC-V.
+// light12 = light_pos, light_color, ambient_color, background_color.  out_rgb: 3 floats per ray; out_rgb8 (optional): RGB32FtoRGB8 of it.
+int rcref_radiance(void* h, const float* rays6, uint64_t n, uint32_t max_depth, const float* light12, float* out_rgb, uint32_t* out_rgb8) {
+  auto sc = ((rcref_scene_t*)h)->scene;
+  kernel_arg_t a{};
+  a.tri_addr = (uint64_t)sc->tri_buf().data();
+  a.triEx_addr = (uint64_t)sc->triEx_buf().data();
+  a.triIdx_addr = (uint64_t)sc->triIdx_buf().data();
+  a.bvh_addr = (uint64_t)sc->bvh_nodes().data();
+  a.tlas_addr = (uint64_t)sc->tlas_nodes().data();
+  a.blas_addr = (uint64_t)sc->blas_nodes().data();
+  a.tex_addr = (uint64_t)sc->tex_buf().data();
+  a.tlas_root = sc->tlas_root();
+  a.samples_per_pixel = 1; a.max_depth = max_depth;
+  a.light_pos = float3_t(light12[0], light12[1], light12[2]);
+  a.light_color = float3_t(light12[3], light12[4], light12[5]);
+  a.ambient_color = float3_t(light12[6], light12[7], light12[8]);
+  a.background_color = float3_t(light12[9], light12[10], light12[11]);
+  for (uint64_t i = 0; i < n; ++i) {
+    ray_t r{float3_t(rays6[6 * i], rays6[6 * i + 1], rays6[6 * i + 2]), float3_t(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5])};
+    float3_t c = Trace(r, &a);
+    out_rgb[3 * i] = c.x; out_rgb[3 * i + 1] = c.y; out_rgb[3 * i + 2] = c.z;
+    if (out_rgb8) out_rgb8[i] = RGB32FtoRGB8(c);
+  }
+  return 0;
+}
+
 // one ray through the reference's TLASIntersect (hit record) -- for traversal-only fixtures
 void rcref_trace(void* h, const float* ray6, float* out_dist, float* out_bc3, uint32_t* out_blas, uint32_t* out_tri) {
   auto sc = ((rcref_scene_t*)h)->scene;

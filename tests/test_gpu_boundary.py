@@ -137,6 +137,22 @@ def test_mirror_bounce_through_vx_api(vrt, po, gpu_device):
     tr.close()
 
 
+def test_mirror_bounce_through_vx_api_matches_the_reference_twin(vrt, golden, gpu_device):
+    """The same pin through the drop-in boundary: the reference-built RTU buffers of tests/golden/mirror_trio.npz (three instances,
+    reflectivity 0 / 0.5 / 0.3 in their records) uploaded with vx_copy_to_dev, kernel_arg_t::max_depth = 3, vx_start: the pixels
+    equal what the reference's software twin (raycast/render.h) returns for these camera rays."""
+    g = golden("mirror_trio")
+    w, h = int(g["width"]), int(g["height"])
+    L = g["light12"]
+    tr = vrt.tracer.Tracer(w, h, max_depth=3)
+    tr.init(g)
+    tr.setup(light_pos=tuple(L[0:3]), light_color=tuple(L[3:6]), ambient=tuple(L[6:9]), background=tuple(L[9:12]))
+    px = tr.run()
+    assert np.array_equal(px, g["rgb8_d3"]), "%d pixels differ" % int((px != g["rgb8_d3"]).sum())
+    assert not np.array_equal(px, g["rgb8_d1"])
+    tr.close()
+
+
 def test_runs_do_not_rebuild_or_reallocate(vrt, gpu_device):
     """The reference host re-uploads kernel_arg_t for every run (tracer.cpp:272-281: vx_upload_bytes -> a new buffer) and
     our mirror frees the previous one: neither may cost an acceleration-layout build or a hipMalloc per run."""

@@ -81,3 +81,21 @@ def test_rng_equals_the_reference_helpers_live(po):
         a, b = po.rng(seed, 512), po.rng(seed, 512, po.ref())
         for x, y in zip(a, b):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+def test_mirror_fixtures_equal_the_reference_twin_live(po, golden, tmp_path):
+    """tests/golden/mirror_*.npz regenerated from the reference's object code now (oracle/gen_golden_mirror.py: both reference scene
+    builders on the same OBJs, the twin's Trace on the RTU camera rays): same buffers, same radiance, bit for bit."""
+    if not po.have_ref_rc():
+        pytest.skip("oracle/_ref/libvxref_rc.so not built")
+    import importlib
+    gm = importlib.import_module("oracle.gen_golden_mirror")
+    gm.OUT = str(tmp_path)
+    gm.TMP = str(tmp_path / "objs")
+    gm.main()
+    for name in ("mirror_teapot", "mirror_trio"):
+        want = golden(name)
+        with np.load(tmp_path / (name + ".npz")) as z:
+            assert sorted(z.files) == sorted(want.keys())
+            for k in z.files:
+                assert np.atleast_1d(z[k]).tobytes() == np.atleast_1d(want[k]).tobytes(), (name, k)
