@@ -518,6 +518,8 @@ def main():
         elif multi and a.shard == "tilerows":
             rtapi.render_interleaved(ds.accel, W, H, rank, world, params, buf.data_ptr(), shadow, None, None, count_ptr, sp)
         else:
+            if count_ptr is None and os.environ.get("VXRT_BENCH_COUNT_RAYS"):      # (diagnostic: what the optional rays counter costs a frame)
+                count_ptr = counters.data_ptr()
             rtapi.render(ds.accel, W, H, y0, y1, params, buf.data_ptr(), shadow, None, None, count_ptr, sp)
 
     # rays per step on this rank (primary + shadow), counted once by the kernel itself

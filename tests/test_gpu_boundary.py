@@ -119,6 +119,51 @@ def test_host_program_renders_and_matches(vrt, po, gpu_device, tmp_path):
     assert np.array_equal(vals, want)
 
 
+def test_samples_per_pixel_traces_the_frame_that_many_times(vrt, po, gpu_device):
+    """kernel_arg_t::samples_per_pixel as the reference's kernel treats it (kernel.cpp:67-80): the same camera ray traced spp times into the
+    same payload -- the pixels of one sample, spp times the rays (MINSTRET).  spp = 0 is refused (pixels undefined in the reference)."""
+    sc = vrt.scene.procedural("blob", 3, 0, 2)
+    w, h = 72, 48
+    px = {}
+    rays = {}
+    for spp in (1, 3):
+        tr = vrt.tracer.Tracer(w, h, samples_per_pixel=spp)
+        tr.init(sc)
+        tr.setup()
+        px[spp] = tr.run()
+        rays[spp] = tr.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0)
+        tr.close()
+    want, _, _ = po.render(sc, w, h)
+    assert np.array_equal(px[1], want) and np.array_equal(px[3], want)
+    assert rays[1] == w * h and rays[3] == 3 * w * h
+
+
+def test_small_scene_buffers_reach_the_device_before_they_are_read(vrt, po, gpu_device):
+    """Uploads of up to 4 KB are kept in the host shadow and sent to the device when something there reads them (the kernel arguments of
+    every frame never are).  A 12-triangle scene's own buffers ARE that small: re-uploaded between two runs, the second run must see the
+    new bytes -- and vx_copy_from_dev of such a buffer returns what was uploaded."""
+    sc = vrt.scene.procedural("cornell")
+    w, h = 40, 32
+    tr = vrt.tracer.Tracer(w, h)
+    tr.init(sc)
+    tr.setup()
+    first = tr.run()
+    want, _, _ = po.render(sc, w, h)
+    assert np.array_equal(first, want)
+    assert sc["blas"].size <= 4096 and sc["tlas"].size <= 4096
+    # move the instance 3 units along z by rewriting its record (transform + inverse), as a host animating the scene would
+    blas = sc["blas"].copy().view(np.float32)
+    blas[17 + 11] += 3.0       # transform[2][3]
+    blas[1 + 11] -= 3.0        # invTransform[2][3]
+    tr.bufs["blas"].write(blas.view(np.uint8))
+    assert bytes(tr.bufs["blas"].read()) == blas.view(np.uint8).tobytes()
+    moved = tr.run()
+    sc2 = vrt.scene.Scene(dict(sc.buffers, blas=blas.view(np.uint8)))
+    want2, _, _ = po.render(sc2, w, h)
+    assert np.array_equal(moved, want2) and not np.array_equal(moved, first)
+    tr.close()
+
+
 def test_mirror_bounce_through_vx_api(vrt, po, gpu_device):
     """kernel_arg_t::max_depth + blas_node_t::reflectivity reach the kernels through vx_copy_to_dev /
     vx_start exactly as the reference host passes them (tracer.cpp:217-259, main.cpp -d)."""
@@ -144,6 +189,7 @@ def test_mirror_bounce_through_vx_api_matches_the_reference_twin(vrt, golden, gp
     g = golden("mirror_trio")
     w, h = int(g["width"]), int(g["height"])
     L = g["light12"]
+    g = dict(g, triIdx=np.arange(g["tri"].size // 36, dtype=np.uint32).view(np.uint8))   # (kernel_arg_t names one; the RTU path never reads it)
     tr = vrt.tracer.Tracer(w, h, max_depth=3)
     tr.init(g)
     tr.setup(light_pos=tuple(L[0:3]), light_color=tuple(L[3:6]), ambient=tuple(L[6:9]), background=tuple(L[9:12]))

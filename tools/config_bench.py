@@ -157,7 +157,22 @@ def main():
                 frame(copy)
             res[copy] = (time.time() - t0) / n * 1e3
         tr.close()
-        out.append({"config": "drop-in vx_* sequence (ctypes host): Sponza-class, 1920x1080, primary + 1 shadow ray, serial frames", "rays_per_frame": int(rays),
+        # the same call sequence from the C++ host (csrc/rt_host.cpp -N: what a compiled host like the reference's pays per frame; the ctypes host
+        # above allocates a fresh 8 MB bytes object per vx_copy_from_dev and pays its page faults)
+        cxx = {}
+        try:
+            import re, subprocess
+            lib = vrt.LIB_DIR
+            r = subprocess.run([os.path.join(lib, "rt_host"), "-m", "proc:atrium:8", "-w", str(W), "-h", str(H), "-S", "-L", "300,480,60", "-N", "1500", "-q", "-o", "/tmp/vxrt_cfg7.ppm",
+                                "-k", os.path.join(vrt.VXBIN_DIR, "kernel.vxbin")], env=dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""), VORTEX_DRIVER="hip"),
+                               capture_output=True, text=True, timeout=600)
+            ms = [float(x) for x in re.findall(r"frame loop \(1500 frames, [^)]*\): ([0-9.]+) ms per frame", r.stdout)]
+            if len(ms) == 2:
+                cxx = {"cxx_host_ms_per_frame_start_wait": ms[0], "cxx_host_ms_per_frame_with_copy_from_dev": ms[1],
+                       "cxx_host_mrays_s_start_wait": round(rays / ms[0] / 1e3, 1), "cxx_host_mrays_s_with_copy": round(rays / ms[1] / 1e3, 1)}
+        except Exception as e:
+            cxx = {"cxx_host_error": repr(e)[:200]}
+        out.append({**cxx, "config": "drop-in vx_* sequence (ctypes host): Sponza-class, 1920x1080, primary + 1 shadow ray, serial frames", "rays_per_frame": int(rays),
                     "scene_upload_s": round(upload_s, 3), "ms_per_frame_start_wait": round(res[False], 4), "ms_per_frame_with_copy_from_dev": round(res[True], 4),
                     "mrays_s_start_wait": round(rays / res[False] / 1e3, 1), "mrays_s_with_copy": round(rays / res[True] / 1e3, 1)})
     if 8 in a.configs:

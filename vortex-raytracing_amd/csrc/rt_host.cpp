@@ -7,7 +7,9 @@
 //
 //   rt_host [-k kernel.vxbin] [-n meshes] [-m model] [-w width] [-h height] [-s samples] [-d depth] [-o out.ppm]
 //   model: an .obj file, or proc:cornell | proc:blob:<subdiv> | proc:atrium:<level> | proc:hairball:<strands>:<segs>
-//   extensions: -S (one shadow ray per hit), -r y0:y1 (row window), -q (no perf dump)
+//   extensions: -S (one shadow ray per hit), -r y0:y1 (row window), -q (no perf dump), -L x,y,z (light position),
+//               -N frames (repeat Tracer::run's call sequence -- vx_upload_bytes, vx_start, vx_ready_wait, vx_mem_free -- that many times and
+//               print the time per frame, then the same with vx_copy_from_dev in every frame: the drop-in path's own rate from a C++ host)
 #include <unistd.h>
 #include <chrono>
 #include <cstdio>
@@ -51,7 +53,8 @@ static const char* output_file = "output.ppm";
 static std::string model = "proc:cornell";
 static uint32_t mesh_count = 1, dst_width = 640, dst_height = 480, spp = 1, max_depth = 1;
 static bool shadow = false, quiet = false;
-static uint32_t row0 = 0, row1 = 0;
+static uint32_t row0 = 0, row1 = 0, n_frames = 0;
+static float light_pos[3] = {0, 10, -10};
 
 static void write_ppm(const std::vector<uint8_t>& out, uint32_t w, uint32_t h, const char* file) {
   // P3, vertical flip, bytes 2,1,0 of each little-endian pixel (tracer.cpp:15-33: same bytes, but the
@@ -95,7 +98,7 @@ static void* make_scene() {
 
 int main(int argc, char** argv) {
   int opt;
-  while ((opt = getopt(argc, argv, "k:n:m:w:h:s:f:z:d:o:cSqr:")) != -1) {
+  while ((opt = getopt(argc, argv, "k:n:m:w:h:s:f:z:d:o:cSqr:N:L:")) != -1) {
     switch (opt) {
     case 'k': kernel_file = optarg; break;
     case 'n': mesh_count = std::atoi(optarg); break;
@@ -110,6 +113,8 @@ int main(int argc, char** argv) {
     case 'S': shadow = true; break;
     case 'q': quiet = true; break;
     case 'r': std::sscanf(optarg, "%u:%u", &row0, &row1); break;
+    case 'N': n_frames = std::atoi(optarg); break;
+    case 'L': std::sscanf(optarg, "%f,%f,%f", &light_pos[0], &light_pos[1], &light_pos[2]); break;
     default: std::printf("Usage: [-k kernel] [-n meshes] [-w width] [-h height] [-m model] [-s samples] [-d depth] [-o output]\n"); return -1;
     }
   }
@@ -154,7 +159,7 @@ int main(int argc, char** argv) {
   RT_CHECK(vx_mem_address(sbt, &ka.sbt_addr));
 
   // Tracer::setup: lights (main.cpp:34-41), uploads, SBT, DCRs
-  const float lp[3] = {0, 10, -10}, lc[3] = {1, 1, 1}, am[3] = {0.4f, 0.4f, 0.4f}, bg[3] = {0.4f, 0.35f, 0.25f};
+  const float* lp = light_pos; const float lc[3] = {1, 1, 1}, am[3] = {0.4f, 0.4f, 0.4f}, bg[3] = {0.4f, 0.35f, 0.25f};
   std::memcpy(ka.light_pos, lp, 12); std::memcpy(ka.light_color, lc, 12);
   std::memcpy(ka.ambient_color, am, 12); std::memcpy(ka.background_color, bg, 12);
   for (int i = 0; i < 8; ++i) {
@@ -185,6 +190,23 @@ int main(int argc, char** argv) {
   RT_CHECK(vx_copy_from_dev(h_output.data(), out, 0, h_output.size()));
   std::printf("kernel wall time (start..ready_wait): %.3f ms\n", std::chrono::duration<double, std::milli>(t3 - t2).count());
   write_ppm(h_output, dst_width, dst_height, output_file);
+  if (n_frames) {
+    // the frame loop of a host that renders a sequence: per frame what Tracer::run does (tracer.cpp:262-288)
+    for (int with_copy = 0; with_copy < 2; ++with_copy) {
+      for (uint32_t f = 0; f < 5 + n_frames; ++f) {
+        if (f == 5) t2 = std::chrono::steady_clock::now();
+        vx_buffer_h a2;
+        RT_CHECK(vx_upload_bytes(dev, &ka, sizeof ka, &a2));
+        RT_CHECK(vx_start(dev, krnl, a2));
+        RT_CHECK(vx_ready_wait(dev, VX_MAX_TIMEOUT));
+        if (with_copy) RT_CHECK(vx_copy_from_dev(h_output.data(), out, 0, h_output.size()));
+        vx_mem_free(a2);
+      }
+      t3 = std::chrono::steady_clock::now();
+      std::printf("frame loop (%u frames, %s): %.4f ms per frame\n", n_frames, with_copy ? "upload_bytes + start + ready_wait + copy_from_dev" : "upload_bytes + start + ready_wait",
+                  std::chrono::duration<double, std::milli>(t3 - t2).count() / n_frames);
+    }
+  }
 
   for (int i = 0; i < 8; ++i) vx_mem_free(buf[i]);
   vx_mem_free(bvh2); vx_mem_free(out); vx_mem_free(sbt); vx_mem_free(args);

@@ -1230,13 +1230,20 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     }
   }
   if (A.counters) {
+    // one device atomic per WORKGROUP and counter (its wavefronts add up in LDS first): per wavefront, the 7,168 read-modify-writes a frame's
+    // launch ends with -- all on one cache line -- cost the frame 40 us (8 %: profiles/r04_p_rays_counter.txt)
+    __shared__ unsigned s_cnt[5];
+    if (threadIdx.x < 5u) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
     unsigned v[5] = {nrays, fx.node, fx.inst, fx.tri, nhit};
 #pragma unroll
     for (int k = 0; k < (STATS ? 5 : 1); ++k) {
       unsigned s = v[k];
       for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-      if (lane == 0 && s) atomicAdd(A.counters + k, (unsigned long long)s);
+      if (lane == 0 && s) atomicAdd(&s_cnt[k], s);
     }
+    __syncthreads();
+    if (threadIdx.x < (STATS ? 5u : 1u) && s_cnt[threadIdx.x]) atomicAdd(A.counters + threadIdx.x, (unsigned long long)s_cnt[threadIdx.x]);
   }
 }
 
@@ -2696,7 +2703,11 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   const bool packed = packed_env >= 0 ? packed_env != 0 : (a->n_ctx > 1 && n_tiles >= LPT_MIN_TILES);
   hipStream_t side = c->side;
   if (side_launch) {
-    if (hipEventRecord(c->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, c->ev_in, 0) != hipSuccess) return fail();
+    // the side stream starts behind what is queued on `s` (the previous frame's shading pass reads the hit records this launch writes) --
+    // unless nothing is: a caller that waits for every frame before it starts the next (the vx_* sequence: vx_ready_wait, then vx_start)
+    // finds the stream drained, and the fork's event record -- a barrier packet in front of the main launch, ~12 us -- is not needed
+    const bool drained = hipStreamQuery(s) == hipSuccess;
+    if (!drained && (hipEventRecord(c->ev_in, s) != hipSuccess || hipStreamWaitEvent(side, c->ev_in, 0) != hipSuccess)) return fail();
     X0.queue = c->ctl + 32 + 2 * CTL_QUEUE_DWORDS;
     X0.defer_count = a->apriori; X0.defer_list = a->apriori + 1; X0.defer_cap = ap_count;
   }

@@ -25,9 +25,13 @@
 extern "C" uint32_t* vxrt_status_word_device(void);   // rt_kernels.hip
 
 // rays counter and status word of a run into host memory the device can write (see vx_device::enqueue_readback)
-__global__ void vx_readback_kernel(const unsigned long long* __restrict__ rays, const uint32_t* __restrict__ status, unsigned long long* __restrict__ host) {
+// ... and clears the counter for the next run: a run is its own launches + this one.  (Rounds 2-3 opened a run with a fill of the counter and
+// an event record and closed it with a second event record -- three more packets on the stream, ~10 us each between a frame's launches; the
+// run's duration for MCYCLE is now taken on the host, from vx_start to the moment ready_wait sees the stream drained.)
+__global__ void vx_readback_kernel(unsigned long long* __restrict__ rays, const uint32_t* __restrict__ status, unsigned long long* __restrict__ host) {
   host[0] = *rays;
   host[1] = (unsigned long long)*status;
+  *rays = 0ull;
   __threadfence_system();
 }
 
@@ -54,6 +58,7 @@ struct Alloc {
   bool reserved = false;    // created by mem_reserve (kernel images)
   bool pooled = false;      // dptr is a slot of the small-buffer slab (no hipMalloc/hipFree of its own)
   uint64_t version = 0;     // bumped by every copy_to_dev into this allocation
+  bool dev_stale = false;   // the host shadow is newer than the device copy (small uploads are sent to the device only when something there reads them)
   std::vector<uint8_t> shadow;  // host copy for small buffers
 };
 
@@ -66,7 +71,6 @@ struct vx_buffer {          // same role as callbacks.inc:14-18
 struct vx_device {
   int hip_dev = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   bool run_pending = false;
   bool have_timing = false;
   std::map<uint64_t, Alloc> allocs;   // keyed by va
@@ -75,7 +79,7 @@ struct vx_device {
   std::unordered_map<uint32_t, uint32_t> dcrs;
   unsigned long long* d_rays = nullptr;
   unsigned long long last_rays = 0;
-  unsigned long long* h_back = nullptr;   // pinned: [0] rays, [1] status word of the run, written by the stream's last kernel
+  unsigned long long* h_back = nullptr;   // pinned: [0] rays, [1] status word of the run -- written by the stream's last kernel; [4] scratch
   static constexpr uint64_t kStageSlot = 4096; static constexpr uint32_t kStageSlots = 64;
   char* stage = nullptr; uint32_t stage_next = 0;   // pinned staging ring of the small uploads
   // small buffers (kernel_arg_t, SBT, kernel selector images: re-allocated per run by the reference host, tracer.cpp:
@@ -84,6 +88,7 @@ struct vx_device {
   std::vector<void*> free_slots;
   uint64_t n_accel_builds = 0, n_hip_mallocs = 0;   // vx_hip_device_stat
   float last_ms = 0.f;
+  std::chrono::steady_clock::time_point t_begin{};   // vx_start of the pending run
   hipDeviceProp_t prop{};
   // acceleration layout of the scene last started, rebuilt only when one of the four traversal
   // buffers was re-uploaded or re-pointed (key = device pointers + upload versions)
@@ -105,11 +110,10 @@ struct vx_device {
     if (hipGetDeviceProperties(&prop, hip_dev) != hipSuccess) return -1;
     total_mem = prop.totalGlobalMem;
     if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
-    if (hipEventCreate(&ev_begin) != hipSuccess || hipEventCreate(&ev_end) != hipSuccess) return -1;
-    if (hipMalloc((void**)&d_rays, sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (hipHostMalloc((void**)&h_back, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return -1;
+    if (hipMalloc((void**)&d_rays, sizeof(unsigned long long)) != hipSuccess || hipMemset(d_rays, 0, sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipHostMalloc((void**)&h_back, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return -1;
     if (hipHostMalloc((void**)&stage, kStageSlot * kStageSlots, hipHostMallocDefault) != hipSuccess) return -1;
-    h_back[0] = h_back[1] = 0;
+    for (int i = 0; i < 8; ++i) h_back[i] = 0;
     return 0;
   }
 
@@ -126,8 +130,6 @@ struct vx_device {
     if (q_hits) (void)hipFree(q_hits);
     if (h_back) (void)hipHostFree(h_back);
     if (stage) (void)hipHostFree(stage);
-    if (ev_begin) (void)hipEventDestroy(ev_begin);
-    if (ev_end) (void)hipEventDestroy(ev_end);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -252,15 +254,14 @@ struct vx_device {
     uint32_t* st = vxrt_status_word_device();
     if (!st) return -1;
     h_back[1] = 0;
-    hipLaunchKernelGGL(vx_readback_kernel, dim3(1), dim3(1), 0, stream, (const unsigned long long*)d_rays, (const uint32_t*)st, h_back);
+    hipLaunchKernelGGL(vx_readback_kernel, dim3(1), dim3(1), 0, stream, d_rays, (const uint32_t*)st, h_back);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
 
   void finish_run() {
     if (!run_pending) return;
     run_pending = false;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) { last_ms = ms; have_timing = true; }
+    last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); have_timing = true;
     last_rays = h_back[0];   // copied back by the stream at the end of the run (enqueue_readback)
   }
 
@@ -270,6 +271,14 @@ struct vx_device {
     wait_idle();
     (void)hipSetDevice(hip_dev);
     const uint64_t off = va - a->va;
+    const bool shadowed = !a->shadow.empty() && off + size <= a->shadow.size();
+    if (size && shadowed && a->size <= kStageSlot) {
+      // A small buffer with a host shadow -- the kernel arguments of every frame (tracer.cpp:262-288), the SBT, the selector images -- is
+      // decoded by start() from the shadow; nothing on the device reads it unless it is one of the scene's own buffers (a 12-triangle
+      // scene) or the reference-quirks image wants the address space as it is.  The device copy is therefore made when one of those
+      // needs it (flush_stale), not per upload: one copy packet less between two frames of the drop-in sequence.
+      a->dev_stale = true;
+    } else
     if (size && size <= kStageSlot && stage) {
       // small uploads (the kernel arguments of every frame, tracer.cpp:262-288): copied into a pinned slot -- the caller's buffer is
       // free again on return, as vx_copy_to_dev promises -- and sent by the stream the runs use, ahead of the next run, without a
@@ -282,8 +291,29 @@ struct vx_device {
       if (hipStreamSynchronize(stream) != hipSuccess) return -1;   // (behind any staged upload still in the stream)
       if (hipMemcpy((char*)a->dptr + off, src, size, hipMemcpyHostToDevice) != hipSuccess) return -1;
     }
-    if (!a->shadow.empty() && off + size <= a->shadow.size()) std::memcpy(a->shadow.data() + off, src, size);
+    if (shadowed) std::memcpy(a->shadow.data() + off, src, size);
     a->version = ++upload_seq;   // unique per device: a buffer freed and allocated again at the same address never repeats a version
+    return 0;
+  }
+
+  // bring the device copy of a lazily uploaded buffer up to date (through the pinned staging ring, on the run's stream)
+  int flush_stale(Alloc* a) {
+    if (!a || !a->dev_stale) return 0;
+    const uint64_t n = std::min<uint64_t>(a->size, a->shadow.size());
+    if (n > kStageSlot || !stage) {
+      if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+      if (hipMemcpy(a->dptr, a->shadow.data(), n, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    } else {
+      if (stage_next == kStageSlots) { if (hipStreamSynchronize(stream) != hipSuccess) return -1; stage_next = 0; }
+      char* slot = stage + (size_t)stage_next++ * kStageSlot;
+      std::memcpy(slot, a->shadow.data(), n);
+      if (hipMemcpyAsync(a->dptr, slot, n, hipMemcpyHostToDevice, stream) != hipSuccess) return -1;
+    }
+    a->dev_stale = false;
+    return 0;
+  }
+  int flush_all_stale() {
+    for (auto& kv : allocs) if (kv.second.dev_stale && flush_stale(&kv.second) != 0) return -1;
     return 0;
   }
 
@@ -292,6 +322,7 @@ struct vx_device {
     if (!a) return -1;
     wait_idle();
     (void)hipSetDevice(hip_dev);
+    if (flush_stale(a) != 0) return -1;
     if (hipStreamSynchronize(stream) != hipSuccess) return -1;   // (behind any staged upload still in the stream)
     if (size && hipMemcpy(dst, (char*)a->dptr + (va - a->va), size, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return 0;
@@ -370,6 +401,9 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   }
   auto ptr = [](Res r) { return (const void*)((const char*)r.a->dptr + r.off); };
   auto count = [](Res r, uint64_t stride) { return (uint64_t)((r.a->size - r.off) / stride); };
+  // the scene's own buffers are read on the device: small ones uploaded lazily get their device copy now
+  for (Alloc* al : {r_tlas.a, r_blas.a, r_bvh.a, r_tri.a, r_triex.a, r_mat.a, r_tex.a})
+    if (flush_stale(al) != 0) return -1;
   vxrt_scene_t sc{};
   sc.tlas = ptr(r_tlas); sc.blas = ptr(r_blas); sc.bvh = ptr(r_bvh); sc.tri = ptr(r_tri);
   sc.triEx = ptr(r_triex); sc.mat = ptr(r_mat); sc.tex = r_tex.a ? ptr(r_tex) : nullptr;
@@ -414,6 +448,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   if (quirks) {
     // reference-quirks mode: the frame's camera rays through the literal restatement of the RTU on a flat image of the address space
     if (shadow || row_stride > 1 || ka.max_depth > 1) { VXLOG("start: reference-quirks mode renders closest-hit frames only (no shadow extension, row stride or mirror bounce)"); return -1; }
+    if (flush_all_stale() != 0) return -1;   // (the image is the address space as the device holds it)
     // the image mirrors the address space: every allocation at the address vx_mem_address reported.  It is kept between runs and only
     // what changed is copied again -- the list of (address, size, upload version) entries, in address order, is compared entry by entry (no
     // rolling hash that could alias): the same set of allocations -> only the re-uploaded ones are copied (every frame re-uploads its
@@ -453,26 +488,27 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
       if (hipMalloc(&q_rays, nr * 24) != hipSuccess || hipMalloc(&q_hits, nr * 24) != hipSuccess) return -1;
       q_rays_cap = nr;
     }
-    if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
-    if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
+    t_begin = std::chrono::steady_clock::now();
     int rc = vxrt_camera_rays(ka.dst_width, ka.dst_height, y0, y1, (float*)q_rays, stream);
     // (the DCRs hold 32-bit device addresses: offsets into the image, as they are addresses into the simulator's RAM)
     if (rc == 0) rc = vxrt_trace_reference_quirks(q_image, q_image_size, d_tlas, d_blas, d_bvh, d_tri, (const float*)q_rays, nr, nullptr, (vxrt_hit_t*)q_hits, VXRT_MODE_CLOSEST, stream);
     if (rc == 0) rc = vxrt_shade_rays(accel, (const float*)q_rays, (const vxrt_hit_t*)q_hits, nr, &sp, nullptr, dstp + (size_t)y0 * ka.dst_width, stream);
-    h_back[2] = nr;   // (pinned; the stream reads it after this call returns)
-    if (rc == 0 && hipMemcpyAsync(d_rays, &h_back[2], sizeof(unsigned long long), hipMemcpyHostToDevice, stream) != hipSuccess) rc = -1;
-    if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
-    if (rc != 0) { VXLOG("start: reference-quirks launch rejected"); return -1; }
+    h_back[4] = nr;   // (pinned; the stream reads it after this call returns)
+    if (rc == 0 && hipMemcpyAsync(d_rays, &h_back[4], sizeof(unsigned long long), hipMemcpyHostToDevice, stream) != hipSuccess) rc = -1;
+    if (rc != 0) { VXLOG("start: reference-quirks launch rejected"); (void)hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream); return -1; }
     if (enqueue_readback() != 0) return -1;
     run_pending = true;
     return 0;
   }
-  if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
-  if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
-  int rc = row_stride > 1 ? vxrt_render_interleaved(accel, ka.dst_width, ka.dst_height, y0 / 8u, row_stride, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream)
-                          : vxrt_render(accel, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream);
-  if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
-  if (rc != 0) { VXLOG("start: launch rejected (shape check)"); return -1; }
+  t_begin = std::chrono::steady_clock::now();
+  // samples_per_pixel: the reference's kernel traces the SAME camera ray that many times into the same payload (kernel.cpp:67-80: GenerateRay
+  // takes no sample index, the colour accumulation is commented out), so the pixel is the one sample's -- and the run costs spp times the rays
+  // and the time.  Honoured as written: the frame is traced spp times (same pixels; MINSTRET and MCYCLE are what a `-s 4` run expects).
+  int rc = 0;
+  for (uint32_t smp = 0; smp < ka.samples_per_pixel && rc == 0; ++smp)
+    rc = row_stride > 1 ? vxrt_render_interleaved(accel, ka.dst_width, ka.dst_height, y0 / 8u, row_stride, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream)
+                        : vxrt_render(accel, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream);
+  if (rc != 0) { VXLOG("start: launch rejected (shape check)"); (void)hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream); return -1; }
   if (enqueue_readback() != 0) return -1;
   run_pending = true;
   return 0;
@@ -509,6 +545,8 @@ int vx_device::start_raycast(uint64_t args_va) {
   }
   auto ptr = [](Res r) { return (const void*)((const char*)r.a->dptr + r.off); };
   auto count = [](Res r, uint64_t stride) { return (uint32_t)std::min<uint64_t>((r.a->size - r.off) / stride, 0x7fffffff); };
+  for (Alloc* al : {r_tlas.a, r_blas.a, r_bvh.a, r_tri.a, r_triex.a, r_idx.a, r_tex.a})      // (small scene buffers uploaded lazily: see upload())
+    if (flush_stale(al) != 0) return -1;
   vxrc_scene_t sc{};
   sc.tlas = ptr(r_tlas); sc.blas = ptr(r_blas); sc.bvh = ptr(r_bvh); sc.tri = ptr(r_tri); sc.triEx = ptr(r_triex);
   sc.triIdx = ptr(r_idx); sc.tex = ptr(r_tex);
@@ -542,10 +580,8 @@ int vx_device::start_raycast(uint64_t args_va) {
     if (vxrc_accel_build(&sc, stream, &rc_accel) != 0) { VXLOG("start: raycast scene rejected (malformed BVH2: child / triangle index out of range or child not after parent)"); return -1; }
     std::memcpy(rc_key, key, sizeof key);
   }
-  if (hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream) != hipSuccess) return -1;
-  if (hipEventRecord(ev_begin, stream) != hipSuccess) return -1;
+  t_begin = std::chrono::steady_clock::now();
   const int rc = vxrc_render_accel(rc_accel, ka.dst_width, ka.dst_height, y0, y1, &pr, (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, stream);
-  if (hipEventRecord(ev_end, stream) != hipSuccess) return -1;
   if (rc != 0) { VXLOG("start: raycast launch rejected (shape check)"); return -1; }
   if (enqueue_readback() != 0) return -1;
   run_pending = true;
