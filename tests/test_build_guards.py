@@ -55,3 +55,29 @@ def test_every_instantiation_tests_the_shard_range_before_its_first_queue_atomic
         g = body[guards[0]]
         prev = body[guards[0] - 1]
         assert "s_cselect_b32" in g and "s_cmp_lt_u32" in prev, (name, prev, g)
+
+
+def test_the_software_twin_kernel_carries_the_same_guard():
+    """rc_kernels.hip's rc_persistent_kernel reserves tiles from the same kind of sharded queue: its range test is the same asm statement,
+    ahead of its queue atomic (the `s_lo < n_tiles` compare had been folded away there as well)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = os.path.join(tempfile.gettempdir(), "vxrc_guard_listing.s")
+    src = os.path.join(ROOT, "vortex-raytracing_amd", "csrc", "rc_kernels.hip")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-S", "--cuda-device-only",
+                        "-o", out, src], check=True, stderr=subprocess.DEVNULL)
+    lines = open(out).read().split("\n")
+    body, on = [], False
+    for l in lines:
+        if re.match(r"_ZN\S*rc_persistent_kernel\S*:", l) or re.match(r"\S*rc_persistent_kernel\S*:", l):
+            on = True
+        elif on:
+            body.append(l)
+            if l.strip().startswith("s_endpgm"):
+                break
+    assert body, "rc_persistent_kernel not found in the listing"
+    guards = [i for i, l in enumerate(body) if "RTGUARD shard_range" in l]
+    atomics = [i for i, l in enumerate(body) if re.match(r"\s*(global|flat)_atomic_add\b", l)]
+    assert guards and atomics and guards[0] < atomics[0]
+    assert "s_cselect_b32" in body[guards[0]] and "s_cmp_lt_u32" in body[guards[0] - 1]

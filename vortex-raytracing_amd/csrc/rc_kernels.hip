@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <new>
 #include <vector>
 #include "../../include/vortex_hip.h"
@@ -36,6 +38,9 @@
 #ifndef RC_LDS_STACK
 #define RC_LDS_STACK 8          // stack entries kept in LDS per lane; deeper ones in scratch (8 + 7 wavefronts per SIMD: +1 % over 12 + 6, +3 % over 16 + 5)
 #endif
+#ifndef RC_WIDE
+#define RC_WIDE 1               // fast-domain rays walk the BVH2 two levels per fetch through 128-byte wide nodes (see the wide step); 0 = the two-wide walk only
+#endif
 #ifndef RC_WAVES
 #define RC_WAVES 7              // wavefronts per SIMD the kernel is compiled for
 #endif
@@ -43,12 +48,14 @@
 #define RC_STATUS_ITER 2u
 #define RC_STATUS_BAD_SCENE 4u
 #define RC_STATUS_SLOW_BOXES 16u  // build-time only: a reachable box is not lo <= hi, finite and within 2^60: the scene keeps the libstdc++ min/max slab form
+#define RC_STATUS_NO_WIDE 32u     // build-time only: some internal node's box is not exactly the union of its children's: the scene keeps the two-wide walk
 #define RC_TLAS_ITER_LIMIT (1u << 20)   // the TLAS is taken as uploaded (not re-laid out), so its walk is bounded
 #define RC_QUEUE_SHARDS 8u
 #define RC_QUEUE_STRIDE 32u
 #define RC_CTL_DWORDS (RC_QUEUE_SHARDS * RC_QUEUE_STRIDE)
 
 extern "C" uint32_t* vxrt_status_word_device(void);   // rt_kernels.hip
+extern "C" int vxrt_internal_lpt_sort(const uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t tiles_per_shard, uint32_t* clear, uint32_t clear_dwords, void* stream);   // rt_kernels.hip
 
 namespace {
 
@@ -75,7 +82,9 @@ struct RcDev {
   const uint32_t* blas_root;               // per instance record: descriptor of its BVH root
   uint32_t n_tri_idx;
   uint32_t fast_boxes;                     // 1: every box of the compact nodes is lo <= hi, finite, within 2^60 (checked by the build): the sign-selected slab form is exact for rays in the fast domain
+  const uint4* nodes_w;                    // wide nodes (128 B, one per internal reference node): the boxes of its GRANDchildren, two tree levels per fetch; nullptr = off
 };
+#define RCD_NONE 0xFFFFFFFEu               // wide node: empty slot
 
 struct RcParams {
   float cpos[3], cfwd[3], cright[3], cup[3], viewplane[2];
@@ -178,6 +187,57 @@ __global__ void rc_accel_nodes_kernel(const uint32_t* __restrict__ ref, uint32_t
   o[3] = make_uint4(rc_child_desc(ref, l, base, end, n_tri_idx, status), rc_child_desc(ref, r, base, end, n_tri_idx, status), 0u, 0u);
 }
 
+// Wide node of internal node i, 128 B: slots 0,1 = the children of its LEFT child (or, if that is a leaf, the leaf itself in slot 0), slots
+// 2,3 = those of its RIGHT child; per slot a box (6 floats) and a descriptor.  One fetch then carries the walk over TWO levels of the BVH2
+// (see the wide step of rc_persistent_kernel for why the visiting order, and with it every hit, stays the reference's).  What the step
+// needs of the skipped level is its boxes' entry distances, to order the two sides (render.h:110): a box that is exactly the union of its
+// children's has per-axis slab values that are the min / max of theirs, so the distance is recomputed from the grandchildren -- the build
+// checks the union property per node and the scene keeps the two-wide walk where it fails.
+//   q0..q5: 24 floats, slot k at [6k .. 6k+5] = lo.xyz, hi.xyz      q6: the four descriptors      q7.x: bit 0 = left child internal, bit 1 = right
+__global__ void rc_accel_wide_kernel(const uint32_t* __restrict__ ref, uint32_t n_nodes, uint4* __restrict__ out,
+                                     const uint32_t* __restrict__ bases, const uint32_t* __restrict__ ends, uint32_t nb,
+                                     uint32_t n_tri_idx, uint32_t* status) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  uint32_t base = 0, end = 0;
+  bool in = false;
+  for (uint32_t j = 0; j < nb; ++j) if (i >= bases[j] && i < ends[j]) { base = bases[j]; end = ends[j]; in = true; }
+  if (!in) return;
+  const uint32_t* w = ref + (size_t)i * 8;
+  if (w[7] != 0u || !rc_node_ok(ref, i, base, end)) return;
+  uint32_t f[24], desc[4], shape = 0u;
+  for (int k = 0; k < 24; ++k) f[k] = 0u;
+  for (int k = 0; k < 4; ++k) desc[k] = RCD_NONE;
+  for (int side = 0; side < 2; ++side) {
+    const uint32_t c = base + w[3] + (uint32_t)side;
+    const uint32_t* cw = ref + (size_t)c * 8;
+    if (cw[7] == 0u && rc_node_ok(ref, c, base, end)) {          // internal child: its two children fill the side's slots
+      shape |= 1u << side;
+      const uint32_t g0 = base + cw[3];
+      for (int g = 0; g < 2; ++g) {
+        const uint32_t* gw = ref + (size_t)(g0 + g) * 8;
+        uint32_t* o = f + 6 * (2 * side + g);
+        o[0] = gw[0]; o[1] = gw[1]; o[2] = gw[2]; o[3] = gw[4]; o[4] = gw[5]; o[5] = gw[6];
+        desc[2 * side + g] = rc_child_desc(ref, g0 + g, base, end, n_tri_idx, status);
+      }
+      // the child's box must be exactly the union of the grandchildren's (float equality, per plane)
+      const uint32_t* a = ref + (size_t)g0 * 8; const uint32_t* b = a + 8;
+      for (int k = 0; k < 3; ++k) {
+        const float lo = fminf(__uint_as_float(a[k]), __uint_as_float(b[k])), hi = fmaxf(__uint_as_float(a[4 + k]), __uint_as_float(b[4 + k]));
+        if (!(lo == __uint_as_float(cw[k])) || !(hi == __uint_as_float(cw[4 + k]))) atomicOr(status, RC_STATUS_NO_WIDE);
+      }
+    } else {                                                      // leaf child (or a malformed one: flagged by the two-wide build): itself, in the side's first slot
+      uint32_t* o = f + 6 * (2 * side);
+      o[0] = cw[0]; o[1] = cw[1]; o[2] = cw[2]; o[3] = cw[4]; o[4] = cw[5]; o[5] = cw[6];
+      desc[2 * side] = rc_child_desc(ref, c, base, end, n_tri_idx, status);
+    }
+  }
+  uint4* o = out + (size_t)i * 8;
+  for (int q = 0; q < 6; ++q) o[q] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+  o[6] = make_uint4(desc[0], desc[1], desc[2], desc[3]);
+  o[7] = make_uint4(shape, 0u, 0u, 0u);
+}
+
 __global__ void rc_accel_tris_kernel(const float* __restrict__ tri, const uint32_t* __restrict__ triIdx, uint32_t n_idx, uint32_t n_tris,
                                      float4* __restrict__ out, uint32_t* status) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,6 +270,10 @@ __global__ void rc_accel_roots_kernel(const uint32_t* __restrict__ ref, const ui
 struct RcArgs {
   uint32_t W, H, y0, y1, tiles_x, n_tiles, per_shard;
   uint32_t* dst; float* colors; uint32_t* status; uint32_t* queue;
+  // optional: queue position -> tile (within each shard's band of the frame, most expensive first: learned from the context's previous
+  // frame of the same window) and where this frame's cost per tile goes (loop iterations of the wavefront that traced it; a leaf-body
+  // run counts three) -- the RTU path's longest-first order (rt_kernels.hip), which is worth +18 % on its serial frames
+  const uint32_t* tile_order; uint32_t* tile_cost;
 };
 
 __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, RcParams p, RcArgs A) {
@@ -230,9 +294,14 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
   // pixel / path state
   uint32_t px = 0, py = 0, smp = 0, bounce = 0;
   float cr = 0, cg = 0, cb = 0, rr = 0, rg = 0, rb = 0, thr = 1.0f;
-  // queue
+  // queue: the home shard is the wavefront's physical XCD (HW_REG_XCC_ID: band s of the frame is traced by the same XCD, and found in its
+  // L2, frame after frame); shards one of the workgroup's wavefronts found handed out are not polled again by the others (s_dry)
   bool queue_empty = false;
-  uint32_t shard = blockIdx.x % RC_QUEUE_SHARDS, tries = 0;
+  const uint32_t shard = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) % RC_QUEUE_SHARDS;
+  uint32_t tries = 0, work = 0, cost_tile = 0xFFFFFFFFu;
+  __shared__ uint32_t s_dry;
+  if (threadIdx.x == 0) s_dry = 0u;
+  __syncthreads();
 
   auto push = [&](uint32_t d) {
     if (sp >= RC_STACK) { atomicOr(A.status, RC_STATUS_STACK); return; }
@@ -273,17 +342,30 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
     // ================= fetch: one 8x8 tile per wavefront once every lane is idle =================
     if (__ballot(cur != RC_CUR_IDLE) == 0ull) {
       uint32_t tile = 0xFFFFFFFFu;
+      uint32_t dry = *(volatile uint32_t*)&s_dry;
       while (!queue_empty && tries < RC_QUEUE_SHARDS) {
-        const uint32_t s_lo = shard * A.per_shard;
-        const uint32_t s_n = s_lo < A.n_tiles ? min(A.per_shard, A.n_tiles - s_lo) : 0u;
+        const uint32_t sid = (shard + tries) % RC_QUEUE_SHARDS;
+        if ((dry >> sid) & 1u) { ++tries; continue; }
+        const uint32_t s_lo = sid * A.per_shard;
+        // a shard past the end of the tile range is skipped by an explicit test the optimiser cannot fold away (the RTU kernel's guard: as a
+        // select feeding `base < s_n`, this compiler dropped the `s_lo < n_tiles` half and a shard past the end handed out tiles >= n_tiles)
+        uint32_t in_range;
+        asm volatile("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0 ; RTGUARD shard_range" : "=s"(in_range)
+                     : "s"(__builtin_amdgcn_readfirstlane(s_lo)), "s"(__builtin_amdgcn_readfirstlane(A.n_tiles)) : "scc");
+        if (!in_range) { ++tries; continue; }
+        const uint32_t s_n = min(A.per_shard, A.n_tiles - s_lo);
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(A.queue + shard * RC_QUEUE_STRIDE, 1u);
+        if (lane == 0) base = atomicAdd(A.queue + sid * RC_QUEUE_STRIDE, 1u);
         base = __shfl(base, 0);
         if (base < s_n) { tile = s_lo + base; break; }
-        shard = (shard + 1u) % RC_QUEUE_SHARDS;
+        if (lane == 0) atomicOr(&s_dry, 1u << sid);
+        dry |= 1u << sid;
         ++tries;
       }
+      if (A.tile_cost && lane == 0 && cost_tile != 0xFFFFFFFFu) A.tile_cost[cost_tile] = work;
       if (tile == 0xFFFFFFFFu) { queue_empty = true; break; }
+      if (A.tile_order) tile = A.tile_order[tile];
+      cost_tile = tile; work = 0;
       px = (tile % A.tiles_x) * 8u + (lane & 7u);
       py = A.y0 + (tile / A.tiles_x) * 8u + (lane >> 3);
       if (px < A.W && py < A.y1) {
@@ -294,6 +376,73 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
 
     // ================= traverse: one step of whatever each lane holds, per iteration =================
     for (;;) {
+      ++work;
+      if (RC_WIDE && sc.nodes_w && __all(!rc_is_node(cur) || lfast)) {
+        if (rc_is_node(cur)) {
+          // ---- WIDE step: two levels of the BVH2 per fetch (fast-domain rays only, wave-uniform choice) ----
+          // The reference (render.h:99-121) tests a node's two children, visits the FARTHER of the two hit ones first (:110 as written; equal
+          // distances: the left one) and leaves the other on its stack; the child it visits next is popped at once -- nothing happens
+          // in between -- so its own step can be taken right here, from the grandchildren's boxes in this record.  The child left on the stack
+          // is replaced by ITS two children, in the order the reference will give them when it pops it (same ray, same boxes: same order).
+          // They are culled against the hit distance of NOW instead of that of the pop: too little culling only visits subtrees whose every
+          // triangle fails the strict `dist < hit.dist` (box distance <= triangle distance), so the hit -- index included, the order of the
+          // subtrees that matter is unchanged -- is the reference's.  The distances of the skipped level, which order its two sides, are
+          // recomputed from the grandchildren: for a box that is exactly the union of two others (checked by the build) every per-axis slab
+          // value is the min / max of theirs, and (lo - o) * (1/d) is monotone in lo.
+          const uint4* np = sc.nodes_w + (size_t)cur * 8;
+          const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4], w5 = np[5], w6 = np[6];
+          const uint32_t shape = np[7].x;
+          const uint32_t fw[24] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w};
+          const uint32_t dsc[4] = {w6.x, w6.y, w6.z, w6.w};
+          const bool nx = rix < 0.0f, ny = riy < 0.0f, nz = riz < 0.0f;
+          float tn[4][3], tf[4][3], d[4];
+          bool v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float lx = __uint_as_float(fw[6 * k]), ly = __uint_as_float(fw[6 * k + 1]), lz = __uint_as_float(fw[6 * k + 2]);
+            const float hx = __uint_as_float(fw[6 * k + 3]), hy = __uint_as_float(fw[6 * k + 4]), hz = __uint_as_float(fw[6 * k + 5]);
+            tn[k][0] = ((nx ? hx : lx) - rox) * rix; tn[k][1] = ((ny ? hy : ly) - roy) * riy; tn[k][2] = ((nz ? hz : lz) - roz) * riz;
+            tf[k][0] = ((nx ? lx : hx) - rox) * rix; tf[k][1] = ((ny ? ly : hy) - roy) * riy; tf[k][2] = ((nz ? lz : hz) - roz) * riz;
+            const float a = fmaxf(fmaxf(tn[k][0], tn[k][1]), tn[k][2]), b = fminf(fminf(tf[k][0], tf[k][1]), tf[k][2]);
+            d[k] = (b < a || b <= 0) ? RC_LARGE_FLOAT : a;
+            v[k] = dsc[k] != RCD_NONE && d[k] != RC_LARGE_FLOAT && d[k] < hitd;
+          }
+          // entry distance of a side: the child's own box (a leaf child sits in the side's first slot) or the union of its two children's
+          float dside[2];
+#pragma unroll
+          for (int sd = 0; sd < 2; ++sd) {
+            const int k0 = 2 * sd, k1 = 2 * sd + 1;
+            if ((shape >> sd) & 1u) {
+              const float a = fmaxf(fmaxf(fminf(tn[k0][0], tn[k1][0]), fminf(tn[k0][1], tn[k1][1])), fminf(tn[k0][2], tn[k1][2]));
+              const float b = fminf(fminf(fmaxf(tf[k0][0], tf[k1][0]), fmaxf(tf[k0][1], tf[k1][1])), fmaxf(tf[k0][2], tf[k1][2]));
+              dside[sd] = (b < a || b <= 0) ? RC_LARGE_FLOAT : a;
+            } else dside[sd] = d[k0];
+          }
+          // each side's children in visiting order (the farther of two hit ones first; equal: the first)
+          uint32_t sq[2][2]; uint32_t ns[2];
+#pragma unroll
+          for (int sd = 0; sd < 2; ++sd) {
+            const int k0 = 2 * sd, k1 = 2 * sd + 1;
+            const bool both = v[k0] && v[k1];
+            const bool sw = both && d[k0] < d[k1];
+            sq[sd][0] = (v[k0] && !sw) ? dsc[k0] : dsc[k1];
+            sq[sd][1] = sw ? dsc[k0] : dsc[k1];
+            ns[sd] = (v[k0] ? 1u : 0u) + (v[k1] ? 1u : 0u);
+          }
+          const bool rfirst = ns[0] != 0u && ns[1] != 0u && dside[0] < dside[1];   // :110 one level up
+          const uint32_t a0 = rfirst ? sq[1][0] : sq[0][0], a1 = rfirst ? sq[1][1] : sq[0][1], na = rfirst ? ns[1] : ns[0];
+          const uint32_t b0 = rfirst ? sq[0][0] : sq[1][0], b1 = rfirst ? sq[0][1] : sq[1][1], nbb = rfirst ? ns[0] : ns[1];
+          const uint32_t n = na + nbb;
+          const uint32_t o0 = na ? a0 : b0;
+          const uint32_t o1 = na == 2u ? a1 : (na == 1u ? b0 : b1);
+          const uint32_t o2 = na == 2u ? b0 : b1;
+          const uint32_t o3 = b1;
+          if (n > 3u) push(o3);
+          if (n > 2u) push(o2);
+          if (n > 1u) push(o1);
+          if (n) cur = o0; else pop();
+        }
+      } else
       if (rc_is_node(cur)) {
         // ---- BVH internal node (render.h:99-121): both children's boxes in one 64-byte record ----
         const uint4* np = sc.nodes_c + (size_t)cur * 4;
@@ -338,6 +487,7 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
         else pop();
       }
       if (__ballot(rc_is_leaf(cur)) != 0ull) {
+        work += 2u;
         if (rc_is_leaf(cur)) {
           // ---- BVH leaf (render.h:88-98): triangles in triIdx order, strict '<' ----
           uint32_t first, count;
@@ -505,17 +655,58 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
 // ---------------------------------------------------------------------------------------------
 // host entry points
 // ---------------------------------------------------------------------------------------------
+// Per-frame state: queue counters, the cost of the last frame's tiles and the order derived from it.  Two of them, handed out by stream, so
+// that frames issued alternately on two streams overlap (the tail of one launch is filled by the head of the next, as on the RTU path).
+struct RcFrameCtx {
+  uint32_t* ctl = nullptr; uint32_t* cost = nullptr; uint32_t* order = nullptr;
+  uint32_t cap = 0, key[4] = {0, 0, 0, 0};
+  bool valid = false, ctl_dirty = true, busy = false, done_recorded = false;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+};
 struct vxrc_accel {
   vxrc_scene_t ref{};
-  void* nodes_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr; uint32_t* ctl = nullptr;
+  void* nodes_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr; void* nodes_w = nullptr;
+  RcFrameCtx ctx[2];
+  uint32_t next_ctx = 0;
+  bool multi_stream = false; hipStream_t first_stream = nullptr; bool stream_seen = false;
   uint32_t fast_boxes = 0;   // see RcDev
 };
 
 extern "C" int vxrc_accel_destroy(vxrc_accel_t* a) {
   if (!a) return 0;
   (void)hipDeviceSynchronize();
-  (void)hipFree(a->nodes_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root); (void)hipFree(a->ctl);
+  (void)hipFree(a->nodes_c); (void)hipFree(a->tri_w); (void)hipFree(a->blas_root); (void)hipFree(a->nodes_w);
+  for (RcFrameCtx& c : a->ctx) {
+    (void)hipFree(c.ctl); (void)hipFree(c.cost); (void)hipFree(c.order);
+    if (c.done) (void)hipEventDestroy(c.done);
+  }
   delete a;
+  return 0;
+}
+
+// frame context for a call on stream s: the one this stream used last, else an unused one, else the other one behind its completion event
+static RcFrameCtx* rc_acquire_ctx(vxrc_accel* a, hipStream_t s) {
+  if (!a->stream_seen) { a->stream_seen = true; a->first_stream = s; } else if (s != a->first_stream) a->multi_stream = true;
+  RcFrameCtx* c = nullptr;
+  for (RcFrameCtx& k : a->ctx) if (!c && k.busy && k.stream == s) c = &k;
+  for (RcFrameCtx& k : a->ctx) if (!c && !k.busy) c = &k;
+  if (!c) c = &a->ctx[a->next_ctx++ % 2];
+  if (!c->ctl) {
+    if (hipMalloc((void**)&c->ctl, RC_CTL_DWORDS * 4) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    c->ctl_dirty = true;
+  }
+  if (c->busy && c->stream != s) {
+    if (c->done_recorded) { if (hipStreamWaitEvent(s, c->done, 0) != hipSuccess) return nullptr; }
+    else if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); if (hipDeviceSynchronize() != hipSuccess) return nullptr; }
+  }
+  return c;
+}
+static int rc_release_ctx(vxrc_accel* a, RcFrameCtx* c, hipStream_t s) {
+  c->done_recorded = a->multi_stream;
+  if (c->done_recorded && hipEventRecord(c->done, s) != hipSuccess) return -1;
+  c->busy = true; c->stream = s;
   return 0;
 }
 
@@ -543,10 +734,11 @@ extern "C" int vxrc_accel_build(const vxrc_scene_t* s, void* stream, vxrc_accel_
   if (!a) return -1;
   a->ref = *s;
   uint32_t* d_ranges = nullptr; uint32_t* d_status = nullptr;
+  static const bool wide_on = [] { const char* e = getenv("VXRC_WIDE"); return !(e && e[0] == '0'); }();
   bool ok = hipMalloc(&a->nodes_c, (size_t)s->n_bvh_nodes * 64) == hipSuccess &&
+            (!(RC_WIDE && wide_on) || hipMalloc(&a->nodes_w, (size_t)s->n_bvh_nodes * 128) == hipSuccess) &&
             hipMalloc(&a->tri_w, (size_t)s->n_tri_idx * 48) == hipSuccess &&
             hipMalloc(&a->blas_root, (size_t)s->n_blas * 4) == hipSuccess &&
-            hipMalloc((void**)&a->ctl, RC_CTL_DWORDS * 4) == hipSuccess &&
             hipMalloc((void**)&d_ranges, bases.size() * 8) == hipSuccess && hipMalloc((void**)&d_status, 4) == hipSuccess;
   uint32_t hstatus = 0;
   if (ok) {
@@ -558,6 +750,8 @@ extern "C" int vxrc_accel_build(const vxrc_scene_t* s, void* stream, vxrc_accel_
     const uint32_t nb = (uint32_t)bases.size();
     hipLaunchKernelGGL(rc_accel_nodes_kernel, dim3((s->n_bvh_nodes + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->bvh, s->n_bvh_nodes, (uint4*)a->nodes_c,
                        d_ranges, d_ranges + nb, nb, s->n_tri_idx, d_status);
+    if (a->nodes_w) hipLaunchKernelGGL(rc_accel_wide_kernel, dim3((s->n_bvh_nodes + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->bvh, s->n_bvh_nodes, (uint4*)a->nodes_w,
+                                       d_ranges, d_ranges + nb, nb, s->n_tri_idx, d_status);
     hipLaunchKernelGGL(rc_accel_tris_kernel, dim3((s->n_tri_idx + 255) / 256), dim3(256), 0, st, (const float*)s->tri, (const uint32_t*)s->triIdx, s->n_tri_idx,
                        s->n_tris, (float4*)a->tri_w, d_status);
     hipLaunchKernelGGL(rc_accel_roots_kernel, dim3((s->n_blas + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->bvh, (const uint32_t*)s->blas, s->n_blas,
@@ -566,8 +760,9 @@ extern "C" int vxrc_accel_build(const vxrc_scene_t* s, void* stream, vxrc_accel_
          hipMemcpy(&hstatus, d_status, 4, hipMemcpyDeviceToHost) == hipSuccess;
   }
   (void)hipFree(d_ranges); (void)hipFree(d_status);
-  if (!ok || (hstatus & ~RC_STATUS_SLOW_BOXES) != 0) { vxrc_accel_destroy(a); return -1; }
+  if (!ok || (hstatus & ~(RC_STATUS_SLOW_BOXES | RC_STATUS_NO_WIDE)) != 0) { vxrc_accel_destroy(a); return -1; }
   a->fast_boxes = (hstatus & RC_STATUS_SLOW_BOXES) ? 0u : 1u;
+  if (a->nodes_w && (hstatus & (RC_STATUS_SLOW_BOXES | RC_STATUS_NO_WIDE))) { (void)hipFree(a->nodes_w); a->nodes_w = nullptr; }   // (the wide walk needs both properties)
   *out = a;
   return 0;
 }
@@ -591,6 +786,7 @@ extern "C" int vxrc_render_accel(vxrc_accel_t* a, uint32_t width, uint32_t heigh
   d.nodes_c = (const uint4*)a->nodes_c; d.tri_w = (const float4*)a->tri_w; d.blas_root = (const uint32_t*)a->blas_root;
   d.n_tri_idx = s->n_tri_idx;
   d.fast_boxes = a->fast_boxes;
+  d.nodes_w = (const uint4*)a->nodes_w;
   RcParams p{};
   for (int i = 0; i < 3; ++i) {
     p.cpos[i] = prm->camera_pos[i]; p.cfwd[i] = prm->camera_forward[i]; p.cright[i] = prm->camera_right[i]; p.cup[i] = prm->camera_up[i];
@@ -606,8 +802,28 @@ extern "C" int vxrc_render_accel(vxrc_accel_t* a, uint32_t width, uint32_t heigh
   if (nt > 0x3ffffffull) return -1;
   A.n_tiles = (uint32_t)nt;
   A.per_shard = (A.n_tiles + RC_QUEUE_SHARDS - 1) / RC_QUEUE_SHARDS;
-  A.dst = dst; A.colors = colors; A.status = st; A.queue = a->ctl;
-  if (hipMemsetAsync(a->ctl, 0, RC_CTL_DWORDS * 4, hs) != hipSuccess) return -1;
+  RcFrameCtx* c = rc_acquire_ctx(a, hs);
+  if (!c) return -1;
+  auto fail = [&]() -> int { c->ctl_dirty = true; (void)rc_release_ctx(a, c, hs); return -1; };
+  A.dst = dst; A.colors = colors; A.status = st; A.queue = c->ctl;
+  if (c->ctl_dirty && hipMemsetAsync(c->ctl, 0, RC_CTL_DWORDS * 4, hs) != hipSuccess) return fail();
+  c->ctl_dirty = true;    // until the sort launch that clears the counters again is enqueued
+  // longest tile first inside each band, learned from this context's previous frame of the same window (VXRC_LPT=0: off)
+  static const bool lpt_on = [] { const char* e = getenv("VXRC_LPT"); return !(e && e[0] == '0'); }();
+  const bool lpt = lpt_on && A.n_tiles >= 4096u;
+  if (lpt) {
+    if (c->cap < A.n_tiles) {
+      if (hipStreamSynchronize(hs) != hipSuccess) return fail();
+      (void)hipFree(c->cost); (void)hipFree(c->order);
+      c->cost = c->order = nullptr; c->cap = 0; c->valid = false;
+      if (hipMalloc((void**)&c->cost, (size_t)A.n_tiles * 4) != hipSuccess || hipMalloc((void**)&c->order, (size_t)A.n_tiles * 4) != hipSuccess) return fail();
+      c->cap = A.n_tiles;
+    }
+    const uint32_t key[4] = {width, height, y0, y1};
+    if (memcmp(key, c->key, sizeof key) != 0) { c->valid = false; memcpy(c->key, key, sizeof key); }
+    A.tile_cost = c->cost;
+    A.tile_order = c->valid ? c->order : nullptr;
+  }
   static int per_cu = 0, cus = 0;
   if (!per_cu) {
     int dev = 0;
@@ -617,7 +833,13 @@ extern "C" int vxrc_render_accel(vxrc_accel_t* a, uint32_t width, uint32_t heigh
   }
   const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * cus, (nt + 3) / 4);
   hipLaunchKernelGGL(rc_persistent_kernel, dim3(grid ? grid : 1), dim3(256), 0, hs, d, p, A);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  if (hipGetLastError() != hipSuccess) return fail();
+  if (lpt) {
+    // the order for this context's next frame, and the queue counters cleared behind the frame (one launch instead of the fill)
+    if (vxrt_internal_lpt_sort(c->cost, c->order, A.n_tiles, A.per_shard, c->ctl, RC_CTL_DWORDS, hs) != 0) return fail();
+    c->valid = true; c->ctl_dirty = false;
+  }
+  return rc_release_ctx(a, c, hs);
 }
 
 // one-shot form: layout built, frame rendered, layout freed (tests, callers that render a scene once)

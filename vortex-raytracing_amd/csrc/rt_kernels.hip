@@ -2199,6 +2199,20 @@ static int release_ctx(vxrt_accel* a, FrameCtx* c, hipStream_t s) {
 
 extern "C" uint32_t* vxrt_status_word_device(void) { return status_word(); }   // shared with rc_kernels.hip (not part of the public header)
 
+// The longest-first tile order of a frame for the software twin's launch (rc_kernels.hip; internal, not part of the public header): the same
+// per-band counting sort the RTU path's shading launch carries (lpt_order_block), as a launch of QUEUE_SHARDS workgroups that also zeroes the
+// `clear_dwords` words at `clear` (the twin's queue counters, for its next frame).
+__global__ __launch_bounds__(256) void lpt_sort_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n_tiles, uint32_t tiles_per_shard,
+                                                       uint32_t* __restrict__ clear, uint32_t clear_dwords) {
+  __shared__ uint32_t s_hist[2048 + 8];
+  if (clear && blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < clear_dwords; i += 256u) clear[i] = 0u;
+  lpt_order_block(blockIdx.x, cost, order, n_tiles, tiles_per_shard, s_hist, nullptr);
+}
+extern "C" int vxrt_internal_lpt_sort(const uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t tiles_per_shard, uint32_t* clear, uint32_t clear_dwords, void* stream) {
+  hipLaunchKernelGGL(lpt_sort_kernel, dim3(QUEUE_SHARDS), dim3(256), 0, (hipStream_t)stream, cost, order, n_tiles, tiles_per_shard, clear, clear_dwords);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" {
 
 const char* vxrt_version(void) { return "vortex-rt-mi355x 0.3 (gfx950, compact 64-byte nodes, persistent wavefronts)"; }
