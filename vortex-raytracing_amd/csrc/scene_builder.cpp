@@ -15,6 +15,7 @@
 #include <atomic>
 #include <cctype>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -51,7 +52,7 @@ static int kBins = 128;     // reference: 8 (bvh.cpp:8).  Under the reinsertion 
 static float kLeafK = 1.0f;  // keep <= kLeafMax triangles in one leaf when the best split saves less than kLeafK node-areas
                              // (reference: always split, i.e. 0; VXS_LEAF_K overrides): -9 % node visits, +15 % triangle tests
 static int kLeafMax = 4;
-static int kThreads = 8;     // worker threads of the BLAS builder (VXS_THREADS overrides; the tree and its layout do not depend on it)
+static int kThreads = 8;     // worker threads of the BLAS builder: min(16, hardware threads); VXS_THREADS overrides; the tree and its layout do not depend on it
 static int kWiden = 0;      // 0: widen the cluster with the largest SAH gain (reference), 1: the one with the largest area
 static int kCollapse = 1;   // 1: build the binary SAH tree to the bottom, optimise it by reinsertion (kOptimize passes), collapse it to 4-wide by the SAH
                             // dynamic programme; 0: widen greedily while building (the builder up to profiles/r03_s).  VXS_COLLAPSE overrides.
@@ -171,6 +172,10 @@ private:
 
   // ---- binary SAH tree to the bottom + SAH-optimal collapse to 4-wide ----
   void build_collapsed() {
+    const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {   // VXS_VERBOSE: seconds since the build of this mesh began
+      if (kVerbose) std::fprintf(stderr, "[scene_builder] %8.3f s  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), what);
+    };
     std::vector<BinNode> bn;
     bn.reserve(2 * (size_t)n_ + 1);
     bn.emplace_back();
@@ -178,7 +183,12 @@ private:
     // the top serially; subtrees below `defer_below` triangles by worker threads into private arrays (disjoint triangle ranges: the
     // in-place partition needs no locks), appended in the order the serial pass met them: nothing depends on the thread count
     const uint32_t defer_below = std::max<uint32_t>(4096u, n_ / 256u);
-    const bool local = kOptimizeLocal < 0 ? n_ > 2000000u : kOptimizeLocal != 0;
+    // 0: every node over the whole tree, serially (13 s per million triangles); 1: the workers optimise their subtrees, one serial pass moves
+    // the nodes of the top; 2 (default): the same, plus rounds at coarser scales IN PLACE and in parallel -- subtrees of n/64 and of n/8
+    // triangles, each taken by one thread -- before the serial pass over the top: what a round of subtrees cannot do (move a node across the
+    // border of its subtree) the next, coarser round can
+    const int mode = kOptimizeLocal < 0 ? 2 : kOptimizeLocal;
+    const bool local = mode != 0;
     std::vector<uint32_t> deferred;
     build_binary(bn, 0, defer_below, &deferred);
     const uint32_t n_top = (uint32_t)bn.size();
@@ -196,7 +206,7 @@ private:
           sub[t].reserve(2 * (size_t)bn[deferred[t]].count + 1);
           sub[t].push_back(bn[deferred[t]]);
           build_binary(sub[t], 0, 0u, nullptr);
-          if (kOptimize > 0 && local) optimize_by_reinsertion(sub[t]);
+          if (kOptimize > 0 && mode == 1) optimize_by_reinsertion(sub[t]);
         }
       };
       const int nthreads = (int)std::min<size_t>((size_t)kThreads, deferred.size());
@@ -213,7 +223,67 @@ private:
         std::vector<BinNode>().swap(L);
       }
     }
-    if (kOptimize > 0) optimize_by_reinsertion(bn, local ? n_top : 0xffffffffu);
+    lap("binary SAH tree built");
+    if (kOptimize > 0 && mode == 2 && !deferred.empty()) {
+      std::vector<uint32_t> parent(bn.size(), 0u);
+      for (uint32_t i = 0; i < (uint32_t)bn.size(); ++i) if (bn[i].left) { parent[bn[i].left] = i; parent[bn[i].right] = i; }
+      // rounds, coarse to fine (as the serial pass takes its nodes largest first): subtrees of at most n / divisor triangles, `passes` passes
+      // over the largest `fraction` of their nodes.  The first round is the one serial piece: the whole tree, its few thousand largest
+      // nodes -- the moves that cross every later border; with it the frame traces as fast as on the serially optimised tree
+      // (profiles/r04_r_builder_ab*.txt: 0.5 % of the nodes do as well as 5 %), without it 1.5 % slower.
+      // VXS_ROUNDS = "divisor:passes:fraction,..." overrides.
+      struct Round { uint32_t divisor; int passes; double fraction; size_t max_nodes; };
+      // up to 2 M triangles: the largest hundredth of the nodes over the whole tree (serial), then n/8, n/64, n/256; above (a 10 M-triangle scene has
+      // 15 M nodes: every full round costs seconds), the same first round and kOptimize passes inside subtrees of ~4,096 triangles
+      const uint32_t big = std::max<uint32_t>(1u, n_ / 1048576u);
+      std::vector<Round> rounds = {{1u, 1, 0.01, 0}, {8u, 1, 1.0, 0}, {64u, 1, 1.0, 0}, {256u, 1, 1.0, 0}};
+      if (n_ > 2000000u) rounds = {{1u, 1, 1.0, 8192}, {256u * big, kOptimize, 1.0, 0}};
+      if (const char* e = std::getenv("VXS_ROUNDS")) {
+        rounds.clear();
+        for (const char* q = e; *q;) {
+          Round r{1u, 1, 1.0, 0};
+          int used = 0;
+          if (std::sscanf(q, "%u:%d:%lf%n", &r.divisor, &r.passes, &r.fraction, &used) < 3 || r.divisor == 0u) break;
+          rounds.push_back(r);
+          q += used;
+          if (*q == ',') ++q;
+        }
+      }
+      for (const Round& rd : rounds) {
+        const uint32_t thresh = std::max<uint32_t>(n_ / rd.divisor, 2u);
+        // the subtrees of this round: the highest nodes of at most `thresh` triangles, largest first
+        std::vector<uint32_t> roots, st{0u};
+        while (!st.empty()) {
+          const uint32_t i = st.back(); st.pop_back();
+          if (!bn[i].left) continue;
+          if (bn[i].count <= thresh) { roots.push_back(i); continue; }
+          st.push_back(bn[i].right); st.push_back(bn[i].left);
+        }
+        std::stable_sort(roots.begin(), roots.end(), [&](uint32_t x, uint32_t y) { return bn[x].count > bn[y].count; });
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+          for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= roots.size()) break;
+            reinsertion_passes(bn, parent, roots[k], 0xffffffffu, rd.passes, rd.fraction, rd.max_nodes);
+          }
+        };
+        const int nthreads = (int)std::min<size_t>((size_t)kThreads, roots.size());
+        std::vector<std::thread> pool;
+        for (int i = 1; i < nthreads; ++i) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+        if (kVerbose) { char msg[96]; std::snprintf(msg, sizeof msg, "round n/%u (%zu subtrees, %d passes over %.2f of their nodes)", rd.divisor, roots.size(), rd.passes, rd.fraction); lap(msg); }
+        recount(bn);     // (the next, finer round picks its subtrees by triangle count: inside this round's subtrees the counts have moved with the nodes)
+      }
+      // ... and, after the fine rounds, the nodes of the serially built top once more over the whole tree: measured, this closing pass is worth
+      // as much as the opening round (75.1 M -> 73.6 M node steps in the headline frame; profiles/r04_r_builder_ab4.txt)
+      reinsertion_passes(bn, parent, 0u, n_top, kOptimize, 1.0);
+      lap("pass over the top");
+      leaf_order(bn);
+      lap("triangles in leaf order");
+    } else
+    if (kOptimize > 0) { optimize_by_reinsertion(bn, local ? n_top : 0xffffffffu); lap("reinsertion"); }
     // the dynamic programme, children before parents
     std::vector<uint32_t> post;
     post.reserve(bn.size());
@@ -257,6 +327,7 @@ private:
       x.f[1] = s2 ? x.f[0] : g2; x.f[2] = s3 ? x.f[0] : g3; x.f[3] = s4 ? x.f[0] : g4;
       x.plan = 1u | (a3 << 2) | (a4 << 4) | ((uint32_t)s2 << 6) | ((uint32_t)s3 << 7) | ((uint32_t)s4 << 8) | (leaf ? kPlanLeaf : 0u);
     }
+    lap("collapse programme");
     // emit, depth first, children contiguous and after their parent
     nodes_.reserve(bn.size());
     nodes_.emplace_back();
@@ -302,38 +373,61 @@ private:
     if (N < 8) return;
     std::vector<uint32_t> parent(N, 0u);
     for (uint32_t i = 0; i < N; ++i) if (bn[i].left) { parent[bn[i].left] = i; parent[bn[i].right] = i; }
+    reinsertion_passes(bn, parent, 0u, limit, kOptimize, kOptimizeFraction);
+    leaf_order(bn);
+  }
+
+  // kOptimize passes of reinsertion INSIDE the subtree under `root`, in place: only nodes of that subtree move, only positions inside it
+  // are searched, only its nodes' boxes and links (and their entries of `parent`) are written -- so disjoint subtrees can be optimised by
+  // different threads at the same time on the shared arrays, and the result does not depend on which thread took which.  `limit`: only
+  // nodes with an index below it are moved.  `fraction`: share of the movable nodes, largest area first, a pass takes (at most `max_nodes`
+  // of them, 0 = no cap).
+  void reinsertion_passes(std::vector<BinNode>& bn, std::vector<uint32_t>& parent, uint32_t root, uint32_t limit, int passes, double fraction, size_t max_nodes = 0) {
     auto unite = [](const Box& a, const Box& b) { Box r; r.lo = vmin(a.lo, b.lo); r.hi = vmax(a.hi, b.hi); return r; };
     auto same = [](const Box& a, const Box& b) { return a.lo.x == b.lo.x && a.lo.y == b.lo.y && a.lo.z == b.lo.z && a.hi.x == b.hi.x && a.hi.y == b.hi.y && a.hi.z == b.hi.z; };
-    auto refit_up = [&](uint32_t i) {   // boxes of i and its ancestors from their children, until one does not change
+    auto refit_up = [&](uint32_t i) {   // boxes of i and its ancestors (up to the subtree's root) from their children, until one does not change
       for (;;) {
         const Box b = unite(bn[bn[i].left].box, bn[bn[i].right].box);
         if (same(b, bn[i].box)) break;
         bn[i].box = b;
-        if (i == 0) break;
+        if (i == root) break;
         i = parent[i];
       }
     };
+    if (!bn[root].left) return;
     struct Cand { float ci; uint32_t node; bool operator<(const Cand& o) const { return ci > o.ci; } };   // (min-heap on the induced cost)
     std::vector<Cand> heap;
-    std::vector<uint32_t> order;
-    order.reserve(N);
+    std::vector<uint32_t> order, dfs;
     auto report = [&](int pass) {   // VXS_VERBOSE: surface-area cost of the binary tree (internal nodes' areas over the root's)
-      if (!kVerbose) return;
+      if (!kVerbose || root != 0u) return;
       double a = 0;
-      for (uint32_t i = 0; i < N; ++i) if (bn[i].left && (i == 0 || parent[i] != 0xffffffffu)) a += bn[i].box.half_area();
-      std::fprintf(stderr, "[scene_builder] reinsertion pass %d: %u nodes, internal area / root area = %.3f\n", pass, N, a / bn[0].box.half_area());
+      dfs.assign(1, root);
+      while (!dfs.empty()) { const uint32_t i = dfs.back(); dfs.pop_back(); if (bn[i].left) { a += bn[i].box.half_area(); dfs.push_back(bn[i].left); dfs.push_back(bn[i].right); } }
+      std::fprintf(stderr, "[scene_builder] reinsertion pass %d: internal area / root area = %.3f\n", pass, a / bn[root].box.half_area());
     };
     report(0);
-    for (int pass = 0; pass < kOptimize; ++pass) {
+    for (int pass = 0; pass < passes; ++pass) {
       if (pass) report(pass);
+      // the movable nodes of the subtree: not the root, not its two children (the root keeps its place), index below `limit`; in index
+      // order first, so that the stable sort by area gives the same sequence whatever order the walk met them in
       order.clear();
-      for (uint32_t i = 1; i < N && i < limit; ++i) if (parent[i] != 0u) order.push_back(i);
-      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bn[a].box.half_area() > bn[b].box.half_area(); });
-      const size_t take = (size_t)((double)order.size() * kOptimizeFraction);
+      dfs.assign(1, root);
+      while (!dfs.empty()) {
+        const uint32_t i = dfs.back(); dfs.pop_back();
+        if (i != root && parent[i] != root && i < limit) order.push_back(i);
+        if (bn[i].left) { dfs.push_back(bn[i].left); dfs.push_back(bn[i].right); }
+      }
+      // largest area first, ties by index (a total order: the same sequence whatever order the walk met the nodes in).  A pass over a small
+      // share of a big subtree does not pay for sorting all of it: the share is selected first (nth_element), then sorted.
+      auto larger = [&](uint32_t a, uint32_t b) { const float x = bn[a].box.half_area(), y = bn[b].box.half_area(); return x > y || (x == y && a < b); };
+      size_t take = (size_t)((double)order.size() * fraction);
+      if (max_nodes && take > max_nodes) take = max_nodes;
+      if (take < order.size()) { std::nth_element(order.begin(), order.begin() + (ptrdiff_t)take, order.end(), larger); order.resize(take); }
+      std::sort(order.begin(), order.end(), larger);
       for (size_t oi = 0; oi < take; ++oi) {
         const uint32_t X = order[oi];
         const uint32_t P = parent[X];
-        if (P == 0u) continue;            // (moved under the root by an earlier step of this pass)
+        if (P == root) continue;          // (moved under the root by an earlier step of this pass)
         const uint32_t G = parent[P];
         const uint32_t S = bn[P].left == X ? bn[P].right : bn[P].left;
         // cut X and P out: S takes P's place under G
@@ -345,9 +439,9 @@ private:
         const float ax = xb.half_area();
         float best_cost = INFINITY; uint32_t best = S;
         heap.clear();
-        heap.push_back({0.0f, bn[0].left}); std::push_heap(heap.begin(), heap.end());
-        heap.push_back({0.0f, bn[0].right}); std::push_heap(heap.begin(), heap.end());
-        // (X lay inside the root's box and still does: the root itself grows by nothing; the root is not a candidate, it stays node 0)
+        heap.push_back({0.0f, bn[root].left}); std::push_heap(heap.begin(), heap.end());
+        heap.push_back({0.0f, bn[root].right}); std::push_heap(heap.begin(), heap.end());
+        // (X lay inside the root's box and still does: the root itself grows by nothing; the root is not a candidate, it keeps its place)
         while (!heap.empty()) {
           std::pop_heap(heap.begin(), heap.end());
           const Cand c = heap.back(); heap.pop_back();
@@ -372,8 +466,20 @@ private:
         refit_up(Q);
       }
     }
-    report(kOptimize);
-    // triangles into the leaf order of the final tree; ranges and counts from the leaves up
+    report(passes);
+  }
+
+  // triangle counts of the internal nodes of a re-linked tree, from the leaves up
+  void recount(std::vector<BinNode>& bn) {
+    std::vector<uint32_t> st{0u}, post;
+    post.reserve(bn.size());
+    while (!st.empty()) { const uint32_t i = st.back(); st.pop_back(); post.push_back(i); if (bn[i].left) { st.push_back(bn[i].left); st.push_back(bn[i].right); } }
+    for (size_t pi = post.size(); pi-- > 0;) { BinNode& x = bn[post[pi]]; if (x.left) x.count = bn[x.left].count + bn[x.right].count; }
+  }
+
+  // triangles into the leaf order of the (re-linked) tree; ranges and counts from the leaves up
+  void leaf_order(std::vector<BinNode>& bn) {
+    const uint32_t N = (uint32_t)bn.size();
     const uint32_t r0 = bn[0].first, rn = bn[0].count;   // (the root's range: a worker's subtree owns a slice of the array)
     std::vector<rt_tri_t> tri2(rn);
     std::vector<rt_triex_t> ex2(triEx_ ? rn : 0);
@@ -1383,6 +1489,7 @@ static void read_knobs() {
   if (const char* e = std::getenv("VXS_OPTIMIZE_LOCAL")) kOptimizeLocal = std::atoi(e);
   if (const char* e = std::getenv("VXS_OPTIMIZE_FRACTION")) kOptimizeFraction = std::atof(e);
   { unsigned hc = std::thread::hardware_concurrency(); kThreads = (int)std::min<unsigned>(hc ? hc : 1u, 16u); }
+  { const unsigned hc = std::thread::hardware_concurrency(); kThreads = (int)std::min(16u, std::max(1u, hc)); }   // (a GPU box gives a process 16 cores per GPU)
   if (const char* e = std::getenv("VXS_THREADS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) kThreads = v; }
   if (const char* e = std::getenv("VXS_LEAF_K")) kLeafK = (float)std::atof(e);
   if (const char* e = std::getenv("VXS_LEAF_MAX")) kLeafMax = std::atoi(e);
