@@ -76,6 +76,10 @@ def parse():
                     help="gloo: rehearsal of the N>1 code path where ranks share one GPU (shares gathered through host memory)")
     ap.add_argument("--one-rank-group", action="store_true",
                     help="diagnostic, one GPU: run the N > 1 code path (process group, interleaved batches, dist.gather, barriers, all_reduce) with a group of ONE rank -- the RCCL calls of the multi-GPU run on a 1-GPU box")
+    ap.add_argument("--other-configs", choices=["none", "short", "full"], default="short",
+                    help="1 GPU only: short host-timed legs of BASELINE.json's other configurations under extras.other_configs (short: bunny-class 1024^2, "
+                         "the diffuse bounce, 3840x2160; full: + the 10M-triangle hairball, 16 spp AO, whose tree takes ~12 s of host time to build)")
+    ap.add_argument("--other-configs-child", choices=["short", "full"], default=None, help=argparse.SUPPRESS)
     ap.add_argument("--random-rays", type=int, default=16777216,
                     help="second leg (SURVEY s8d 'random rays vs fixed BVH'): N incoherent rays per GPU through vxrt_trace, reported under extras; 0 = skip")
     return ap.parse_args()
@@ -298,6 +302,67 @@ def profile_mismatch(prof, ident):
     return None
 
 
+def other_configs(vrt, torch, dev, ds, scene, params, full):
+    """BASELINE.json's other configurations as short legs of this run (they are parity-test cases -- tests/test_gpu_configs.py -- not the bench
+    line): strictly serial frames through the C ABI, inputs resident, each leg timed by the host clock between two device
+    synchronisations, rays counted by the launches themselves in an untimed frame.  Runs in a child process of the bench (see main);
+    tools/config_bench.py holds the longer versions."""
+    rtapi = vrt.rtapi
+    s = torch.cuda.current_stream().cuda_stream
+    rtapi.accel_frames_in_flight(ds.accel, 1)
+
+    def leg(name, first, frame, frames, **more):
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        first(cnt.data_ptr())
+        torch.cuda.synchronize()
+        rays = int(cnt.item())
+        for _ in range(3):
+            frame()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            frame()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / frames * 1e3
+        assert rtapi.status(s) == 0
+        return dict({"config": name, "frames_timed": frames, "rays_per_frame": rays, "ms_per_frame": round(ms, 4), "mrays_s": round(rays / ms / 1e3, 1)}, **more)
+
+    out = []
+    W, H = 1920, 1080
+    px = torch.zeros((2160, 3840), dtype=torch.int32, device=dev)
+    out.append(leg("configs[2] as worded: Sponza-class, 1920x1080, primary + 1 diffuse bounce (vxrt_render_diffuse_bounce)",
+                   lambda c: rtapi.render_diffuse_bounce(ds.accel, W, H, 0, H, params, px.data_ptr(), seed=3, rays_ptr=c, stream=s),
+                   lambda: rtapi.render_diffuse_bounce(ds.accel, W, H, 0, H, params, px.data_ptr(), seed=3, stream=s), 40, tris=scene.n_tris))
+    out.append(leg("configs[3] on one GPU: Sponza-class, 3840x2160, primary + 1 shadow ray",
+                   lambda c: rtapi.render(ds.accel, 3840, 2160, 0, 2160, params, px.data_ptr(), 1, None, None, c, s),
+                   lambda: rtapi.render(ds.accel, 3840, 2160, 0, 2160, params, px.data_ptr(), 1, None, None, None, s), 20, tris=scene.n_tris))
+    t0 = time.perf_counter()
+    bunny = vrt.scene.procedural("bunny", 6, 0, 1)
+    bs = time.perf_counter() - t0
+    db = vrt.tracer.DeviceScene(bunny, dev)
+    pb = rtapi.default_shade_params()
+    pb.light_pos[:] = (20.0, 260.0, -150.0)
+    out.append(leg("configs[1]: bunny-class (framed), 1024x1024, primary + 1 shadow ray",
+                   lambda c: rtapi.render(db.accel, 1024, 1024, 0, 1024, pb, px.data_ptr(), 1, None, None, c, s),
+                   lambda: rtapi.render(db.accel, 1024, 1024, 0, 1024, pb, px.data_ptr(), 1, None, None, None, s), 100, tris=bunny.n_tris, host_build_s=round(bs, 2)))
+    db.close()
+    if full:
+        import numpy as np
+        t0 = time.perf_counter()
+        hair = vrt.scene.procedural("hairball_fill", 20000, 250, 7)
+        bs = time.perf_counter() - t0
+        dh = vrt.tracer.DeviceScene(hair, dev)
+        b = hair.bounds
+        radius = 0.25 * 0.5 * float(np.linalg.norm(np.array(b[3:]) - np.array(b[:3])))
+        ph = rtapi.default_shade_params()
+        ph.light_pos[:] = (0.0, 400.0, 0.0)
+        out.append(leg("configs[4]: hairball (framed), 1920x1080, 16 spp AO (tmax = 0.25 scene radius)",
+                       lambda c: rtapi.render_ao(dh.accel, W, H, 0, H, ph, 16, radius, px.data_ptr(), seed=7, rays_ptr=c, stream=s),
+                       lambda: rtapi.render_ao(dh.accel, W, H, 0, H, ph, 16, radius, px.data_ptr(), seed=7, stream=s), 5, tris=hair.n_tris, host_build_s=round(bs, 1)))
+        dh.close()
+    return out
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, as fresh child processes (one per
     GPU, `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`), BEFORE anything in this process touches
@@ -348,6 +413,20 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+
+    if a.other_configs_child:
+        # the legs of the other configurations, in a process of their own (started by rank 0 of a 1-GPU run once its own figures are
+        # taken): a process with the bench's streams alive maps more streams than the card has hardware queues, and a small frame's main
+        # and side stream then share one (the bunny-class frame measured 0.50 ms there, 0.35 ms alone)
+        torch.cuda.set_device(0)
+        vrt = importlib.import_module("vortex-raytracing_amd")
+        scene = vrt.scene.procedural("atrium", a.level, 0, 3)
+        ds = vrt.tracer.DeviceScene(scene, "cuda:0")
+        params = vrt.rtapi.default_shade_params()
+        params.light_pos[:] = (300.0, 480.0, 60.0)
+        legs = other_configs(vrt, torch, "cuda:0", ds, scene, params, a.other_configs_child == "full")
+        os.write(json_fd, (json.dumps(legs) + "\n").encode())
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -703,6 +782,15 @@ def main():
                                      "node_fetches": rstats["node_fetches"], "tri_fetches": rstats["tri_fetches"]}
         del rays, hits
 
+    if world == 1 and a.other_configs != "none" and (W, H, a.level) == (1920, 1080, 8):
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--other-configs-child", a.other_configs], capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("[")]
+            extras["other_configs"] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or "no output")[-300:]}
+        except Exception as e:      # (a failed side leg never takes the bench line with it)
+            extras["other_configs"] = {"error": repr(e)[:300]}
+
     if rank == 0:
         if not multi:
             par = "1 GPU: whole frames, %d per set of launches (vxrt_render_batch), %d sets in flight" % (B, nfl) if B > 1 else "1 GPU: whole frame"
@@ -839,6 +927,7 @@ def main():
             else:
                 ach = pr["valu_instr_per_launch"] * world / (rr["ms_per_launch"] * 1e-3) / 1e9
                 blk.update({"achieved": round(ach, 1), "frac": round(ach / (world * SIMDS * clock / 2.0), 4), "valu_instr_per_launch": pr["valu_instr_per_launch"],
+                            "lane_utilisation": pr.get("lane_utilisation"), "wait_any_of_wave_cycles": pr.get("wait_any_of_wave_cycles"),
                             "valu_source": pr.get("source")})
             out["roofline_random_rays"] = blk
         if world == 1 and not a.no_cpu_baseline:

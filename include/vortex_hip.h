@@ -429,7 +429,15 @@ int vxrt_status(void* stream, uint32_t* status);
 int vx_hip_buffer_device_ptr(vx_buffer_h hbuffer, void** dev_ptr);
 
 /* Host-side counters of a hip-backend device: which 0 = acceleration layouts built by vx_start so far (one per scene upload,
- * not one per run), 1 = hipMalloc calls made for buffers (buffers up to 4 KB share slabs). */
+ * not one per run), 1 = hipMalloc calls made for buffers (buffers up to 4 KB share slabs), 2 = runs split over more than one GPU,
+ * 3 = GPUs behind this device.
+ *
+ * More than one GPU behind ONE vx_device (the unmodified reference host, which opens one device: tracer.cpp:78):
+ *   VORTEX_HIP_DEVICES=0,1,2,3   the first index holds the address space (every vx_mem_* / vx_copy_* call), the others keep a copy of the
+ * scene's seven buffers (refreshed when one is uploaded again) and their own acceleration layout.  vx_start of a whole frame traces tile
+ * rows k, k+n, ... on the k-th listed device and copies them into the first device's output buffer, behind which the run's last kernel
+ * waits: vx_ready_wait, vx_copy_from_dev and vx_mpm_query (MINSTRET = rays of all shares) behave as with one GPU.  A run the host restricted
+ * itself (DCR 0x7F0-0x7F3), a reference-quirks run and the software twin's kernel stay on the first device. */
 int vx_hip_device_stat(vx_device_h hdevice, uint32_t which, uint64_t* value);
 
 const char* vxrt_version(void);

@@ -292,3 +292,79 @@ def test_reference_quirks_dcr_renders_what_the_rtu_would_on_this_address_space(v
     tr.close()
     print("quirk mode: %d rays took the stale base_ptr, %d of %d pixels differ from the canonical frame" % (st["stale_base"], int((quirk != canon).sum()), w * h))
     assert st["stale_base"] > 0 and (quirk != canon).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,shape", [("0,0", (200, 120)), ("0,0,0", (136, 61)), ("0,0,0,0,0", (64, 40))])
+def test_vortex_hip_devices_splits_a_frame_behind_one_vx_device(vrt, po, gpu_device, monkeypatch, devices, shape):
+    """VORTEX_HIP_DEVICES=a,b,...: the unmodified reference host opens ONE device (tracer.cpp:78); the backend keeps the address space on the
+    first listed GPU and has every listed GPU trace tile rows k, k+n, ... of each whole frame from its own copy of the scene.  On the one-GPU
+    box the list repeats device 0 (every share has its own copy, layout, stream and framebuffer, as on separate GPUs; only the copies stay
+    on one card).  The frame, the ray count (MINSTRET) and a re-uploaded scene buffer must behave as with one device; a run the host
+    restricts with the row-window DCRs stays on the first device.  (136x61: the frame's last tile row is 5 rows high.)"""
+    w, h = shape
+    sc = vrt.scene.procedural("blob", 3, 0, 2)
+    want = po.render_ex(sc, w, h, shadow=1)[0]
+    n = len(devices.split(","))
+    monkeypatch.setenv("VORTEX_HIP_DEVICES", devices)
+    tr = vrt.tracer.Tracer(w, h)
+    tr.init(sc)
+    monkeypatch.delenv("VORTEX_HIP_DEVICES")
+    tr.setup(shadow=True)
+    assert tr.dev.hip_stat(3) == n
+    px = tr.run()
+    assert np.array_equal(px, want)
+    rays = tr.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0)
+    one = vrt.tracer.Tracer(w, h)
+    one.init(sc)
+    one.setup(shadow=True)
+    assert np.array_equal(one.run(), want)
+    assert rays == one.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0) and one.dev.hip_stat(3) == 1
+    one.close()
+    assert tr.dev.hip_stat(2) == 1 and tr.dev.hip_stat(0) == n     # one layout per share, built once
+    for _ in range(3):
+        assert np.array_equal(tr.run(), want)
+    assert tr.dev.hip_stat(2) == 4 and tr.dev.hip_stat(0) == n
+    # a re-uploaded scene buffer reaches every share: move the instance and compare with the oracle on the moved scene
+    blas = sc["blas"].copy().view(np.float32)
+    blas[17 + 3] += 6.0        # transform[0][3]
+    blas[1 + 3] -= 6.0         # invTransform[0][3]
+    tr.bufs["blas"].write(blas.view(np.uint8))
+    sc2 = vrt.scene.Scene(dict(sc.buffers, blas=blas.view(np.uint8)))
+    want2 = po.render_ex(sc2, w, h, shadow=1)[0]
+    assert not np.array_equal(want2, want)
+    assert np.array_equal(tr.run(), want2)
+    # a row window set by the host: that run is the first device's alone, and renders only the window (setup() uploads the original scene again)
+    before = tr.dev.hip_stat(2)
+    tr.setup(shadow=True, row_window=(8, 24))
+    part = tr.run()
+    assert tr.dev.hip_stat(2) == before
+    assert np.array_equal(part[8:24], want[8:24])
+    tr.close()
+
+
+@pytest.mark.gpu
+def test_vortex_hip_devices_rejects_a_malformed_list(vrt, gpu_device, monkeypatch):
+    for bad in ("0;1", "x", "0,99"):
+        monkeypatch.setenv("VORTEX_HIP_DEVICES", bad)
+        with pytest.raises(vrt.runtime.VxError):
+            vrt.runtime.Device()
+    monkeypatch.delenv("VORTEX_HIP_DEVICES")
+
+
+@pytest.mark.gpu
+def test_host_program_on_two_shares(vrt, po, gpu_device, tmp_path):
+    """The C++ host (same call sequence as the reference's main.cpp) with VORTEX_HIP_DEVICES set: same picture."""
+    import subprocess
+    exe = os.path.join(vrt.LIB_DIR, "rt_host")
+    if not os.path.exists(exe):
+        pytest.skip("rt_host not built")
+    out = tmp_path / "out.ppm"
+    env = dict(os.environ, LD_LIBRARY_PATH=vrt.LIB_DIR + ":" + os.environ.get("LD_LIBRARY_PATH", ""), VORTEX_DRIVER="hip", VORTEX_HIP_DEVICES="0,0")
+    r = subprocess.run([exe, "-m", "proc:cornell", "-w", "48", "-h", "40", "-o", str(out), "-k", os.path.join(vrt.VXBIN_DIR, "kernel.vxbin")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    vals = np.array(out.read_text().split()[4:], dtype=np.int64).reshape(40, 48, 3)
+    rpx, _, _ = po.render(vrt.scene.procedural("cornell"), 48, 40)
+    want = np.stack([(rpx >> 16) & 255, (rpx >> 8) & 255, rpx & 255], -1)[::-1]
+    assert np.array_equal(vals, want)

@@ -18,13 +18,14 @@ for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT"; do
   i=$((i+1))
   echo "pass $i: $pmc"
-  timeout -k 5 150 rocprofv3 --pmc $pmc --output-format csv -d "$OUT/pass$i" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1 --random-rays 0 "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed: $pmc" | tee -a "$OUT/errors.log"
+  timeout -k 5 150 rocprofv3 --pmc $pmc --output-format csv -d "$OUT/pass$i" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1 --random-rays 0 --other-configs none "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed: $pmc" | tee -a "$OUT/errors.log"
 done
 python "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
 # one more pass WITH the random-ray leg (16 Mi rays through vxrt_trace), summarised on its own (the frame kernels' per-frame figures above
 # are ratios of dispatch counts and must not see its extra dispatches): the instruction count of the ray-buffer kernel's launch
 echo "pass rr: SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY (random-ray leg on)"
-timeout -k 5 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d "$OUT/rr/pass1" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1 "$@" > "$OUT/pass_rr.log" 2>&1 || echo "pass rr (random rays) failed" | tee -a "$OUT/errors.log"
+timeout -k 5 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d "$OUT/rr/pass1" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1 --other-configs none "$@" > "$OUT/pass_rr.log" 2>&1 || echo "pass rr (random rays) failed" | tee -a "$OUT/errors.log"
+timeout -k 5 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d "$OUT/rr/pass2" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1 --other-configs none "$@" > "$OUT/pass_rr2.log" 2>&1 || echo "pass rr2 (random rays, lane utilisation) failed" | tee -a "$OUT/errors.log"
 python "$ROOT/tools/pmc_summary.py" "$OUT/rr" > "$OUT/summary_rr.txt" 2>&1
 rm -rf "$OUT/rr"
 cat "$OUT/summary.txt"

@@ -106,5 +106,10 @@ if tr and rr_line:
     per_launch = sum(v["SQ_INSTS_VALU"] for v in tr.values())
     res["random_rays"] = {"n": rr_line["rays_per_gpu"], "node_fetches": rr_line["node_fetches"], "tri_fetches": rr_line["tri_fetches"],
                           "valu_instr_per_launch": int(per_launch), "source": label + " (pass with the random-ray leg: SQ_INSTS_VALU, mean over its launches)"}
+    big = max(tr.values(), key=lambda v: v["SQ_INSTS_VALU"])       # the main instantiation (the EXACT launch carries a handful of rays)
+    if big.get("SQ_ACTIVE_INST_VALU") and big.get("SQ_THREAD_CYCLES_VALU"):
+        res["random_rays"]["lane_utilisation"] = round(big["SQ_THREAD_CYCLES_VALU"] / (64.0 * big["SQ_ACTIVE_INST_VALU"]), 4)
+    if big.get("SQ_WAIT_ANY") and big.get("SQ_WAVE_CYCLES"):
+        res["random_rays"]["wait_any_of_wave_cycles"] = round(big["SQ_WAIT_ANY"] / big["SQ_WAVE_CYCLES"], 4)
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("valu_instr_per_frame", "valu_instr_classes", "valu_simd_cycles_per_frame", "valu_simd_cycles_all_x2.2", "valu_simd_cycles_slow_class_upper_bound_x4.1", "hbm_bytes_per_frame")}))

@@ -26,8 +26,8 @@ cat "$OUT/driver_cmd.txt"
 tools/rehearse_multi.sh > "$OUT/multi_gpu_rehearsal.txt" 2>&1; tail -4 "$OUT/multi_gpu_rehearsal.txt"
 python tools/config_bench.py 2 3 4 5 6 7 2>/dev/null | grep "^{" > "$OUT/configs.jsonl"; cut -c1-260 "$OUT/configs.jsonl"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_pipelined" -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/stats_pipelined.log" 2>&1 || { echo "rocprof pipelined failed"; exit 1; }
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -- python "$ROOT/bench.py" --no-cpu-baseline --frames-in-flight 1 > "$OUT/stats_serial.log" 2>&1 || { echo "rocprof serial failed"; exit 1; }
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_pipelined" -- python "$ROOT/bench.py" --no-cpu-baseline --other-configs none > "$OUT/stats_pipelined.log" 2>&1 || { echo "rocprof pipelined failed"; exit 1; }
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -- python "$ROOT/bench.py" --no-cpu-baseline --frames-in-flight 1 --other-configs none > "$OUT/stats_serial.log" 2>&1 || { echo "rocprof serial failed"; exit 1; }
 for m in pipelined serial; do
   f=$(find "$OUT/stats_$m" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cut -c1-400 "$f" | head -12 > "$OUT/kernel_stats_$m.csv" && head -6 "$OUT/kernel_stats_$m.csv" | cut -c1-200

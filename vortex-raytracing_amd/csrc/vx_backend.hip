@@ -68,9 +68,28 @@ struct vx_buffer {          // same role as callbacks.inc:14-18
   uint64_t size;
 };
 
+// One more GPU behind the same vx_device (VORTEX_HIP_DEVICES=a,b,...): it keeps its own copy of the scene's buffers and its own
+// acceleration layout, traces tile rows k, k+n, ... of every whole frame into a framebuffer of its own and copies them into the first
+// device's output buffer, where vx_copy_from_dev finds the frame.  The unmodified reference host sees one device.
+struct Helper {
+  int hip_dev = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;          // behind the share's copy into the first device's framebuffer
+  struct Mirror { const void* src = nullptr; uint64_t version = 0, bytes = 0; void* dptr = nullptr; } m[7];
+  vxrt_accel_t* accel = nullptr;
+  uint64_t key[14] = {0};
+  uint32_t* fb = nullptr; uint64_t fb_bytes = 0;
+  unsigned long long* d_rays = nullptr;
+  unsigned long long* h_back = nullptr;   // pinned, portable: [0] rays of the share, [1] that device's status word
+};
+
 struct vx_device {
   int hip_dev = 0;
   hipStream_t stream = nullptr;
+  std::vector<Helper> helpers;
+  hipEvent_t ev_scene = nullptr;      // on `stream`, behind the uploads a helper's mirror copies read
+  uint32_t fanned = 0;                // devices the pending run was split over (1 = this one alone)
+  uint64_t n_fanned_runs = 0;         // vx_hip_device_stat 2
   bool run_pending = false;
   bool have_timing = false;
   std::map<uint64_t, Alloc> allocs;   // keyed by va
@@ -106,6 +125,22 @@ struct vx_device {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { VXLOG("no HIP device"); return -1; }
     hip_dev = e ? std::atoi(e) % n : 0;
+    // VORTEX_HIP_DEVICES=0,1,2,3: the first entry is the device of the address space, the others trace a share of every whole frame
+    // (an index may repeat -- two shares on one GPU -- which is how the one-GPU tests drive this path)
+    std::vector<int> list;
+    if (const char* l = std::getenv("VORTEX_HIP_DEVICES")) {
+      for (const char* p = l; *p;) {
+        char* end = nullptr;
+        const long v = std::strtol(p, &end, 10);
+        if (end == p) { VXLOG("VORTEX_HIP_DEVICES: expected a comma-separated list of device indices, got '%s'", l); return -1; }
+        if (v < 0 || v >= n) { VXLOG("VORTEX_HIP_DEVICES: device %ld of %d", v, n); return -1; }
+        list.push_back((int)v);
+        p = (*end == ',') ? end + 1 : end;
+        if (*end && *end != ',') { VXLOG("VORTEX_HIP_DEVICES: expected a comma-separated list of device indices, got '%s'", l); return -1; }
+      }
+      if (list.size() > 8) { VXLOG("VORTEX_HIP_DEVICES: at most 8 devices"); return -1; }
+      if (!list.empty()) hip_dev = list[0];
+    }
     if (hipSetDevice(hip_dev) != hipSuccess) return -1;
     if (hipGetDeviceProperties(&prop, hip_dev) != hipSuccess) return -1;
     total_mem = prop.totalGlobalMem;
@@ -114,12 +149,137 @@ struct vx_device {
     if (hipHostMalloc((void**)&h_back, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return -1;
     if (hipHostMalloc((void**)&stage, kStageSlot * kStageSlots, hipHostMallocDefault) != hipSuccess) return -1;
     for (int i = 0; i < 8; ++i) h_back[i] = 0;
+    if (list.size() > 1) {
+      if (hipEventCreateWithFlags(&ev_scene, hipEventDisableTiming) != hipSuccess) return -1;
+      for (size_t k = 1; k < list.size(); ++k) {
+        Helper h;
+        h.hip_dev = list[k];
+        if (hipSetDevice(h.hip_dev) != hipSuccess) return -1;
+        if (h.hip_dev != hip_dev) {
+          // both directions: the mirrors are read from the first device, the share of the frame is written to it
+          hipError_t pe = hipDeviceEnablePeerAccess(hip_dev, 0);
+          if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) VXLOG("device %d cannot address device %d directly (%s): copies between them are staged", h.hip_dev, hip_dev, hipGetErrorString(pe));
+          (void)hipGetLastError();
+        }
+        if (hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking) != hipSuccess) return -1;
+        if (hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess) return -1;
+        if (hipMalloc((void**)&h.d_rays, sizeof(unsigned long long)) != hipSuccess || hipMemset(h.d_rays, 0, sizeof(unsigned long long)) != hipSuccess) return -1;
+        if (hipHostMalloc((void**)&h.h_back, 8 * sizeof(unsigned long long), hipHostMallocPortable) != hipSuccess) return -1;
+        for (int i = 0; i < 8; ++i) h.h_back[i] = 0;
+        helpers.push_back(h);
+      }
+      if (hipSetDevice(hip_dev) != hipSuccess) return -1;
+      for (auto& h : helpers) if (h.hip_dev != hip_dev) {
+        hipError_t pe = hipDeviceEnablePeerAccess(h.hip_dev, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      }
+    }
     return 0;
+  }
+
+  void free_helper(Helper& h) {
+    (void)hipSetDevice(h.hip_dev);
+    if (h.stream) (void)hipStreamSynchronize(h.stream);
+    if (h.accel) (void)vxrt_accel_destroy(h.accel);
+    for (auto& m : h.m) if (m.dptr) (void)hipFree(m.dptr);
+    if (h.fb) (void)hipFree(h.fb);
+    if (h.d_rays) (void)hipFree(h.d_rays);
+    if (h.h_back) (void)hipHostFree(h.h_back);
+    if (h.done) (void)hipEventDestroy(h.done);
+    if (h.stream) (void)hipStreamDestroy(h.stream);
+    h = Helper{};
+  }
+
+  // a helper's copy of the scene (the seven buffers of `sc`, as the first device holds them now) and its layout for them;
+  // `ver` = upload versions of those buffers, `bytes` = their sizes.  Runs on the helper's stream, behind ev_scene.
+  int prepare_helper(Helper& h, const vxrt_scene_t& sc, const uint64_t ver[7], const uint64_t bytes[7], uint64_t fb_bytes) {
+    if (hipSetDevice(h.hip_dev) != hipSuccess) return -1;
+    if (hipStreamWaitEvent(h.stream, ev_scene, 0) != hipSuccess) return -1;
+    const void* src[7] = {sc.tlas, sc.blas, sc.bvh, sc.tri, sc.triEx, sc.mat, sc.tex};
+    bool changed = false;
+    for (int i = 0; i < 7; ++i) {
+      Helper::Mirror& m = h.m[i];
+      if (m.src == src[i] && m.bytes == bytes[i] && m.version == ver[i]) continue;
+      changed = true;
+      if (m.bytes != bytes[i] || !m.dptr) {
+        if (hipStreamSynchronize(h.stream) != hipSuccess) return -1;
+        if (h.accel) { (void)vxrt_accel_destroy(h.accel); h.accel = nullptr; }
+        if (m.dptr) (void)hipFree(m.dptr);
+        m = Helper::Mirror{};
+        if (src[i] && bytes[i]) {
+          if (hipMalloc(&m.dptr, bytes[i]) != hipSuccess) { VXLOG("hipMalloc(%llu) on device %d failed", (unsigned long long)bytes[i], h.hip_dev); return -1; }
+          ++n_hip_mallocs;
+        }
+      }
+      if (src[i] && bytes[i]) {
+        const hipError_t ce = h.hip_dev == hip_dev ? hipMemcpyAsync(m.dptr, src[i], bytes[i], hipMemcpyDeviceToDevice, h.stream)
+                                                   : hipMemcpyPeerAsync(m.dptr, h.hip_dev, src[i], hip_dev, bytes[i], h.stream);
+        if (ce != hipSuccess) { VXLOG("scene copy to device %d: %s", h.hip_dev, hipGetErrorString(ce)); return -1; }
+      }
+      m.src = src[i]; m.bytes = bytes[i]; m.version = ver[i];
+    }
+    if (h.fb_bytes < fb_bytes) {
+      if (hipStreamSynchronize(h.stream) != hipSuccess) return -1;
+      if (h.fb) (void)hipFree(h.fb);
+      h.fb = nullptr; h.fb_bytes = 0;
+      if (hipMalloc((void**)&h.fb, fb_bytes) != hipSuccess) return -1;
+      ++n_hip_mallocs;
+      h.fb_bytes = fb_bytes;
+    }
+    if (changed || !h.accel) {
+      if (h.accel) { (void)vxrt_accel_destroy(h.accel); h.accel = nullptr; }
+      vxrt_scene_t hs = sc;
+      hs.tlas = h.m[0].dptr; hs.blas = h.m[1].dptr; hs.bvh = h.m[2].dptr; hs.tri = h.m[3].dptr;
+      hs.triEx = h.m[4].dptr; hs.mat = h.m[5].dptr; hs.tex = h.m[6].dptr;
+      ++n_accel_builds;
+      if (vxrt_accel_build(&hs, h.stream, &h.accel) != 0) { VXLOG("start: device %d rejected the scene its first device accepted", h.hip_dev); return -1; }
+    }
+    return 0;
+  }
+
+  // tile rows k, k+n, ... of the helper's framebuffer into the same rows of the first device's output buffer, then the share's ray
+  // count and that device's status word into pinned memory, then the event the first device's stream waits for
+  int finish_helper(Helper& h, uint32_t k, uint32_t n, uint32_t width, uint32_t height, uint32_t* dst) {
+    if (hipSetDevice(h.hip_dev) != hipSuccess) return -1;
+    const size_t row = (size_t)width * 4, band = row * 8, pitch = band * n;
+    const uint32_t tile_rows = (height + 7) / 8;
+    const uint32_t mine = tile_rows > k ? (tile_rows - k + n - 1) / n : 0;       // tile rows k, k+n, ...
+    uint32_t full = mine;
+    const uint32_t last = k + (mine ? (mine - 1) * n : 0);
+    const bool ragged = mine && (last + 1) * 8 > height;                         // the frame's last tile row, cut short by the frame
+    if (ragged) --full;
+    hipError_t ce = hipSuccess;
+    if (full) ce = hipMemcpy2DAsync((char*)dst + band * k, pitch, (const char*)h.fb + band * k, pitch, band, full, hipMemcpyDeviceToDevice, h.stream);
+    if (ce != hipSuccess) {
+      // (no rectangle copy between these devices: one copy per tile row)
+      (void)hipGetLastError();
+      ce = hipSuccess;
+      for (uint32_t i = 0; i < full && ce == hipSuccess; ++i) {
+        const size_t off = band * (k + (size_t)i * n);
+        ce = h.hip_dev == hip_dev ? hipMemcpyAsync((char*)dst + off, (const char*)h.fb + off, band, hipMemcpyDeviceToDevice, h.stream)
+                                  : hipMemcpyPeerAsync((char*)dst + off, hip_dev, (const char*)h.fb + off, h.hip_dev, band, h.stream);
+      }
+    }
+    if (ce == hipSuccess && ragged) {
+      const size_t off = band * last, len = row * (height - last * 8);
+      ce = h.hip_dev == hip_dev ? hipMemcpyAsync((char*)dst + off, (const char*)h.fb + off, len, hipMemcpyDeviceToDevice, h.stream)
+                                : hipMemcpyPeerAsync((char*)dst + off, hip_dev, (const char*)h.fb + off, h.hip_dev, len, h.stream);
+    }
+    if (ce != hipSuccess) { VXLOG("copy of device %d's share of the frame: %s", h.hip_dev, hipGetErrorString(ce)); return -1; }
+    uint32_t* st = vxrt_status_word_device();
+    if (!st) return -1;
+    h.h_back[1] = 0;
+    hipLaunchKernelGGL(vx_readback_kernel, dim3(1), dim3(1), 0, h.stream, h.d_rays, (const uint32_t*)st, h.h_back);
+    if (hipGetLastError() != hipSuccess) return -1;
+    return hipEventRecord(h.done, h.stream) == hipSuccess ? 0 : -1;
   }
 
   ~vx_device() {
     (void)hipSetDevice(hip_dev);
     if (stream) (void)hipStreamSynchronize(stream);   // simx dtor waits for the run (vortex.cpp:69-71)
+    for (auto& h : helpers) free_helper(h);
+    (void)hipSetDevice(hip_dev);
+    if (ev_scene) (void)hipEventDestroy(ev_scene);
     if (accel) (void)vxrt_accel_destroy(accel);
     if (rc_accel) (void)vxrc_accel_destroy(rc_accel);
     for (auto& kv : allocs) if (kv.second.dptr && !kv.second.pooled) (void)hipFree(kv.second.dptr);
@@ -263,6 +423,7 @@ struct vx_device {
     run_pending = false;
     last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); have_timing = true;
     last_rays = h_back[0];   // copied back by the stream at the end of the run (enqueue_readback)
+    if (fanned > 1) for (auto& h : helpers) last_rays += h.h_back[0];   // (their streams' events were joined by `stream` before its own readback)
   }
 
   int upload(uint64_t va, const void* src, uint64_t size) {
@@ -347,6 +508,7 @@ struct vx_device {
 int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   wait_idle();   // ensure prior run completed (vortex.cpp:331-333)
   (void)hipSetDevice(hip_dev);
+  fanned = 1;
   dcrs[VX_DCR_BASE_STARTUP_ADDR0] = (uint32_t)krnl_va;
   dcrs[VX_DCR_BASE_STARTUP_ADDR1] = (uint32_t)(krnl_va >> 32);
   dcrs[VX_DCR_BASE_STARTUP_ARG0] = (uint32_t)args_va;
@@ -505,6 +667,42 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   // takes no sample index, the colour accumulation is commented out), so the pixel is the one sample's -- and the run costs spp times the rays
   // and the time.  Honoured as written: the frame is traced spp times (same pixels; MINSTRET and MCYCLE are what a `-s 4` run expects).
   int rc = 0;
+  const uint32_t n_dev = (uint32_t)helpers.size() + 1;
+  if (n_dev > 1 && row_stride <= 1 && y0 == 0 && y1 == ka.dst_height && (ka.dst_height + 7) / 8 >= n_dev) {
+    // VORTEX_HIP_DEVICES: a whole frame is split by interleaved 8-row tile rows over the listed devices (the split bench.py's ranks use);
+    // a run the host already restricted (DCR 0x7F0-0x7F3) stays on the first device
+    const uint64_t ver[7] = {r_tlas.a->version, r_blas.a->version, r_bvh.a->version, r_tri.a->version, r_triex.a->version, r_mat.a->version, r_tex.a ? r_tex.a->version : 0};
+    const uint64_t bytes[7] = {r_tlas.a->size - r_tlas.off, r_blas.a->size - r_blas.off, r_bvh.a->size - r_bvh.off, r_tri.a->size - r_tri.off,
+                               r_triex.a->size - r_triex.off, r_mat.a->size - r_mat.off, r_tex.a ? r_tex.a->size - r_tex.off : 0};
+    if (hipEventRecord(ev_scene, stream) != hipSuccess) return -1;
+    for (auto& h : helpers)
+      if (prepare_helper(h, sc, ver, bytes, (uint64_t)ka.dst_width * ka.dst_height * 4) != 0) { (void)hipSetDevice(hip_dev); return -1; }
+    t_begin = std::chrono::steady_clock::now();
+    for (uint32_t smp = 0; smp < ka.samples_per_pixel && rc == 0; ++smp) {
+      (void)hipSetDevice(hip_dev);
+      rc = vxrt_render_interleaved(accel, ka.dst_width, ka.dst_height, 0, n_dev, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream);
+      for (uint32_t k = 1; k < n_dev && rc == 0; ++k) {
+        Helper& h = helpers[k - 1];
+        (void)hipSetDevice(h.hip_dev);
+        rc = vxrt_render_interleaved(h.accel, ka.dst_width, ka.dst_height, k, n_dev, &sp, (int)shadow, h.fb, nullptr, nullptr, h.d_rays, h.stream);
+      }
+    }
+    for (uint32_t k = 1; k < n_dev && rc == 0; ++k) rc = finish_helper(helpers[k - 1], k, n_dev, ka.dst_width, ka.dst_height, dstp);
+    (void)hipSetDevice(hip_dev);
+    for (auto& h : helpers) if (rc == 0 && hipStreamWaitEvent(stream, h.done, 0) != hipSuccess) rc = -1;
+    if (rc != 0) {
+      VXLOG("start: launch on %u devices rejected", n_dev);
+      for (auto& h : helpers) { (void)hipSetDevice(h.hip_dev); (void)hipStreamSynchronize(h.stream); (void)hipMemsetAsync(h.d_rays, 0, sizeof(unsigned long long), h.stream); }
+      (void)hipSetDevice(hip_dev);
+      (void)hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream);
+      return -1;
+    }
+    if (enqueue_readback() != 0) return -1;
+    fanned = n_dev;
+    ++n_fanned_runs;
+    run_pending = true;
+    return 0;
+  }
   for (uint32_t smp = 0; smp < ka.samples_per_pixel && rc == 0; ++smp)
     rc = row_stride > 1 ? vxrt_render_interleaved(accel, ka.dst_width, ka.dst_height, y0 / 8u, row_stride, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream)
                         : vxrt_render(accel, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream);
@@ -600,8 +798,16 @@ int vx_device::ready_wait(uint64_t timeout_ms) {
     if ((uint64_t)us >= timeout_ms * 1000ull) return -1;
     if (us > 2000) std::this_thread::sleep_for(std::chrono::microseconds(20));   // frames take well under 2 ms: poll those without sleeping
   }
+  const uint32_t was_fanned = fanned;
   finish_run();
-  const uint32_t st = (uint32_t)h_back[1];
+  uint32_t st = (uint32_t)h_back[1];
+  if (was_fanned > 1) for (auto& h : helpers) if (h.h_back[1]) {
+    st |= (uint32_t)h.h_back[1];
+    uint32_t cleared = 0;
+    (void)hipSetDevice(h.hip_dev);
+    (void)vxrt_status(h.stream, &cleared);
+    (void)hipSetDevice(hip_dev);
+  }
   if (st != 0) {
     uint32_t cleared = 0;
     (void)vxrt_status(stream, &cleared);   // read-and-clear, so that the next run starts clean
@@ -628,6 +834,8 @@ extern "C" int vx_hip_device_stat(vx_device_h hdevice, uint32_t which, uint64_t*
   switch (which) {
   case 0: *value = d->n_accel_builds; return 0;
   case 1: *value = d->n_hip_mallocs; return 0;
+  case 2: *value = d->n_fanned_runs; return 0;          // runs split over the devices of VORTEX_HIP_DEVICES
+  case 3: *value = d->helpers.size() + 1; return 0;     // devices behind this vx_device
   }
   return -1;
 }

@@ -113,7 +113,7 @@ class Device:
             self.handle = None
 
     def hip_stat(self, which):
-        """vx_hip_device_stat: 0 = acceleration layouts built, 1 = hipMalloc calls for buffers"""
+        """vx_hip_device_stat: 0 = acceleration layouts built, 1 = hipMalloc calls for buffers, 2 = runs split over several GPUs, 3 = GPUs behind the device"""
         v = C.c_uint64()
         check(hip_lib().vx_hip_device_stat(self.handle, which, C.byref(v)), "vx_hip_device_stat")
         return int(v.value)
