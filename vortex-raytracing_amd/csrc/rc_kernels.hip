@@ -43,6 +43,9 @@
 #endif
 #ifndef RC_WAVES
 #define RC_WAVES 7              // wavefronts per SIMD the kernel is compiled for
+#ifndef RC_LEAF_LANES
+#define RC_LEAF_LANES 1         // leaves are tested once this many lanes hold one (or no lane holds a node): a lane with a leaf WAITS -- it cannot go on, the order of its triangle tests is the reference's
+#endif
 #endif
 #define RC_STATUS_STACK 1u      // same bits as the RTU path's status word
 #define RC_STATUS_ITER 2u
@@ -486,7 +489,8 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
         else if (hitRight) cur = right;
         else pop();
       }
-      if (__ballot(rc_is_leaf(cur)) != 0ull) {
+      const unsigned long long leaf_lanes = __ballot(rc_is_leaf(cur));
+      if (leaf_lanes != 0ull && (RC_LEAF_LANES <= 1 || __popcll(leaf_lanes) >= RC_LEAF_LANES || __ballot(rc_is_node(cur)) == 0ull)) {
         work += 2u;
         if (rc_is_leaf(cur)) {
           // ---- BVH leaf (render.h:88-98): triangles in triIdx order, strict '<' ----
