@@ -292,12 +292,17 @@ def tree_id(scene):
 def profile_mismatch(prof, ident):
     """Why the checked-in per-frame counters (profiles/valu_profile.json) do NOT describe this run, or None if they do: the file
     carries the identity of the run it was taken from -- frame size, tree hash and node count, kernel source id, and the traversal
-    counts the counting build reported there -- and every one of them must equal this run's."""
+    counts the counting build reported there.  All must equal this run's, except the two fetch counts, which may differ by 0.1 %: the counting
+    build's totals move by a few thousandths of a per cent between runs (which of a tile's rays a lane shares its leaf pass with depends on the
+    order tiles were handed out), far below what a different tree, frame or kernel would change them by."""
     want = prof.get("identity")
     if not want:
         return "profiles/valu_profile.json carries no identity block (written by an older tools/roofline_from_pmc.py)"
     for k in ("width", "height", "shadow", "bvh_nodes", "tree_sha16", "kernel_source_sha16", "node_fetches_timed", "tri_fetches_timed", "rays"):
-        if want.get(k) != ident.get(k):
+        a, b = want.get(k), ident.get(k)
+        if k.endswith("_fetches_timed") and a and b and abs(a - b) <= 1e-3 * max(a, b):
+            continue
+        if a != b:
             return "profiles/valu_profile.json was taken on another %s (%r there, %r here): re-run tools/round_profile.sh" % (k, want.get(k), ident.get(k))
     return None
 
@@ -920,7 +925,8 @@ def main():
             why_rr = why_not
             if not why_rr and not pr:
                 why_rr = "profiles/valu_profile.json holds no counter pass of the ray-buffer kernel"
-            if not why_rr and (pr.get("n") != rr["rays_per_gpu"] or pr.get("node_fetches") != rr["node_fetches"] or pr.get("tri_fetches") != rr["tri_fetches"]):
+            near = lambda a, b: bool(a and b) and abs(a - b) <= 1e-3 * max(a, b)      # (see profile_mismatch)
+            if not why_rr and (pr.get("n") != rr["rays_per_gpu"] or not near(pr.get("node_fetches"), rr["node_fetches"]) or not near(pr.get("tri_fetches"), rr["tri_fetches"])):
                 why_rr = "the profiled ray buffer differs from this run's (rays or fetch counts)"
             if why_rr:
                 blk["frac_is_null_because"] = why_rr
