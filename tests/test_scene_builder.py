@@ -126,7 +126,7 @@ def test_every_builder_variant_keeps_the_invariants():
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         outs = {}
-        for mode, kv in (("0", {"VXS_COLLAPSE": "0"}), ("1", {"VXS_COLLAPSE": "1", "VXS_OPTIMIZE": "0"}), ("2", {}), ("3", {"VXS_OPTIMIZE_LOCAL": "1"})):
+        for mode, kv in (("0", {"VXS_COLLAPSE": "0"}), ("1", {"VXS_COLLAPSE": "1", "VXS_OPTIMIZE": "0"}), ("2", {}), ("3", {"VXS_OPTIMIZE_LOCAL": "0"})):
             env = dict(os.environ, **kv)
             r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "m" + mode)], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
