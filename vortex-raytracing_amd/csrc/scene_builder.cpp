@@ -104,6 +104,15 @@ struct WideNode {           // float-box node before quantisation (role of bvh_n
 // (bits [1:0] [3:2] [5:4]: slots given to the left child when the two children share 2 / 3 / 4; [6] [7] [8]: stays one child when
 // offered 2 / 3 / 4; [9]: leaf).  The dynamic programme of Ylitie, Karras & Laine 2017 ("Efficient incoherent ray traversal on GPUs
 // through compressed wide BVHs", s3.1) for width 4; csrc/bvh_builder.hip runs the same one on the GPU.
+// one background thread at a time for work nobody waits for (freeing a big array); joined before the next one starts and when the library
+// is unloaded or the process exits, so no thread of this library outlives its code
+struct Disposer {
+  std::thread th;
+  template <class F> void run(F&& f) { if (th.joinable()) th.join(); th = std::thread(std::forward<F>(f)); }
+  ~Disposer() { if (th.joinable()) th.join(); }
+};
+static Disposer g_disposer;
+
 struct BinNode {
   Box box;
   uint32_t first = 0, count = 0;
@@ -405,7 +414,7 @@ private:
     }
     lap("wide nodes emitted");
     // (returning a gigabyte of touched pages to the system costs most of a second at 10 M triangles: not on the caller's time)
-    if (bn.size() > (1u << 20)) { auto* gone = new std::vector<BinNode>(std::move(bn)); std::thread([gone]() { delete gone; }).detach(); }
+    if (bn.size() > (1u << 20)) { auto* gone = new std::vector<BinNode>(std::move(bn)); g_disposer.run([gone]() { delete gone; }); }
   }
 
   // Insertion-based optimisation of the binary tree (Bittner, Hapala & Havran, "Fast insertion-based optimization of bounding volume
