@@ -709,14 +709,17 @@ def main():
         stream.wait_stream(st_)
     end_ev = torch.cuda.Event(enable_timing=True)
     end_ev.record(stream)
-    if probe:
-        probe.launch(1, sptr)          # (behind the end event: not part of the span it closes; its ~30 us are inside the host-timed region)
     t_issued = time.perf_counter() - t0     # host time to issue the K steps (diagnostic: a host-bound run has t_issued ~ elapsed)
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if probe:
+        # the second clock probe, right behind the region's closing synchronisation (tens of microseconds after the last step: the chip moves its
+        # clock over milliseconds).  A measurement's own kernel -- a 30 us spin -- is not part of the K steps and is not timed with them.
+        probe.launch(1, sptr)
+        torch.cuda.synchronize()
     if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -841,7 +844,7 @@ def main():
                 "peak_is": "1024 SIMDs x clock held in the timed region / 2 cycles per wave64 VALU instruction (guide constant)",
                 "clock_ghz_held": round(clock_held, 4) if clock_held else None,
                 "clock_probe_ghz_before_after": [round(c, 4) if c else None for c in clk],
-                "clock_source": "one-wavefront s_memtime / s_memrealtime probe right before the first and right after the last timed step (lib/libvxrt_calib.so)" if clock_held
+                "clock_source": "one-wavefront s_memtime / s_memrealtime probe right before the timed region opens and right after it closes (lib/libvxrt_calib.so)" if clock_held
                                 else "nominal %.1f GHz (probe library not available)" % CLOCK_GHZ,
                 "kernel": "rt_persistent_kernel<JOB_RENDER%s> (+ EXACT launches + rt_shade_kernel)" % ("_SHADOW" if shadow else ""),
                 "kernel_ms": round(kern_ms, 4), "kernel_ms_overlapped": round(ovl_ms, 4), "kernel_ms_isolated": round(iso_ms, 4),
