@@ -13,21 +13,13 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FLAGS = ["-DRT_TOP_NODES=84", "-DRT_LDS_STACK_RENDER=5", "-DRT_LDS_STACK_RENDER_PACKED=4", "-DRT_TRI_LDS=4", "-DRT_TRI_LDS_MIN=2"]
 
 
 def test_lds_staging_variants_stay_bit_equal(vrt, gpu_device):
     bld = importlib.import_module("vortex-raytracing_amd.build")
     if not os.path.exists(bld.HIPCC):
         pytest.skip("hipcc not installed on this box")
-    d = os.path.join(bld.HERE, "lib_ab", "lds_staging")
-    os.makedirs(d, exist_ok=True)
-    so = os.path.join(d, "libvortex-hip.so")
-    src = [os.path.join(bld.CSRC, f) for f in bld.PRODUCT_HIP_SOURCES]
-    if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in src):
-        subprocess.run([bld.HIPCC] + bld.HIP_FLAGS + FLAGS + ["-shared", "-o", so] + src, check=True, timeout=900)
-    for f in ("libvortex.so", "libvxrt_scene.so"):
-        shutil.copy2(os.path.join(bld.LIB, f), os.path.join(d, f))
+    d = bld.build_test_variant()          # (built by __graft_entry__.build() where hipcc cross-compiles; rebuilt here only if a source is newer)
     env = dict(os.environ, VXRT_LIB_DIR=d, VXRT_DEBUG="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-s", "-k",
                         "reference_fixture or render_matches_oracle or shadow_rays_extension"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)

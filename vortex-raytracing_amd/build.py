@@ -66,6 +66,25 @@ def write_selectors():
             f.write(blob)
 
 
+# The two LDS-staging variants north_star prescribes (top of the tree, triangles of shared leaves) lost their A/Bs and are compiled out of the
+# shipped library; tests/test_gpu_variants.py runs the parity tests on a library with BOTH switched on so that the code cannot rot.  Built
+# here (hipcc cross-compiles without a GPU) so that the GPU box loads it instead of compiling it.
+TEST_VARIANT_FLAGS = ["-DRT_TOP_NODES=84", "-DRT_LDS_STACK_RENDER=5", "-DRT_LDS_STACK_RENDER_PACKED=4", "-DRT_TRI_LDS=4", "-DRT_TRI_LDS_MIN=2"]
+
+
+def build_test_variant(force=False):
+    d = os.path.join(HERE, "lib_ab", "lds_staging")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, "libvortex-hip.so")
+    src = [os.path.join(CSRC, f) for f in PRODUCT_HIP_SOURCES]
+    hdrs = [os.path.join(CSRC, "rt_types.h"), os.path.join(HERE, "..", "include", "vortex_hip.h")]
+    if force or _newer(so, src + hdrs):
+        _run([HIPCC] + HIP_FLAGS + TEST_VARIANT_FLAGS + ["-shared", "-o", so] + src)
+    for f in ("libvortex.so", "libvxrt_scene.so"):
+        shutil.copy2(os.path.join(LIB, f), os.path.join(d, f))
+    return d
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIB, exist_ok=True)
     hdrs = [os.path.join(CSRC, "rt_types.h"), os.path.join(HERE, "..", "include", "vortex_hip.h")]
@@ -99,6 +118,7 @@ def build(force=False, verbose=True):
         _run(["g++"] + CXX_FLAGS + ["-o", host] + host_src + ["-L" + LIB, "-lvortex", "-lvxrt_scene", "-pthread", "-Wl,-rpath,$ORIGIN"])
 
     write_selectors()
+    build_test_variant(force)
     return {"hip": hip_so, "stub": stub_so, "scene": scene_so}
 
 
