@@ -11,7 +11,9 @@ box's 16 cores, the 3840x2160 frame and the 10M-triangle hairball's 25.5 M rays 
   configs[4]           10M-triangle hairball framed to fill the view, 1920x1080, 16 spp AO          -> every pixel, count, colour
   configs[3]           the atrium at 3840x2160 as N interleaved tile-row sets (the 8-GPU split of bench.py), assembled
                        with sharding.assemble_interleaved, equals the one-shot frame and the oracle's: every pixel
-  software twin        the 1,048,576-triangle BVH2 at 1920x1080, frames alternating on two streams                  -> every pixel of every frame"""
+  software twin        the 1,048,576-triangle BVH2 at 1920x1080, frames alternating on two streams                  -> every pixel of every frame
+  random-ray leg       bench.py's 16 Mi random rays through vxrt_trace in one launch                                -> every 16th hit record (1 Mi), bit for bit
+  several GPUs         the headline frame through vx_start on three shares behind one vx_device (VORTEX_HIP_DEVICES) -> every pixel"""
 import numpy as np
 import pytest
 
@@ -455,3 +457,37 @@ def test_headline_frame_on_three_shares_behind_one_vx_device(vrt, po, gpu_device
     np.testing.assert_array_equal(a, want)
     np.testing.assert_array_equal(b, want)
     assert rays == want_rays
+
+
+def test_the_random_ray_leg_matches_oracle(vrt, po, gpu_device, atrium):
+    """north_star's second figure as bench.py runs it: 16 Mi synthetic random rays (torch generator seeded 12345: origins in the scene's box,
+    directions on the sphere) against the 1,048,576-triangle BVH through vxrt_trace, ONE launch.  1,048,576 of its hit records -- every 16th
+    ray of the buffer, so every part of the launch is sampled -- against the canonical restatement, bit for bit, closest hit; and the first
+    262,144 rays in any-hit mode against the faithful one."""
+    import torch
+    sc, ds = atrium
+    n = 16777216
+    g = torch.Generator(device=gpu_device).manual_seed(12345)
+    lo = torch.tensor(sc.bounds[:3], device=gpu_device)
+    hi = torch.tensor(sc.bounds[3:], device=gpu_device)
+    o = lo + (hi - lo) * torch.rand((n, 3), generator=g, device=gpu_device)
+    d = torch.randn((n, 3), generator=g, device=gpu_device)
+    d = d / d.norm(dim=1, keepdim=True)
+    rays = torch.cat([o, d], 1).contiguous()
+    del o, d
+    hits = torch.zeros(n * 24, dtype=torch.uint8, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.trace(ds.accel, rays.data_ptr(), n, hits.data_ptr(), vrt.rtapi.MODE_CLOSEST, None, s)
+    torch.cuda.synchronize()
+    assert vrt.rtapi.status(s) == 0
+    got = hits.view(n, 24)[::16].contiguous().cpu().numpy().view(po.HIT_DTYPE).reshape(-1)
+    sample = rays[::16].contiguous().cpu().numpy()
+    want = po.trace_mt(po.trace_canonical, sc, sample)
+    assert len(want) == 1048576 and 0.3 < (want["dist"] < 1e29).mean() < 1.0      # (hits and misses both)
+    assert np.array_equal(_bits(got), _bits(want))
+    m = 262144
+    vrt.rtapi.trace(ds.accel, rays.data_ptr(), m, hits.data_ptr(), vrt.rtapi.MODE_ANY, None, s)
+    torch.cuda.synchronize()
+    got_any = hits.view(n, 24)[:m].contiguous().cpu().numpy().view(po.HIT_DTYPE).reshape(-1)
+    want_any = po.trace_mt(po.trace_faithful, sc, rays[:m].cpu().numpy(), any_hit=True)
+    assert np.array_equal(_bits(got_any), _bits(want_any))
