@@ -491,3 +491,34 @@ def test_the_random_ray_leg_matches_oracle(vrt, po, gpu_device, atrium):
     got_any = hits.view(n, 24)[:m].contiguous().cpu().numpy().view(po.HIT_DTYPE).reshape(-1)
     want_any = po.trace_mt(po.trace_faithful, sc, rays[:m].cpu().numpy(), any_hit=True)
     assert np.array_equal(_bits(got_any), _bits(want_any))
+
+
+def test_largest_frames(vrt, po, gpu_device):
+    """Maximum sizes: a 7680x4320 frame (33 M pixels, 518,400 tiles, an 800 MB hit-record buffer) of the bunny-class scene, primary + shadow --
+    72 rows spread over the frame and its last row against the oracle; and the shape check at the limit: 2^25 tiles (2.1 G pixels) are the
+    most one set of launches takes -- a window one tile row larger is refused (-1) before anything is allocated or launched."""
+    import torch
+    sc = vrt.scene.procedural("bunny", 6, 0, 1)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    w, h = 7680, 4320
+    light = (20.0, 260.0, -150.0)
+    p = vrt.rtapi.default_shade_params()
+    p.light_pos[:] = light
+    px = torch.full((h, w), 0x5A5A5A5A, dtype=torch.int32, device=gpu_device)
+    cnt = torch.zeros(1, dtype=torch.int64, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.render(ds.accel, w, h, 0, h, p, px.data_ptr(), 1, None, None, cnt.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert vrt.rtapi.status(s) == 0
+    got = px.cpu().numpy().view(np.uint32)
+    ranges = _spread_rows(h, 8, 8) + [(h - 1, h)]
+    want, _, _, _ = po.render_ex_mt(sc, w, h, po.shade_params(light_pos=light), 1, ranges=ranges)
+    for y0, y1 in ranges:
+        np.testing.assert_array_equal(got[y0:y1], want[y0:y1])
+    assert int(cnt.item()) > w * h and (got != 0x5A5A5A5A).all()
+    # 8 x 2^25 tiles wide and one tile row high is the limit; nothing is written for a refused window
+    one = torch.zeros(16, dtype=torch.int32, device=gpu_device)
+    with pytest.raises(RuntimeError):
+        vrt.rtapi.render(ds.accel, 8 * (1 << 25) - 7, 9, 0, 9, p, one.data_ptr(), 0, None, None, None, s)
+    assert vrt.rtapi.status(s) == 0 and int(one.abs().sum().item()) == 0
+    ds.close()
