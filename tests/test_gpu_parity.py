@@ -660,3 +660,42 @@ def test_reference_quirks_mode_equals_the_reference_on_every_ray(vrt, po, golden
         mask = po.stale_base_mask(g, g["rays"])
         assert differ.any() and not (differ & ~mask).any()
         ds.close()
+
+
+@pytest.mark.gpu
+def test_identity_instance_start_and_signed_zero_origins(vrt, po, gpu_device):
+    """A single instance whose inverse transform is the identity lets a ray start at the BLAS root with the world ray as it is (start_ray):
+    the reference's matrix arithmetic would return the same bits -- except for an origin component that is -0, which it turns into +0; such
+    rays take the general instance step.  Rays through vertices and along axis planes of a box at the origin, with every +0 / -0 / non-zero
+    pattern of the origin, against the faithful restatement; then the same triangles under a TRANSLATED instance (no identity: the general
+    step for every ray) and under an identity whose zeros are -0."""
+    sc = vrt.scene.procedural("cornell")
+    rng = np.random.default_rng(5)
+    lo, hi = np.array(sc.bounds[:3]), np.array(sc.bounds[3:])
+    n = 4096
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pat = rng.integers(0, 3, size=(n, 3))                      # per component: keep / +0 / -0
+    o[pat == 1] = 0.0
+    o[pat == 2] = -0.0
+    assert (np.signbit(o) & (o == 0)).any() and ((o == 0) & ~np.signbit(o)).any()
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    for variant in ("identity", "translated", "negative zeros"):
+        bufs = dict(sc.buffers)
+        blas = sc["blas"].copy().view(np.float32)
+        if variant == "translated":
+            blas[1 + 3] -= 7.0        # invTransform[0][3]
+            blas[17 + 3] += 7.0       # transform[0][3]
+        elif variant == "negative zeros":
+            m = blas[1:13]
+            m[m == 0] = -0.0
+        bufs["blas"] = blas.view(np.uint8)
+        s2 = vrt.scene.Scene(bufs)
+        ds = vrt.tracer.DeviceScene(s2, gpu_device)
+        for mode, any_hit in ((vrt.rtapi.MODE_CLOSEST, False), (vrt.rtapi.MODE_ANY, True)):
+            got = gpu_trace(vrt, ds, rays, mode=mode)
+            want, _ = po.trace_faithful(s2, rays, any_hit=any_hit)
+            assert np.array_equal(_bits(got), _bits(want)), (variant, mode)
+        assert (want["dist"] < 1e29).any()
+        ds.close()

@@ -85,6 +85,7 @@ struct SceneDev {
   uint32_t n_top;
   uint32_t tlas_root_top;
   const uint32_t* blas_root_top;
+  uint32_t ident_root;       // 1: the TLAS root is an instance leaf whose inverse transform is the identity (see start_ray)
 };
 
 struct HitRec { float dist, bx, by, bz; uint32_t blasIdx, triIdx; };
@@ -801,7 +802,21 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     nrays++;
     // single-instance scenes (the reference's default): the TLAS root is the instance leaf, enter it
     // right away with the ray at hand instead of re-deriving it in the instance step
-    if (is_inst_desc(root_desc)) enter_instance(root_desc & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz);
+    if (is_inst_desc(root_desc)) {
+      // ... and when that instance's inverse transform is the identity (checked by the accel build: ones on the diagonal, zeros of either sign
+      // elsewhere), the object-space ray IS the world ray, bit for bit, so the record fetch, the 18 multiply-adds, three divisions and the
+      // second domain check of the instance step are skipped.  Why the bits agree: 1*x is x; adding products that are +-0 leaves a non-zero x
+      // alone and turns a zero sum into +0 -- so the only component the arithmetic would change is an origin component that is -0 (it becomes
+      // +0); directions have no zero component inside the fast domain.  Rays with a -0 origin component take the general step.
+      const bool no_neg_zero = __float_as_uint(ox) != 0x80000000u && __float_as_uint(oy) != 0x80000000u && __float_as_uint(oz) != 0x80000000u;
+      if (sc.ident_root && safe && no_neg_zero) {   // (an EXACT launch's rays outside the fast domain -- zero, infinite or NaN components -- take the general step)
+        if (STATS) { fx.node++; fx.inst++; }
+        flags &= ~F_WORLD;
+        CTX(0) = __float_as_uint(dx); CTX(1) = __float_as_uint(dy); CTX(2) = __float_as_uint(dz);
+        CTX(8) = root_desc & PAYLOAD_MASK;
+        cur = blas_roots[root_desc & PAYLOAD_MASK];
+      } else enter_instance(root_desc & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz);
+    }
   };
   // (the scratch part of the stack through volatile pointers: the compiler must not speculate its loads into the common path)
   volatile uint32_t* const vovf_d = ovf_d;
@@ -2297,6 +2312,16 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
   if (!ok || (hstatus & STATUS_BAD_SCENE) != 0) { accel_free(a); return -1; }   // malformed tree: rejected before any traversal
   a->dev.nodes_c = (const uint4*)a->nodes_c; a->dev.ref_tlas = (const uint32_t*)s->tlas; a->dev.n_tlas = s->n_tlas_nodes; a->dev.tri_w = (const float4*)a->tri_w;
   a->dev.blas_root = (const uint32_t*)a->blas_root; a->dev.tlas_root = troot;
+  a->dev.ident_root = 0u;
+  if (troot >= 0xC0000000u && troot < DESC_IDLE) {   // (an instance descriptor) a single instance under the TLAS root: is its inverse transform (dwords 1-12 of the record) the identity?
+    float m[12];
+    static const bool ident_off = [] { const char* e = getenv("VXRT_IDENT_ROOT"); return e && e[0] == '0'; }();
+    if (!ident_off && hipMemcpy(m, (const uint32_t*)s->blas + (size_t)(troot & PAYLOAD_MASK) * (RT_BLAS_STRIDE / 4) + 1, sizeof m, hipMemcpyDeviceToHost) == hipSuccess) {
+      bool id = true;
+      for (int i = 0; i < 12; ++i) id = id && m[i] == ((i % 5 == 0) ? 1.0f : 0.0f);     // (m[0], m[5], m[10] on the diagonal; -0 == 0)
+      a->dev.ident_root = id ? 1u : 0u;
+    }
+  }
   a->dev.exact_decode = (hstatus & STATUS_FMA_DECODE_DIFFERS) ? 1u : 0u;
   a->dev.ref_bvh = (const uint32_t*)s->bvh;
   a->dev.blas = (const uint32_t*)s->blas; a->dev.triEx = (const rt_triex_t*)s->triEx;
