@@ -358,7 +358,8 @@ typedef struct vxrc_params {     /* the fields of raycast/common.h:126-150 kerne
 typedef struct vxrc_accel vxrc_accel_t;
 int vxrc_accel_build(const vxrc_scene_t* scene, void* stream, vxrc_accel_t** out);
 int vxrc_accel_destroy(vxrc_accel_t* accel);
-/* vxrc_render on a prebuilt layout (asynchronous on `stream`; one frame in flight per layout). */
+/* vxrc_render on a prebuilt layout (asynchronous on `stream`; the layout keeps four frame contexts: frames issued round robin on up to
+ * four streams overlap). */
 int vxrc_render_accel(vxrc_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                       const vxrc_params_t* params, uint32_t* dst, float* colors, void* stream);
 

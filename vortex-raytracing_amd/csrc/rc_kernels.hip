@@ -671,7 +671,10 @@ struct RcFrameCtx {
 struct vxrc_accel {
   vxrc_scene_t ref{};
   void* nodes_c = nullptr; void* tri_w = nullptr; void* blas_root = nullptr; void* nodes_w = nullptr;
-  RcFrameCtx ctx[2];
+#ifndef RC_CTXS
+#define RC_CTXS 4             // frame contexts of a layout: frames issued round robin on up to 4 streams overlap (1 / 2 / 3 / 4 in flight: 3.68 / 4.08 / 4.17 / 4.19 Grays/s, profiles/r04_af_twin_frames_in_flight.txt)
+#endif
+  RcFrameCtx ctx[RC_CTXS];
   uint32_t next_ctx = 0;
   bool multi_stream = false; hipStream_t first_stream = nullptr; bool stream_seen = false;
   uint32_t fast_boxes = 0;   // see RcDev
@@ -695,7 +698,7 @@ static RcFrameCtx* rc_acquire_ctx(vxrc_accel* a, hipStream_t s) {
   RcFrameCtx* c = nullptr;
   for (RcFrameCtx& k : a->ctx) if (!c && k.busy && k.stream == s) c = &k;
   for (RcFrameCtx& k : a->ctx) if (!c && !k.busy) c = &k;
-  if (!c) c = &a->ctx[a->next_ctx++ % 2];
+  if (!c) c = &a->ctx[a->next_ctx++ % RC_CTXS];
   if (!c->ctl) {
     if (hipMalloc((void**)&c->ctl, RC_CTL_DWORDS * 4) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) return nullptr;
