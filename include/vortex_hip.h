@@ -199,6 +199,11 @@ typedef struct vxrt_accel vxrt_accel_t;
 int vxrt_accel_build(const vxrt_scene_t* scene, void* stream, vxrt_accel_t** out);
 int vxrt_accel_destroy(vxrt_accel_t* accel);
 uint64_t vxrt_accel_bytes(const vxrt_accel_t* accel);
+/* What the build found (diagnostic): which = 0 -> internal levels on the longest root-to-leaf path, TLAS and BLAS together, counted up
+ * to 17; 1 -> 1 if the scene is at most 16 levels deep and its timed launches keep 48-entry traversal stacks (deeper scenes: the
+ * reference's 32 levels, 96 entries + the LDS part); 2 -> 1 if the TLAS root is a single identity instance; 3 -> 1 if the scene
+ * takes the ldexp decode / generic slab form. */
+int vxrt_accel_info(const vxrt_accel_t* accel, uint32_t which, uint64_t* value);
 
 /* Number of frames (vxrt_render / vxrt_trace calls) this accel keeps in flight, 1..8, default 1.
  * Each in-flight frame has its own hit-record buffer, deferred-ray list and side stream; calls take
@@ -358,6 +363,11 @@ typedef struct vxrc_params {     /* the fields of raycast/common.h:126-150 kerne
 typedef struct vxrc_accel vxrc_accel_t;
 int vxrc_accel_build(const vxrc_scene_t* scene, void* stream, vxrc_accel_t** out);
 int vxrc_accel_destroy(vxrc_accel_t* accel);
+/* What the build decided (diagnostic): which = 0 -> 1 if the walk takes two BVH2 levels per fetch (wide nodes), 0 if it keeps the
+ * reference's two-wide walk (a box that is not the union of its children's, an unbounded box, or a tree deeper than 42 internal
+ * levels, whose wide walk could need more than the reference's 64 stack entries); which = 1 -> internal nodes on the longest
+ * root-to-leaf path (0 when the wide layout was not requested). */
+int vxrc_accel_info(const vxrc_accel_t* accel, uint32_t which, uint64_t* value);
 /* vxrc_render on a prebuilt layout (asynchronous on `stream`; the layout keeps four frame contexts: frames issued round robin on up to
  * four streams overlap). */
 int vxrc_render_accel(vxrc_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,

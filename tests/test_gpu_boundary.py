@@ -164,6 +164,38 @@ def test_small_scene_buffers_reach_the_device_before_they_are_read(vrt, po, gpu_
     tr.close()
 
 
+def test_a_small_framebuffer_cleared_by_the_host_keeps_the_rendered_pixels(vrt, po, gpu_device):
+    """A framebuffer of <= 4 KB (16x16 pixels) that the host writes before vx_start -- clearing it, as a frame loop does -- is a lazy
+    upload like any other small buffer.  It must reach the device BEFORE the run: flushed by the vx_copy_from_dev after the run, it
+    would put the host's zeros over the pixels the kernels just wrote.  Both kernels (RTU frame, twin); a row window keeps the
+    host's bytes outside it."""
+    sc = vrt.scene.procedural("cornell")
+    w, h = 16, 16
+    want, _, _ = po.render(sc, w, h)
+    tr = vrt.tracer.Tracer(w, h)
+    tr.init(sc)
+    tr.setup()
+    tr.bufs["out"].write(np.zeros(w * h * 4, np.uint8))
+    assert np.array_equal(tr.run(), want)
+    # second frame of the loop: cleared to another pattern, rendered again
+    tr.bufs["out"].write(np.full(w * h * 4, 0xAB, np.uint8))
+    assert np.array_equal(tr.run(), want)
+    # a row window: rows outside it keep what the host uploaded, rows inside are the frame's
+    tr.bufs["out"].write(np.full(w * h * 4, 0xCD, np.uint8))
+    tr.setup(row_window=(8, 16))
+    got = tr.run()
+    assert np.array_equal(got[8:], want[8:]) and np.all(got[:8] == 0xCDCDCDCD)
+    tr.close()
+    rsc = vrt.scene.rc_procedural("cornell")
+    rt = vrt.tracer.RaycastTracer(w, h)
+    rt.init(rsc)
+    rt.setup(vrt.scene.rc_camera_like_rtu(w, h), (0.0, 10.0, -10.0, 1.0, 1.0, 1.0, 0.4, 0.4, 0.4, 0.4, 0.35, 0.25))
+    first = rt.run().copy()
+    rt.bufs["out"].write(np.zeros(w * h * 4, np.uint8))
+    assert np.array_equal(rt.run(), first) and np.any(first != 0)
+    rt.close()
+
+
 def test_mirror_bounce_through_vx_api(vrt, po, gpu_device):
     """kernel_arg_t::max_depth + blas_node_t::reflectivity reach the kernels through vx_copy_to_dev /
     vx_start exactly as the reference host passes them (tracer.cpp:217-259, main.cpp -d)."""

@@ -699,3 +699,38 @@ def test_identity_instance_start_and_signed_zero_origins(vrt, po, gpu_device):
             assert np.array_equal(_bits(got), _bits(want)), (variant, mode)
         assert (want["dist"] < 1e29).any()
         ds.close()
+
+
+def test_wave_log_reports_every_slot_it_documents(vrt, po, gpu_device):
+    """vxrt_render_wave_log (diagnostic build, include/vortex_hip.h): 16 u64 per wavefront.  The tools that explain a launch's tail
+    (tools/wave_balance.py, wave_balance_batch.py) divide by slots 10-12 -- shader clocks inside the node body, the instance + leaf
+    part, and the whole wavefront -- so those must be written and consistent; the frame the build renders is still the oracle's."""
+    import ctypes as C
+    import torch
+    sc = vrt.scene.procedural("atrium", 5, 0, 3)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    w, h = 320, 200
+    L = vrt.rtapi._lib()
+    L.vxrt_render_wave_log.restype = C.c_int
+    L.vxrt_render_wave_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vrt.rtapi.ShadeParams), C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    p = vrt.rtapi.default_shade_params()
+    px = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
+    cnt = torch.zeros(8, dtype=torch.int64, device=gpu_device)
+    log = torch.zeros((4 * 8 * 256, 16), dtype=torch.int64, device=gpu_device)
+    assert L.vxrt_render_wave_log(ds.accel, w, h, 0, h, C.byref(p), 0, px.data_ptr(), cnt.data_ptr(), log.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    lg = log.cpu().numpy()
+    lg = lg[lg[:, 1] > 0]
+    assert len(lg) > 0 and int(lg[:, 2].sum()) == w * h                 # rays started, over the wavefronts that ran
+    xcd = (lg[:, 9].astype(np.uint64) >> np.uint64(56)).astype(np.int64)
+    assert xcd.min() >= 0 and xcd.max() <= 7
+    busy = lg[lg[:, 3] > 0]                                             # wavefronts that got a tile
+    assert len(busy) > 0
+    assert (busy[:, 12] > 0).all()                                      # shader clocks of the whole wavefront
+    assert (busy[:, 10] > 0).all() and (busy[:, 10] + busy[:, 11] <= busy[:, 12]).all()
+    assert (busy[:, 13] + busy[:, 14] <= busy[:, 12]).all()
+    assert (busy[:, 4] <= busy[:, 3]).all() and (busy[:, 5] <= 64 * busy[:, 4]).all()
+    rpx, _, _ = po.render(sc, w, h)
+    assert np.array_equal(px.cpu().numpy().view(np.uint32), rpx)
+    ds.close()

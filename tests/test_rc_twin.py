@@ -243,3 +243,99 @@ def test_twin_accel_is_reusable_and_rejects_malformed_scenes(vrt, po, golden, gp
     for mut in (child_out_of_range, child_before_parent, leaf_past_tri_idx, tri_idx_past_tris, bad_bvh_offset):
         bad_scene(mut)
     torch.cuda.synchronize()
+
+
+def _chain_scene(vrt, k):
+    """A chain-like BVH2, 2k internal levels deep, in the twin's formats: node N_i = (A_i = (leaf, leaf), B_i = (leaf, N_i+1)), triangles
+    stacked along the view direction, larger and farther with depth, so that every ray hits every box and the walk -- which visits the
+    FARTHER child first (render.h:110) -- goes all the way down with everything else left on its stack: one entry per level in the
+    reference's walk, three per two levels in a walk that takes two levels per fetch."""
+    sc = vrt.scene.rc_procedural("cornell")
+    tris, nodes = [], []
+
+    def tri(i):
+        x, s = 200.0 + 4.0 * i, 12.0 + 2.5 * i
+        tris.append([x, 100.0 - s, -s, x, 100.0 + s, -s, x, 100.0 + 0.3 * s, s])
+        return len(tris) - 1
+
+    def leaf(t):
+        v = np.array(tris[t], np.float32).reshape(3, 3)
+        return {"lo": v.min(0), "hi": v.max(0), "first": t, "count": 1}
+
+    def union(a, b):
+        return {"lo": np.minimum(a["lo"], b["lo"]), "hi": np.maximum(a["hi"], b["hi"]), "kids": (a, b)}
+
+    def build(i, left):
+        if left == 0:
+            return leaf(tri(3 * i))
+        a = union(leaf(tri(3 * i)), leaf(tri(3 * i + 1)))
+        b1 = leaf(tri(3 * i + 2))
+        return union(a, union(b1, build(i + 1, left - 1)))
+
+    root = build(0, k)
+    out = [None, None]                       # slot 1 stays empty, as in the reference's 2N-node buffer (children are adjacent pairs)
+    def emit(n, at):
+        out[at] = n
+        if "kids" in n:
+            l = len(out)
+            out.extend([None, None])
+            n["left"] = l
+            emit(n["kids"][0], l)
+            emit(n["kids"][1], l + 1)
+    import sys
+    sys.setrecursionlimit(10000)
+    emit(root, 0)
+    bvh = np.zeros((len(out), 8), np.uint32)
+    fb = bvh.view(np.float32)
+    for i, n in enumerate(out):
+        if n is None:
+            continue
+        fb[i, 0:3], fb[i, 4:7] = n["lo"], n["hi"]
+        if "kids" in n:
+            bvh[i, 3], bvh[i, 7] = n["left"], 0
+        else:
+            bvh[i, 3], bvh[i, 7] = n["first"], n["count"]
+    nt = len(tris)
+    ex = np.zeros((nt, 15), np.float32)
+    ex[:, 0] = ex[:, 3] = ex[:, 6] = -1.0
+    b = {k_: v.copy() for k_, v in sc.items() if k_ in ("tlas", "blas", "tex")}
+    b["bvh"] = bvh.view(np.uint8).reshape(-1)
+    b["tri"] = np.array(tris, np.float32).view(np.uint8).reshape(-1)
+    b["triEx"] = ex.view(np.uint8).reshape(-1)
+    b["triIdx"] = np.arange(nt, dtype=np.uint32).view(np.uint8)
+    b["tlas_root"] = int(sc["tlas_root"])
+    tl = b["tlas"].view(np.float32).reshape(-1, 8)
+    tl[:, 0:3], tl[:, 4:7] = root["lo"], root["hi"]
+    assert len(b["blas"]) == 160 and b["blas"].view(np.uint32)[32] == 0
+    return b
+
+
+def test_restatement_walks_a_chain_of_fifty_levels(vrt, po):
+    """The reference's own walk needs one stack entry per level: 50 < BVH_STACK_SIZE = 64, so the restatement renders the chain."""
+    sc = _chain_scene(vrt, 25)
+    w, h = 48, 32
+    px, _ = po.rc_render(po.rc_args(sc, w, h, vrt.scene.rc_camera_like_rtu(w, h), po.RC_DEFAULT_LIGHT, 1, 1))
+    assert len(np.unique(px)) > 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,wide", [(21, 1), (22, 0), (25, 0), (31, 0)])
+def test_hip_twin_on_a_chain_like_tree(vrt, po, gpu_device, k, wide):
+    """A BVH2 2k internal levels deep that the reference walks inside its 64 stack entries.  The walk that takes two levels per fetch
+    leaves up to three entries per two levels: it is used up to 42 levels (63 entries) and the build keeps the reference's own walk
+    beyond -- either way the frame is the restatement's, and no stack overflow is reported."""
+    import torch
+    sc = _chain_scene(vrt, k)
+    w, h = 96, 64
+    cam = vrt.scene.rc_camera_like_rtu(w, h)
+    want, _ = po.rc_render(po.rc_args(sc, w, h, cam, po.RC_DEFAULT_LIGHT, 1, 1))
+    ds = vrt.tracer.RcDeviceScene(sc, gpu_device)
+    assert vrt.rtapi.rc_accel_info(ds.accel, 1) == 2 * k
+    assert vrt.rtapi.rc_accel_info(ds.accel, 0) == wide
+    px = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.rc_render_accel(ds.accel, w, h, 0, h, vrt.rtapi.rc_params(cam, po.RC_DEFAULT_LIGHT, 1, 1), px.data_ptr(), None, s)
+    assert vrt.rtapi.status(s) == 0
+    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), want)
+    assert len(np.unique(want)) > 3
+    ds.close()

@@ -47,6 +47,8 @@
 #ifndef RC_LEAF_LANES
 #define RC_LEAF_LANES 1         // leaves are tested once this many lanes hold one (or no lane holds a node): a lane with a leaf WAITS -- it cannot go on, the order of
 #endif                          // its triangle tests is the reference's.  Measured: 8 / 16 / 24 / 32 lanes all 3-5 % slower than 1 (profiles/r04_w_twin_leaf_lanes.txt)
+// deepest tree (internal nodes on a root-to-leaf path) whose wide walk stays inside RC_STACK entries: three entries per two levels
+#define RC_WIDE_MAX_DEPTH (2u * (RC_STACK / 3u))
 #define RC_STATUS_STACK 1u      // same bits as the RTU path's status word
 #define RC_STATUS_ITER 2u
 #define RC_STATUS_BAD_SCENE 4u
@@ -239,6 +241,34 @@ __global__ void rc_accel_wide_kernel(const uint32_t* __restrict__ ref, uint32_t 
   for (int q = 0; q < 6; ++q) o[q] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
   o[6] = make_uint4(desc[0], desc[1], desc[2], desc[3]);
   o[7] = make_uint4(shape, 0u, 0u, 0u);
+}
+
+// Depth of the BVH2s in INTERNAL nodes on a root-to-leaf path -- what bounds a walk's stack.  The reference's walk (render.h:99-121) leaves at
+// most one entry per internal node of its path; the wide step takes two levels per fetch and leaves up to THREE (the side it does not enter,
+// as its two children, and the sibling of the grandchild it does enter), about 1.5 per level: a chain-like tree 43 to 63 levels deep that the
+// reference walks inside its 64 entries would overflow the wide walk.  The build therefore measures the depth and keeps the two-wide walk for
+// a scene whose wide walk could need more than RC_STACK entries.  Level by level (a node's children lie after it, so the trees are acyclic):
+// pass t gives every child of a node of level t the level t + 1; `deepest` ends as the last level any node reached.
+__global__ void rc_accel_depth_kernel(const uint32_t* __restrict__ ref, uint32_t n_nodes, const uint32_t* __restrict__ bases, const uint32_t* __restrict__ ends,
+                                      uint32_t nb, uint32_t level, uint32_t* __restrict__ depth, uint32_t* __restrict__ deepest) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  uint32_t base = 0, end = 0;
+  bool in = false;
+  for (uint32_t j = 0; j < nb; ++j) if (i >= bases[j] && i < ends[j]) { base = bases[j]; end = ends[j]; in = true; }
+  if (!in) return;
+  const uint32_t* w = ref + (size_t)i * 8;
+  if (w[7] != 0u || !rc_node_ok(ref, i, base, end)) return;      // leaves (and malformed slots: flagged elsewhere) need no entry
+  if (level == 1u) {                                              // the roots: node 0 of every instance (render.h:84)
+    if (i == base) { depth[i] = 1u; *deepest = 1u; }
+    return;
+  }
+  if (depth[i] != level - 1u) return;
+  const uint32_t l = base + w[3];
+  for (uint32_t c = l; c <= l + 1u; ++c) {
+    const uint32_t* cw = ref + (size_t)c * 8;
+    if (cw[7] == 0u && rc_node_ok(ref, c, base, end)) { atomicMax(&depth[c], level); *deepest = level; }   // (every writer of a pass stores the same value)
+  }
 }
 
 __global__ void rc_accel_tris_kernel(const float* __restrict__ tri, const uint32_t* __restrict__ triIdx, uint32_t n_idx, uint32_t n_tris,
@@ -678,6 +708,7 @@ struct vxrc_accel {
   uint32_t next_ctx = 0;
   bool multi_stream = false; hipStream_t first_stream = nullptr; bool stream_seen = false;
   uint32_t fast_boxes = 0;   // see RcDev
+  uint32_t depth = 0;        // internal nodes on the longest root-to-leaf path (measured when the wide layout was built; 0 = not measured)
 };
 
 extern "C" int vxrc_accel_destroy(vxrc_accel_t* a) {
@@ -690,6 +721,15 @@ extern "C" int vxrc_accel_destroy(vxrc_accel_t* a) {
   }
   delete a;
   return 0;
+}
+
+extern "C" int vxrc_accel_info(const vxrc_accel_t* a, uint32_t which, uint64_t* value) {
+  if (!a || !value) return -1;
+  switch (which) {
+  case 0: *value = a->nodes_w ? 1u : 0u; return 0;
+  case 1: *value = a->depth; return 0;
+  }
+  return -1;
 }
 
 // frame context for a call on stream s: the one this stream used last, else an unused one, else the other one behind its completion event
@@ -740,18 +780,20 @@ extern "C" int vxrc_accel_build(const vxrc_scene_t* s, void* stream, vxrc_accel_
   auto a = new (std::nothrow) vxrc_accel();
   if (!a) return -1;
   a->ref = *s;
-  uint32_t* d_ranges = nullptr; uint32_t* d_status = nullptr;
+  uint32_t* d_ranges = nullptr; uint32_t* d_status = nullptr; uint32_t* d_depth = nullptr;
   static const bool wide_on = [] { const char* e = getenv("VXRC_WIDE"); return !(e && e[0] == '0'); }();
   bool ok = hipMalloc(&a->nodes_c, (size_t)s->n_bvh_nodes * 64) == hipSuccess &&
             (!(RC_WIDE && wide_on) || hipMalloc(&a->nodes_w, (size_t)s->n_bvh_nodes * 128) == hipSuccess) &&
             hipMalloc(&a->tri_w, (size_t)s->n_tri_idx * 48) == hipSuccess &&
             hipMalloc(&a->blas_root, (size_t)s->n_blas * 4) == hipSuccess &&
-            hipMalloc((void**)&d_ranges, bases.size() * 8) == hipSuccess && hipMalloc((void**)&d_status, 4) == hipSuccess;
-  uint32_t hstatus = 0;
+            hipMalloc((void**)&d_ranges, bases.size() * 8) == hipSuccess && hipMalloc((void**)&d_status, 8) == hipSuccess &&
+            (!a->nodes_w || hipMalloc((void**)&d_depth, (size_t)s->n_bvh_nodes * 4) == hipSuccess);
+  uint32_t hstatus = 0, deepest = 0;
   if (ok) {
     ok = hipMemcpy(d_ranges, bases.data(), bases.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(d_ranges + bases.size(), ends.data(), ends.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemset(d_status, 0, 4) == hipSuccess && hipMemsetAsync(a->tri_w, 0, (size_t)s->n_tri_idx * 48, st) == hipSuccess;
+         hipMemset(d_status, 0, 8) == hipSuccess && hipMemsetAsync(a->tri_w, 0, (size_t)s->n_tri_idx * 48, st) == hipSuccess &&
+         (!d_depth || hipMemsetAsync(d_depth, 0, (size_t)s->n_bvh_nodes * 4, st) == hipSuccess);
   }
   if (ok) {
     const uint32_t nb = (uint32_t)bases.size();
@@ -763,13 +805,23 @@ extern "C" int vxrc_accel_build(const vxrc_scene_t* s, void* stream, vxrc_accel_
                        s->n_tris, (float4*)a->tri_w, d_status);
     hipLaunchKernelGGL(rc_accel_roots_kernel, dim3((s->n_blas + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->bvh, (const uint32_t*)s->blas, s->n_blas,
                        s->n_bvh_nodes, d_ranges, d_ranges + nb, nb, s->n_tri_idx, (uint32_t*)a->blas_root, d_status);
+    // depth of the trees, for the wide walk's stack (see rc_accel_depth_kernel): one pass per level, up to the first level the wide walk
+    // could not hold any more (no host round trip in between: a pass past the deepest level finds nothing to do)
+    if (d_depth)
+      for (uint32_t level = 1; level <= RC_WIDE_MAX_DEPTH + 1u; ++level)
+        hipLaunchKernelGGL(rc_accel_depth_kernel, dim3((s->n_bvh_nodes + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->bvh, s->n_bvh_nodes,
+                           d_ranges, d_ranges + nb, nb, level, d_depth, d_status + 1);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
-         hipMemcpy(&hstatus, d_status, 4, hipMemcpyDeviceToHost) == hipSuccess;
+         hipMemcpy(&hstatus, d_status, 4, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(&deepest, d_status + 1, 4, hipMemcpyDeviceToHost) == hipSuccess;
   }
-  (void)hipFree(d_ranges); (void)hipFree(d_status);
+  (void)hipFree(d_ranges); (void)hipFree(d_status); (void)hipFree(d_depth);
   if (!ok || (hstatus & ~(RC_STATUS_SLOW_BOXES | RC_STATUS_NO_WIDE)) != 0) { vxrc_accel_destroy(a); return -1; }
   a->fast_boxes = (hstatus & RC_STATUS_SLOW_BOXES) ? 0u : 1u;
   if (a->nodes_w && (hstatus & (RC_STATUS_SLOW_BOXES | RC_STATUS_NO_WIDE))) { (void)hipFree(a->nodes_w); a->nodes_w = nullptr; }   // (the wide walk needs both properties)
+  // ... and a stack that holds it: up to three entries per two levels.  A deeper tree keeps the reference's own walk, one entry per level.
+  if (a->nodes_w && deepest > RC_WIDE_MAX_DEPTH) { (void)hipFree(a->nodes_w); a->nodes_w = nullptr; }
+  a->depth = deepest;
   *out = a;
   return 0;
 }

@@ -522,6 +522,9 @@ __device__ __forceinline__ void ao_sample_ray(uint32_t x, uint32_t y, uint32_t W
 #define RT_WG_WAVES 4       // wavefronts per workgroup of the persistent kernels (the staged top of the tree is shared by them)
 #endif
 #define RT_WG_THREADS (64 * RT_WG_WAVES)
+#ifndef RT_SHALLOW_LEVELS
+#define RT_SHALLOW_LEVELS 16  // internal levels (TLAS + BLAS) up to which a scene takes the SHALLOW instantiations: 48 stack entries instead of 96 + the LDS levels
+#endif
 #ifndef RT_TOP_NODES
 #define RT_TOP_NODES 0      // internal nodes of the top of the tree staged in LDS per workgroup (64 B each); 0 = off
 #endif
@@ -567,8 +570,23 @@ __device__ __forceinline__ size_t hit_index(uint32_t x, uint32_t lr, uint32_t ti
 // window, 8 * stride for the interleaved tile rows of vxrt_render_interleaved)
 __device__ __forceinline__ uint32_t frame_row(uint32_t lr, uint32_t y0, uint32_t row_step) { return y0 + (lr >> 3) * row_step + (lr & 7u); }
 
+// Division of a tile index (< 2^25: render_common refuses larger launches) by a divisor that is the same for the whole launch -- tiles per row,
+// tiles per frame of a batch -- as a multiply-high, an add and a shift with constants the host derives once (Granlund & Montgomery 1994:
+// L = ceil(log2 d), m = floor(2^32 (2^L - d) / d) + 1, x / d = (mulhi(x, m) + x) >> L; the sum cannot overflow for x < 2^31).  The compiler's
+// own expansion of x / d for a runtime d is a float reciprocal + two correction steps, ~20 VALU instructions per division and a hoisted
+// reciprocal per divisor held in a VGPR for the whole kernel; a lane derives its pixel from its job three times per pixel.
+struct FastDiv { uint32_t d, m, s; };
+static FastDiv fast_div_make(uint32_t d) {
+  FastDiv f{d ? d : 1u, 1u, 0u};
+  while ((1ull << f.s) < f.d) ++f.s;
+  f.m = (uint32_t)((((1ull << f.s) - f.d) << 32) / f.d) + 1u;
+  return f;
+}
+__device__ __forceinline__ uint32_t fast_div(uint32_t x, const FastDiv& f) { return (__umulhi(x, f.m) + x) >> f.s; }
+
 struct PersistArgs {
   uint32_t W, H, y0, y1, tiles_x;
+  FastDiv div_tiles_x, div_frame_tiles;   // (tiles_x, frame_tiles as divisors: see FastDiv)
   uint32_t row_step;              // frame rows between two consecutive tile rows of the window: 8, or 8 * stride (interleaved)
   uint32_t total;                 // number of jobs (tiles*64 pixels, or rays); an upper bound when total_dev is set
   const uint32_t* total_dev;      // optional: the job count lives in device memory (produced by an earlier kernel of the stream)
@@ -635,7 +653,11 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 // PACKED: the instantiation for frames traced in sets that overlap on two streams (bench.py's pipelined mode, batches): 8 wavefronts
 // per SIMD (64 VGPRs, 5 stack levels in LDS) instead of 7 -- +1.6 % there, where many tiles per wavefront hide the few spilled
 // registers, and -8 % on a serial frame, which keeps 7 (profiles/r03_c_flag_variants.txt)
-template <int JOB, int STATS, bool LDEXP, bool EXACT, bool PACKED = false>
+// SHALLOW: the scene's trees are at most RT_SHALLOW_LEVELS internal levels deep on any root-to-leaf path, TLAS and BLAS together (measured by the
+// accel build, accel_depth_kernel), so a lane's stack never holds more than 3 x RT_SHALLOW_LEVELS entries and the part of it that lives in
+// scratch is sized for that instead of for the reference's 32 levels: 344 instead of 768 bytes per lane for the 8-wavefront instantiation.
+// (The 1,048,576-triangle atrium is 13 levels deep, the 10 M-triangle hairball 15.)  Timed builds only; deeper scenes take the full-size form.
+template <int JOB, int STATS, bool LDEXP, bool EXACT, bool PACKED = false, bool SHALLOW = false>
 __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JOB_TRACE ? RT_WAVES_TRACE : (JOB == JOB_RENDER_GI ? RT_WAVES_GI : (PACKED ? RT_WAVES_RENDER_PACKED : RT_WAVES_RENDER)))) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
   // stack levels in LDS: what the instantiation's occupancy leaves room for (160 KB per CU)
   constexpr int LSTK = EXACT ? LDS_STACK : (JOB == JOB_TRACE ? RT_LDS_STACK_TRACE : (JOB == JOB_RENDER_GI ? RT_LDS_STACK_GI : (PACKED ? RT_LDS_STACK_RENDER_PACKED : RT_LDS_STACK_RENDER)));
@@ -682,8 +704,11 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   // JOB_RENDER_GI: colour and albedo of the pixel's primary hit and the pixel's bounce ray (world space), kept while that ray is traced
   float g_col[3] = {0.f, 0.f, 0.f}, g_alb[3] = {0.f, 0.f, 0.f}, g_ray[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int sp = 0;                     // entries below the register top (LDS, then scratch)
-  uint32_t ovf_d[RT_STACK_ENTRIES];
-  float ovf_m[RT_STACK_ENTRIES];
+  // entries past the LDS levels (scratch): the whole stack holds STACK_CAP entries below the register top
+  constexpr int STACK_CAP = SHALLOW ? 3 * RT_SHALLOW_LEVELS : LSTK + RT_STACK_ENTRIES;
+  static_assert(STACK_CAP > LSTK, "stack");
+  uint32_t ovf_d[STACK_CAP - LSTK];
+  float ovf_m[STACK_CAP - LSTK];
   // wave-uniform job-queue state
   bool queue_empty = false;
   // Home shard = the PHYSICAL XCD the wavefront runs on (HW_REG_XCC_ID, 0..7), so that band s of the frame is traced by the same XCD in every
@@ -711,11 +736,22 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   if (STATS && A.wave_log) { t_first = wall_clock64(); wl_tstart = __builtin_readcyclecounter(); }
 
   auto pixel_of = [&](uint32_t r, uint32_t& x, uint32_t& y) {
+    // (the job id goes through an empty asm statement: the compiler then derives the pixel again wherever it is asked for -- a dozen
+    // instructions -- instead of keeping x, y and the table addresses of every lane alive, in scratch, from the start of a ray to its end)
+    asm volatile("" : "+v"(r));
     uint32_t tile = r >> 6;
     const uint32_t l = r & 63u;
-    if (A.pbatch) tile %= A.frame_tiles;   // (a batch of frames: same window, frame_tiles tiles apart)
-    x = (tile % A.tiles_x) * 8u + (l & 7u);
-    y = A.y0 + (tile / A.tiles_x) * A.row_step + (l >> 3);
+    if (A.pbatch) tile -= fast_div(tile, A.div_frame_tiles) * A.frame_tiles;   // (a batch of frames: same window, frame_tiles tiles apart)
+    const uint32_t ty = fast_div(tile, A.div_tiles_x);
+    x = (tile - ty * A.tiles_x) * 8u + (l & 7u);
+    y = A.y0 + ty * A.row_step + (l >> 3);
+  };
+  // where the lane's hit record goes (same reason for the empty asm statement as in pixel_of: the address is formed where it is used -- one
+  // multiply-add -- instead of living in two registers, or two scratch slots, for the length of the ray)
+  auto hit_slot = [&]() -> HitRec* {
+    uint32_t j = job;
+    asm volatile("" : "+v"(j));
+    return A.hits + j;
   };
   // the lane's world-space ray, re-derived from its job (deterministic: same bits every time)
   auto world_ray = [&](float& ox, float& oy, float& oz, float& dx, float& dy, float& dz, float& tmax_) {
@@ -735,7 +771,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
         const float pd = __uint_as_float(CTX(5));   // distance of this pixel's primary hit
         float sox, soy, soz, sdx, sdy, sdz, sdist;
         float lpx = p.lpos[0], lpy = p.lpos[1], lpz = p.lpos[2];
-        if (A.pbatch) { const ShadeParams* q = A.pbatch + (job >> 6) / A.frame_tiles; lpx = q->lpos[0]; lpy = q->lpos[1]; lpz = q->lpos[2]; }
+        if (A.pbatch) { const ShadeParams* q = A.pbatch + fast_div(job >> 6, A.div_frame_tiles); lpx = q->lpos[0]; lpy = q->lpos[1]; lpz = q->lpos[2]; }
         shadow_ray(lpx, lpy, lpz, ox, oy, oz, dx, dy, dz, pd, sox, soy, soz, sdx, sdy, sdz, sdist);
         ox = sox; oy = soy; oz = soz; dx = sdx; dy = sdy; dz = sdz;
         tmax_ = sdist;
@@ -754,7 +790,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
       HitRec h;
       h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;
       h.dist = __uint_as_float(CTX(5)); h.blasIdx = CTX(6); h.triIdx = CTX(7);
-      A.hits[job] = h;
+      *hit_slot() = h;
     }
     if (counted) nrays--;   // the EXACT launch counts the ray when it starts it again
     cur = DESC_IDLE;
@@ -908,7 +944,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             // the tile these jobs belong to: queue position -> tile through the order of the launch; its cost is taken from here to the next tile's start
             const uint32_t pos = loc_next >> 6;
             const uint32_t tile = A.tile_order ? A.tile_order[pos] : pos;
-            loc_off = (tile << 6) - (loc_next & ~63u);
+            loc_off = __builtin_amdgcn_readfirstlane((tile << 6) - (loc_next & ~63u));   // (wave-uniform: a scalar register)
             if (A.tile_cost && tile != lpt_tile) {
               if (lane == 0 && lpt_tile != 0xFFFFFFFFu) A.tile_cost[lpt_tile] = lpt_work;
               if (STATS && A.wave_log) {   // (diagnostic: when the tile was started and how long the one before it took, in 100 MHz clocks, behind the costs)
@@ -933,7 +969,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             if (EXACT) {
               const uint32_t wd = A.defer_list[job];
               job = wd & 0x7fffffffu;
-              if (wd >> 31) { flags = F_SHADOW | F_RESUMED; if (JOB == JOB_RENDER_SHADOW) CTX(5) = __float_as_uint(A.hits[job].dist); }
+              if (wd >> 31) { flags = F_SHADOW | F_RESUMED; if (JOB == JOB_RENDER_SHADOW) CTX(5) = __float_as_uint(hit_slot()->dist); }
             }
             float ox, oy, oz, dx, dy, dz, tm;
             if (JOB == JOB_TRACE) {
@@ -1018,7 +1054,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           const bool v0 = c[0].d < __builtin_inff(), v1 = c[1].d < __builtin_inff(), v2 = c[2].d < __builtin_inff(), v3 = c[3].d < __builtin_inff();
           if (v0 || v1 || v2 || v3) {
             bool more = true;
-            if (sp + 4 > LSTK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
+            if (sp + 4 > STACK_CAP) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
             cur = v0 ? c[0].desc : (v1 ? c[1].desc : (v2 ? c[2].desc : c[3].desc));
             if (more) {
               if (v1 && v0) push(c[1].desc, c[1].d);
@@ -1034,7 +1070,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           // canonicalising v_max x, x in front of them)
           if (c[0].d < __builtin_inff()) {
             bool more = true;
-            if (sp + 4 > LSTK + RT_STACK_ENTRIES) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
+            if (sp + 4 > STACK_CAP) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
             // far first so that the nearest pending sibling is on top (:98-103)
             if (more && c[3].d < __builtin_inff()) push(c[3].desc, vmax_nonan(path_m, c[3].d));
             if (more && c[2].d < __builtin_inff()) push(c[2].desc, vmax_nonan(path_m, c[2].d));
@@ -1152,7 +1188,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           h.dist = hitd; h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;   // rt_traversal.cpp:311-313
           h.blasIdx = CTX(6); h.triIdx = CTX(7);
         }
-        A.hits[job] = h;
+        *hit_slot() = h;
         cur = DESC_IDLE;
       } else if (JOB == JOB_RENDER_GI) {
         // one diffuse bounce, in the lane (see JOB_RENDER_GI above).  Every step is the code of the pass it replaces:
@@ -1205,7 +1241,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           float ox, oy, oz, dx, dy, dz, sox, soy, soz, sdx, sdy, sdz, sdist;
           generate_ray(A.utab[x], A.vtab[y], ox, oy, oz, dx, dy, dz);
           float lpx = p.lpos[0], lpy = p.lpos[1], lpz = p.lpos[2];
-          if (A.pbatch) { const ShadeParams* q = A.pbatch + (job >> 6) / A.frame_tiles; lpx = q->lpos[0]; lpy = q->lpos[1]; lpz = q->lpos[2]; }
+          if (A.pbatch) { const ShadeParams* q = A.pbatch + fast_div(job >> 6, A.div_frame_tiles); lpx = q->lpos[0]; lpy = q->lpos[1]; lpz = q->lpos[2]; }
           shadow_ray(lpx, lpy, lpz, ox, oy, oz, dx, dy, dz, hitd, sox, soy, soz, sdx, sdy, sdz, sdist);
           CTX(5) = __float_as_uint(hitd);
           flags = F_SHADOW;
@@ -1215,17 +1251,17 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             h.dist = hitd; h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;
             h.blasIdx = CTX(6); h.triIdx = CTX(7);
           }
-          A.hits[job] = h;   // tile-major: job = tile * 64 + lane
+          *hit_slot() = h;   // tile-major: job = tile * 64 + lane
           cur = DESC_IDLE;
         }
       } else if (EXACT && (flags & F_RESUMED)) {
         // occlusion ray handed over by the main launch: the record is in memory already, only the result is added
-        if (found) A.hits[job].blasIdx |= 0x80000000u;
+        if (found) hit_slot()->blasIdx |= 0x80000000u;
         cur = DESC_IDLE;
       } else {
         h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;
         h.dist = __uint_as_float(CTX(5)); h.blasIdx = CTX(6) | (found ? 0x80000000u : 0u); h.triIdx = CTX(7);   // found = occluded
-        A.hits[job] = h;
+        *hit_slot() = h;
         cur = DESC_IDLE;
       }
     }
@@ -1240,7 +1276,9 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     if (lane == 0) {
       unsigned long long* w = A.wave_log + 16ull * (blockIdx.x * (uint32_t)WG_WAVES + (threadIdx.x >> 6));
       w[13] = wl_tf; w[14] = wl_tfin; w[15] = wl_tq;
-      w[0] = t_first; w[1] = wall_clock64(); w[2] = s; w[8] = wl_no23; w[9] = (unsigned long long)wl_no3 | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 56);   // [63:56] physical XCD w[10] = wl_tn; w[11] = wl_tl; w[12] = __builtin_readcyclecounter() - wl_tstart;
+      w[0] = t_first; w[1] = wall_clock64(); w[2] = s; w[8] = wl_no23;
+      w[9] = (unsigned long long)wl_no3 | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 56);   // [63:56] physical XCD
+      w[10] = wl_tn; w[11] = wl_tl; w[12] = __builtin_readcyclecounter() - wl_tstart;
       w[3] = wl_iter; w[4] = wl_node_x; w[5] = wl_node_l; w[6] = wl_leaf_x; w[7] = wl_leaf_l;
     }
   }
@@ -1947,6 +1985,29 @@ __global__ void accel_roots_kernel(const uint32_t* __restrict__ tlas, const uint
   }
 }
 
+// Depth of the scene in INTERNAL levels on a root-to-leaf path, TLAS and BLAS together: what bounds a lane's stack (a node step leaves at most
+// three pending siblings; instance and leaf steps leave none).  One pass per level over the compact nodes (children lie after their parents, so
+// the trees are acyclic): pass t gives every internal child of a node of level t - 1 the level t; a TLAS leaf hands its level on to the root of
+// its instance's BLAS.  `deepest` ends as the last level any node reached.  Only reached nodes are read (unreached slots are not initialised).
+__global__ void accel_depth_kernel(const uint4* __restrict__ nodes_c, uint32_t n_nodes, uint32_t tlas_root, const uint32_t* __restrict__ blas_root,
+                                   uint32_t level, uint32_t* __restrict__ depth, uint32_t* __restrict__ deepest) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  auto reach = [&](uint32_t d) {
+    if (is_inst_desc(d)) d = blas_root[d & PAYLOAD_MASK];
+    if (!is_node_desc(d)) return;
+    const uint32_t c = d & PAYLOAD_MASK;
+    if (c < n_nodes) { atomicMax(&depth[c], level); *deepest = level; }   // (every writer of a pass stores the same value)
+  };
+  if (level == 1u) {
+    if (i == 0) reach(tlas_root);
+    return;
+  }
+  if (i >= n_nodes || depth[i] != level - 1u) return;
+  const uint4* np = nodes_c + (size_t)i * CNODE_VEC4;
+  const uint4 q2 = np[2], q3 = np[3];
+  reach(q2.z); reach(q2.w); reach(q3.x); reach(q3.y);
+}
+
 // Top of the tree for LDS staging: breadth-first from the TLAS root through the instance roots, the first `cap` internal
 // nodes get slots 0..n-1 (so the levels every ray walks come first).  The image holds their compact nodes as four planes of
 // `cap` uint4 with the child descriptors of staged children rewritten to DESC_TOP_FLAG | slot; the *_top roots likewise.
@@ -2131,6 +2192,8 @@ struct vxrt_accel {
   uint32_t ap_count = 0, ap_key[6] = {0, 0, 0, 0, 0, 0};
   uint64_t ap_cap = 0;
   float max_reflectivity = 0.0f;   // over the instance records: > 0 enables the mirror-bounce path
+  uint32_t levels = 0;             // internal levels on the longest root-to-leaf path (TLAS + BLAS), counted up to RT_SHALLOW_LEVELS + 1
+  bool shallow = false;            // levels <= RT_SHALLOW_LEVELS: the timed launches take the SHALLOW instantiations
   int device = 0;
 };
 
@@ -2308,8 +2371,27 @@ int vxrt_accel_build(const vxrt_scene_t* s, void* stream, vxrt_accel_t** out) {
          hipMemcpy(hdr, a->top_roots, sizeof hdr, hipMemcpyDeviceToHost) == hipSuccess;
     n_top = hdr[0]; troot_top = hdr[1];
   }
+  // depth class of the scene (see accel_depth_kernel): RT_SHALLOW_LEVELS + 1 passes, no host round trip in between -- a scene that still
+  // reaches new nodes in the last one is deeper than the class
+  uint32_t levels = 0;
+  if (ok && (hstatus & STATUS_BAD_SCENE) == 0) {
+    const uint32_t nc = s->n_tlas_nodes + s->n_bvh_nodes;
+    uint32_t* d_depth = nullptr;
+    ok = hipMalloc((void**)&d_depth, ((size_t)nc + 1) * 4) == hipSuccess && hipMemsetAsync(d_depth, 0, ((size_t)nc + 1) * 4, st) == hipSuccess;
+    if (ok) {
+      for (uint32_t level = 1; level <= RT_SHALLOW_LEVELS + 1u; ++level)
+        hipLaunchKernelGGL(accel_depth_kernel, dim3(level == 1u ? 1u : (nc + 255) / 256), dim3(256), 0, st, (const uint4*)a->nodes_c, nc, troot,
+                           (const uint32_t*)a->blas_root, level, d_depth, d_depth + nc);
+      ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+           hipMemcpy(&levels, d_depth + nc, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d_depth);
+  }
   (void)hipFree(d_ranges); (void)hipFree(d_status); (void)hipFree(d_troot);
   if (!ok || (hstatus & STATUS_BAD_SCENE) != 0) { accel_free(a); return -1; }   // malformed tree: rejected before any traversal
+  static const int shallow_env = [] { const char* e = getenv("VXRT_SHALLOW"); return e ? atoi(e) : -1; }();   // (measurement knob: 0 = full-size stacks for every scene)
+  a->levels = levels;
+  a->shallow = levels <= RT_SHALLOW_LEVELS && shallow_env != 0;
   a->dev.nodes_c = (const uint4*)a->nodes_c; a->dev.ref_tlas = (const uint32_t*)s->tlas; a->dev.n_tlas = s->n_tlas_nodes; a->dev.tri_w = (const float4*)a->tri_w;
   a->dev.blas_root = (const uint32_t*)a->blas_root; a->dev.tlas_root = troot;
   a->dev.ident_root = 0u;
@@ -2343,6 +2425,17 @@ uint64_t vxrt_accel_bytes(const vxrt_accel_t* a) {
   if (!a) return 0;
   return (uint64_t)a->ref.n_tlas_nodes * CNODE_VEC4 * 16 + (uint64_t)a->ref.n_bvh_nodes * CNODE_VEC4 * 16 +
          (uint64_t)a->ref.n_tris * WTRI_FLOATS * 4 + (uint64_t)a->ref.n_blas * 4;
+}
+
+int vxrt_accel_info(const vxrt_accel_t* a, uint32_t which, uint64_t* value) {
+  if (!a || !value) return -1;
+  switch (which) {
+  case 0: *value = a->levels; return 0;            // internal levels on the longest root-to-leaf path, counted up to RT_SHALLOW_LEVELS + 1
+  case 1: *value = a->shallow ? 1u : 0u; return 0; // the timed launches take the SHALLOW instantiations (48-entry stacks)
+  case 2: *value = a->dev.ident_root; return 0;    // the TLAS root is one identity instance (rays keep their world coordinates)
+  case 3: *value = a->dev.exact_decode; return 0;  // the scene takes the ldexp decode / generic slab form
+  }
+  return -1;
 }
 
 int vxrt_accel_frames_in_flight(vxrt_accel_t* a, uint32_t n) {
@@ -2389,14 +2482,15 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   X.total_dev = nullptr;   // the EXACT launch takes its count from the deferral list
   X.order = nullptr;
   ShadeParams p{};
-#define LAUNCH_T(ST, LD) do { \
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, false>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, false>, n)), dim3(RT_WG_THREADS), 0, s, a->dev, p, A); \
+#define LAUNCH_T(ST, LD, SH) do { \
+    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, false, false, SH>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, false, false, SH>, n)), dim3(RT_WG_THREADS), 0, s, a->dev, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, true>), dim3(std::max<uint32_t>(EXACT_GRID, persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, true>, n / 8, 256))), dim3(256), 0, s, a->dev, p, X); } while (0)
   // (the EXACT launch's grid grows with the ray buffer -- a workgroup per 2,048 rays, up to the machine: how many rays were deferred
   // is known on the device only, and a buffer of axis-parallel rays defers all of them; with nothing deferred its wavefronts find
   // every shard empty without an atomic and exit)
-  if (stats_counters) { if (a->dev.exact_decode) LAUNCH_T(1, true); else LAUNCH_T(1, false); }
-  else                { if (a->dev.exact_decode) LAUNCH_T(0, true); else LAUNCH_T(0, false); }
+  if (stats_counters)  { if (a->dev.exact_decode) LAUNCH_T(1, true, false); else LAUNCH_T(1, false, false); }
+  else if (a->shallow) { if (a->dev.exact_decode) LAUNCH_T(0, true, true); else LAUNCH_T(0, false, true); }
+  else                 { if (a->dev.exact_decode) LAUNCH_T(0, true, false); else LAUNCH_T(0, false, false); }
 #undef LAUNCH_T
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -2615,6 +2709,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   }
   PersistArgs A{};
   A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.row_step = row_step; A.total = n_tiles * 64u;
+  A.div_tiles_x = fast_div_make(tiles_x); A.div_frame_tiles = fast_div_make(frame_tiles); A.frame_tiles = frame_tiles;
   A.hits = (HitRec*)c->hitbuf; A.counters = counters; A.status = st; A.wave_log = wave_log;
   A.utab = a->uvtab; A.vtab = a->uvtab + width;
   if (batch > 1) {
@@ -2763,11 +2858,13 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     uint32_t div = grid_div_env > 0 ? (uint32_t)grid_div_env : ((grid_div_env == 0 && a->n_ctx > 1 && (uint64_t)A.total < 2ull * 64ull * RT_WG_WAVES * cap) ? a->n_ctx : 1u); \
     if (div > 1u) g = std::min<uint32_t>(g, std::max<uint32_t>(cap / div, 1u)); \
     return std::max<uint32_t>(1u, g > side_wgs_r ? g - side_wgs_r : 1u); }()
-#define LAUNCH_P(J, ST, LD, PK) do { \
+#define LAUNCH_P(J, ST, LD, PK, SH) do { \
     if (side_launch) hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(side_wgs), block, 0, side, sc, p, X0); \
-    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false, PK>), dim3(MAIN_GRID((rt_persistent_kernel<J, ST, LD, false, PK>))), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
+    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false, PK, SH>), dim3(MAIN_GRID((rt_persistent_kernel<J, ST, LD, false, PK, SH>))), dim3(RT_WG_THREADS), 0, s, sc, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, true>), dim3(EXACT_GRID), block, 0, s, sc, p, X); } while (0)
-#define LAUNCH_PD(J, ST, PK) do { if (sc.exact_decode) LAUNCH_P(J, ST, true, PK); else LAUNCH_P(J, ST, false, PK); } while (0)
+#define LAUNCH_PD(J, ST, PK) do { if (sc.exact_decode) LAUNCH_P(J, ST, true, PK, false); else LAUNCH_P(J, ST, false, PK, false); } while (0)
+  // (timed builds: the scene's depth class picks the size of the scratch part of the stack)
+#define LAUNCH_PDS(J, PK) do { if (a->shallow) { if (sc.exact_decode) LAUNCH_P(J, 0, true, PK, true); else LAUNCH_P(J, 0, false, PK, true); } else LAUNCH_PD(J, 0, PK); } while (0)
   // one diffuse bounce: the whole frame in the persistent launches (JOB_RENDER_GI).  (The multi-pass form it replaced -- list the hit
   // pixels, generate the rays, a 2 M-ray trace launch, accumulate, final -- took the same 1.18 ms: profiles/r03_f_gi_fused_ab.txt)
   const bool gi_fused = ao && ao->reserved == VXRT_AO_MODE_DIFFUSE_BOUNCE;
@@ -2776,12 +2873,13 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
     A.dst = dst; A.colors = colors; A.gi_seed = ao->seed;
     X.dst = dst; X.colors = colors; X.gi_seed = ao->seed;
     X0.dst = dst; X0.colors = colors; X0.gi_seed = ao->seed;
-    LAUNCH_PD(JOB_RENDER_GI, 0, false);
+    LAUNCH_PDS(JOB_RENDER_GI, false);
   } else
   if (stats == 2)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 2, false); else LAUNCH_PD(JOB_RENDER, 2, false); }
   else if (stats)  { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 1, false); else LAUNCH_PD(JOB_RENDER, 1, false); }
-  else if (packed) { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 0, true); else LAUNCH_PD(JOB_RENDER, 0, true); }
-  else             { if (shadow) LAUNCH_PD(JOB_RENDER_SHADOW, 0, false); else LAUNCH_PD(JOB_RENDER, 0, false); }
+  else if (packed) { if (shadow) LAUNCH_PDS(JOB_RENDER_SHADOW, true); else LAUNCH_PDS(JOB_RENDER, true); }
+  else             { if (shadow) LAUNCH_PDS(JOB_RENDER_SHADOW, false); else LAUNCH_PDS(JOB_RENDER, false); }
+#undef LAUNCH_PDS
 #undef LAUNCH_PD
 #undef LAUNCH_P
 #undef MAIN_GRID

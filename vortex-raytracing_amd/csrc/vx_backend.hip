@@ -566,6 +566,10 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   // the scene's own buffers are read on the device: small ones uploaded lazily get their device copy now
   for (Alloc* al : {r_tlas.a, r_blas.a, r_bvh.a, r_tri.a, r_triex.a, r_mat.a, r_tex.a})
     if (flush_stale(al) != 0) return -1;
+  // ... and so does the output buffer: a host that cleared a small framebuffer (<= 4 KB: 32x32 pixels) before the run left a
+  // lazy upload behind, which must reach the device BEFORE the kernels write pixels -- flushed later (by vx_copy_from_dev) it
+  // would put the host's old bytes over the frame
+  if (flush_stale(r_dst.a) != 0) return -1;
   vxrt_scene_t sc{};
   sc.tlas = ptr(r_tlas); sc.blas = ptr(r_blas); sc.bvh = ptr(r_bvh); sc.tri = ptr(r_tri);
   sc.triEx = ptr(r_triex); sc.mat = ptr(r_mat); sc.tex = r_tex.a ? ptr(r_tex) : nullptr;
@@ -743,7 +747,7 @@ int vx_device::start_raycast(uint64_t args_va) {
   }
   auto ptr = [](Res r) { return (const void*)((const char*)r.a->dptr + r.off); };
   auto count = [](Res r, uint64_t stride) { return (uint32_t)std::min<uint64_t>((r.a->size - r.off) / stride, 0x7fffffff); };
-  for (Alloc* al : {r_tlas.a, r_blas.a, r_bvh.a, r_tri.a, r_triex.a, r_idx.a, r_tex.a})      // (small scene buffers uploaded lazily: see upload())
+  for (Alloc* al : {r_tlas.a, r_blas.a, r_bvh.a, r_tri.a, r_triex.a, r_idx.a, r_tex.a, r_dst.a})      // (small scene buffers uploaded lazily: see upload(); the output buffer: see start())
     if (flush_stale(al) != 0) return -1;
   vxrc_scene_t sc{};
   sc.tlas = ptr(r_tlas); sc.blas = ptr(r_blas); sc.bvh = ptr(r_bvh); sc.tri = ptr(r_tri); sc.triEx = ptr(r_triex);

@@ -216,6 +216,27 @@ def rc_accel_build(scene, stream=None):
     return h
 
 
+def accel_info(accel, which):
+    """vxrt_accel_info: 0 -> internal levels of the deepest path (counted up to 17), 1 -> 48-entry stacks (depth class <= 16),
+    2 -> single identity instance under the TLAS root, 3 -> ldexp decode."""
+    L = _lib()
+    L.vxrt_accel_info.restype = C.c_int
+    L.vxrt_accel_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    v = C.c_uint64()
+    check(L.vxrt_accel_info(accel, which, C.byref(v)), "vxrt_accel_info")
+    return int(v.value)
+
+
+def rc_accel_info(accel, which):
+    """vxrc_accel_info: 0 -> the walk takes two levels per fetch (wide nodes), 1 -> internal levels of the deepest tree."""
+    L = _lib()
+    L.vxrc_accel_info.restype = C.c_int
+    L.vxrc_accel_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    v = C.c_uint64()
+    check(L.vxrc_accel_info(accel, which, C.byref(v)), "vxrc_accel_info")
+    return int(v.value)
+
+
 def rc_accel_destroy(accel):
     if accel:
         L = _lib()
