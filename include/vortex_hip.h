@@ -366,7 +366,7 @@ int vxrc_accel_destroy(vxrc_accel_t* accel);
 /* What the build decided (diagnostic): which = 0 -> 1 if the walk takes two BVH2 levels per fetch (wide nodes), 0 if it keeps the
  * reference's two-wide walk (a box that is not the union of its children's, an unbounded box, or a tree deeper than 42 internal
  * levels, whose wide walk could need more than the reference's 64 stack entries); which = 1 -> internal nodes on the longest
- * root-to-leaf path (0 when the wide layout was not requested). */
+ * root-to-leaf path, counted up to 43 (0 when the wide layout was not requested). */
 int vxrc_accel_info(const vxrc_accel_t* accel, uint32_t which, uint64_t* value);
 /* vxrc_render on a prebuilt layout (asynchronous on `stream`; the layout keeps four frame contexts: frames issued round robin on up to
  * four streams overlap). */
@@ -425,6 +425,12 @@ int vxrt_trace_reference_quirks(const void* image, uint64_t image_size, uint32_t
  * [288 + 32 k] of the EXACT launch over the deferred list, [544 + 32 k] of the a-priori EXACT launch.  A vxrt_trace call leaves the
  * block as its launches left it (the next call clears it). */
 int vxrt_debug_read_control(vxrt_accel_t* accel, uint32_t ctx, uint32_t* out, uint32_t n_dwords, void* stream);
+/* Diagnostic (tools/xcd_tail.py): from now on every main traversal launch on this layout -- the TIMED kernels included -- leaves per
+ * wavefront (index = workgroup * 4 + wavefront of the workgroup) [0] the constant 100 MHz clock at its end and [1] rays it started |
+ * physical XCD << 56 in `log` (device memory, 2 u64 per wavefront, room for 8,192 wavefronts); NULL switches it off.  One store per
+ * wavefront, at its end.  The pointer is captured by the launches enqueued after the call (no synchronisation): the caller keeps the
+ * memory alive until they have run. */
+int vxrt_debug_end_log(vxrt_accel_t* accel, unsigned long long* log);
 /* diagnostic (tools/tile_tail.py): what frame context `ctx` learned for sets of `batch` frames -- per-tile cost (loop iterations of the
  * wavefront that traced it in the last launch; start clocks, durations and steal distances behind them after a wave-log launch) and the
  * tile order derived from it.  Returns the capacity in tiles. */

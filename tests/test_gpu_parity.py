@@ -722,7 +722,9 @@ def test_wave_log_reports_every_slot_it_documents(vrt, po, gpu_device):
     torch.cuda.synchronize()
     lg = log.cpu().numpy()
     lg = lg[lg[:, 1] > 0]
-    assert len(lg) > 0 and int(lg[:, 2].sum()) == w * h                 # rays started, over the wavefronts that ran
+    # rays started, over the wavefronts of the MAIN launch: every pixel but the column and the row through the middle of the frame (u == 0
+    # or v == 0: a zero direction component, traced by the EXACT launch on the side stream, which keeps no log)
+    assert len(lg) > 0 and int(lg[:, 2].sum()) == w * h - (w + h - 1)
     xcd = (lg[:, 9].astype(np.uint64) >> np.uint64(56)).astype(np.int64)
     assert xcd.min() >= 0 and xcd.max() <= 7
     busy = lg[lg[:, 3] > 0]                                             # wavefronts that got a tile
@@ -734,3 +736,60 @@ def test_wave_log_reports_every_slot_it_documents(vrt, po, gpu_device):
     rpx, _, _ = po.render(sc, w, h)
     assert np.array_equal(px.cpu().numpy().view(np.uint32), rpx)
     ds.close()
+
+
+@pytest.mark.parametrize("k,shallow", [(5, 1), (16, 1), (17, 0), (32, 0)])
+def test_depth_class_picks_the_stack_and_deep_chains_match_the_oracle(vrt, po, gpu_device, k, shallow):
+    """The accel build measures the scene's depth (internal levels on the longest root-to-leaf path) and scenes of at most 16 levels
+    run with 48-entry stacks, deeper ones with the reference's 32 levels' worth.  A chain-like BVH4 k levels deep whose camera rays
+    leave three pending siblings per level (3 k entries at the bottom: exactly 48 at k = 16, 96 at k = 32, the reference's own limit):
+    hit records (frame kernels, 7 and 8 wavefronts per SIMD, with shadow rays; ray buffers, closest and any hit) equal the oracle's
+    and no overflow is reported."""
+    import torch
+    from scenes import chain_bvh4
+    sc = chain_bvh4(vrt, k)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    assert vrt.rtapi.accel_info(ds.accel, 0) == min(k, 17)
+    import os
+    assert vrt.rtapi.accel_info(ds.accel, 1) == (0 if os.environ.get("VXRT_SHALLOW") == "0" else shallow)   # (measurement knob: full-size stacks for every scene)
+    w, h = 96, 72
+    rays = po.camera_rays(w, h)
+    want, st = po.trace_canonical(sc, rays)
+    assert st["max_stack"] == 3 * k and (want["dist"] < 1e29).mean() > 0.1
+    got = gpu_trace(vrt, ds, rays)
+    assert np.array_equal(_bits(got), _bits(want))
+    wf, _ = po.trace_faithful(sc, rays, any_hit=True)
+    assert np.array_equal(_bits(gpu_trace(vrt, ds, rays, mode=vrt.rtapi.MODE_ANY)), _bits(wf))
+    p = vrt.rtapi.default_shade_params()
+    p.light_pos[:] = (-50.0, 180.0, 40.0)
+    rpx, rhits, _, _ = po.render_ex(sc, w, h, po.shade_params(light_pos=(-50.0, 180.0, 40.0)), 1)
+    px, hn, _, _ = gpu_render(vrt, ds, w, h, shadow=1, params=p)
+    assert np.array_equal(px, rpx)
+    assert np.array_equal(_bits(hn), _bits(rhits))
+    ds.close()
+
+
+def test_a_tree_deeper_than_the_reference_allows_sets_the_overflow_status(vrt, po, gpu_device):
+    """36 levels with three pending siblings each need 108 stack entries: more than the reference's 32-level trail allows (undefined
+    behaviour there).  The kernels drop what does not fit, flag it (status bit 0) and end; the next scene on the device is unaffected."""
+    import torch
+    from scenes import chain_bvh4
+    sc = chain_bvh4(vrt, 36)
+    ds = vrt.tracer.DeviceScene(sc, gpu_device)
+    assert vrt.rtapi.accel_info(ds.accel, 1) == 0
+    w, h = 64, 48
+    rays = torch.from_numpy(po.camera_rays(w, h)).to(gpu_device)
+    out = torch.zeros(w * h * 24, dtype=torch.uint8, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.trace(ds.accel, rays.data_ptr(), w * h, out.data_ptr(), vrt.rtapi.MODE_CLOSEST, None, s)
+    assert vrt.rtapi.status(s) & 1
+    px = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
+    vrt.rtapi.render(ds.accel, w, h, 0, h, vrt.rtapi.default_shade_params(), px.data_ptr(), 0, None, None, None, s)
+    assert vrt.rtapi.status(s) & 1
+    assert vrt.rtapi.status(s) == 0                      # read-and-clear
+    ds.close()
+    ok = chain_bvh4(vrt, 8)
+    d2 = vrt.tracer.DeviceScene(ok, gpu_device)
+    got = gpu_trace(vrt, d2, po.camera_rays(w, h))
+    assert np.array_equal(_bits(got), _bits(po.trace_canonical(ok, po.camera_rays(w, h))[0]))
+    d2.close()

@@ -25,3 +25,17 @@ def test_lds_staging_variants_stay_bit_equal(vrt, gpu_device):
                         "reference_fixture or render_matches_oracle or shadow_rays_extension"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
     assert " passed" in r.stdout and "top-of-tree nodes staged" in (r.stdout + r.stderr)     # the variant library is the one that ran
+
+
+def test_eight_wavefront_instantiation_on_small_frames_and_deep_trees(vrt, gpu_device):
+    """The 8-wavefront (`PACKED`) instantiation of the frame kernel is picked for sets of frames that overlap on several streams at the
+    benchmark's sizes only; the full-size tests cover it there on a shallow scene.  A child process forces it for every frame
+    (VXRT_PACKED=1) and runs the frame parity tests -- the deep chains that take the full-size stacks among them; a second one forces the
+    full-size stacks on every scene (VXRT_SHALLOW=0), so that both depth classes of both occupancies are compared with the oracle."""
+    for extra in ({"VXRT_PACKED": "1"}, {"VXRT_PACKED": "1", "VXRT_SHALLOW": "0"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-k",
+                            "depth_class or render_matches_oracle or shadow_rays_extension or overflow_status"],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, (extra, r.stdout[-3000:], r.stderr[-1500:])
+        assert " passed" in r.stdout

@@ -187,6 +187,14 @@ def main():
             if len(ms) == 2:
                 cxx = {"cxx_host_ms_per_frame_start_wait": ms[0], "cxx_host_ms_per_frame_with_copy_from_dev": ms[1],
                        "cxx_host_mrays_s_start_wait": round(rays / ms[0] / 1e3, 1), "cxx_host_mrays_s_with_copy": round(rays / ms[1] / 1e3, 1)}
+            # kernel_arg_t::samples_per_pixel = 5 (the reference host's `-s 5`: the frame's rays five times in ONE vx_start, kernel.cpp:67-80)
+            r5 = subprocess.run([os.path.join(lib, "rt_host"), "-m", "proc:atrium:8", "-w", str(W), "-h", str(H), "-S", "-L", "300,480,60", "-s", "5", "-N", "300", "-q", "-o", "/tmp/vxrt_cfg7.ppm",
+                                 "-k", os.path.join(vrt.VXBIN_DIR, "kernel.vxbin")], env=dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""), VORTEX_DRIVER="hip"),
+                                capture_output=True, text=True, timeout=600)
+            ms5 = [float(x) for x in re.findall(r"frame loop \(300 frames, [^)]*\): ([0-9.]+) ms per frame", r5.stdout)]
+            if len(ms5) == 2:
+                cxx.update({"cxx_host_spp5_ms_per_start_wait": ms5[0], "cxx_host_spp5_ms_per_start_with_copy_from_dev": ms5[1],
+                            "cxx_host_spp5_mrays_s_start_wait": round(5 * rays / ms5[0] / 1e3, 1), "cxx_host_spp5_mrays_s_with_copy": round(5 * rays / ms5[1] / 1e3, 1)})
         except Exception as e:
             cxx = {"cxx_host_error": repr(e)[:200]}
         out.append({**cxx, "config": "drop-in vx_* sequence (ctypes host): Sponza-class, 1920x1080, primary + 1 shadow ray, serial frames", "rays_per_frame": int(rays),

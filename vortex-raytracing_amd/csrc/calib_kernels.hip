@@ -211,10 +211,54 @@ int vxcal_valu_loop(int op, uint32_t blocks, uint32_t n_iter, float* out, unsign
 }
 uint32_t vxcal_instr_per_iter(void) { return CAL_CHAINS * CAL_UNROLL; }
 
+// XCD probe (tools/xcd_probe.py): is one XCD slower than another, and at what -- issuing VALU instructions, waiting for memory, or device-scope
+// atomics?  One wavefront per workgroup, as many workgroups as asked for (the dispatcher deals them over the XCDs); every wavefront stamps the
+// shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) around three loops of fixed work:
+//   (1) n_alu x 64 dependent v_fma_f32                                   -> VALU issue: 100 MHz ticks per loop give the XCD's real clock
+//   (2) n_chase dependent loads through `chase` (a random cycle over a buffer far larger than the L2), every lane its own chain -> memory latency
+//   (3) n_atom dependent device-scope atomic adds on ONE word (lane 0)    -> round trip to wherever that word's line lives
+// out, 8 u64 per wavefront: [0] physical XCD | HW_ID << 8, [1] 100 MHz clock at the start, [2..3] loop 1 in 100 MHz ticks / shader clocks,
+// [4..5] loop 2, [6..7] loop 3.
+__global__ __launch_bounds__(64) void vxcal_xcd_probe_kernel(uint32_t n_alu, const uint32_t* __restrict__ chase, uint32_t chase_len, uint32_t n_chase,
+                                                             uint32_t* __restrict__ atom, uint32_t n_atom, unsigned long long* __restrict__ out, float* __restrict__ sink) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20), hwid = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+  unsigned long long r[4], c[4];
+  float a = (float)lane * 1e-3f + 1.0f;
+  const float m = 1.0000001f, k = 0.25f;
+  r[0] = wall_clock64(); c[0] = __builtin_readcyclecounter();
+  for (uint32_t i = 0; i < n_alu; ++i) {
+#pragma unroll
+    for (int u = 0; u < 64; ++u) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(m), "v"(k));
+  }
+  r[1] = wall_clock64(); c[1] = __builtin_readcyclecounter();
+  uint32_t idx = (blockIdx.x * 64u + lane) * 2654435761u % chase_len;
+  for (uint32_t i = 0; i < n_chase; ++i) idx = __builtin_nontemporal_load(chase + idx);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  r[2] = wall_clock64(); c[2] = __builtin_readcyclecounter();
+  uint32_t v = idx & 1u;
+  if (lane == 0) for (uint32_t i = 0; i < n_atom; ++i) v = atomicAdd(atom, (v & 1u) + 1u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  r[3] = wall_clock64(); c[3] = __builtin_readcyclecounter();
+  if (a == 123.456f || idx == 0xFFFFFFFFu || v == 0xFFFFFFFFu) sink[0] = a;   // (keeps the loops alive)
+  if (lane == 0) {
+    unsigned long long* w = out + 8ull * blockIdx.x;
+    w[0] = (unsigned long long)xcc | ((unsigned long long)hwid << 8); w[1] = r[0];
+    for (int j = 0; j < 3; ++j) { w[2 + 2 * j] = r[j + 1] - r[j]; w[3 + 2 * j] = c[j + 1] - c[j]; }
+  }
+}
+
 // Clock probe: ONE wavefront reads the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime), spins for `ticks`
 // of the latter (a bounded loop: it also ends after max_iter iterations) and reads both again.  out[0] = shader cycles, out[1] =
 // 100 MHz ticks: shader clock in GHz = out[0] / out[1] / 10.  Launched right before and right after a timed region, on the stream
 // that carries it, it says what clock the chip held there (the power management reacts over milliseconds, the probe takes ~30 us).
+int vxcal_xcd_probe(uint32_t n_waves, uint32_t n_alu, const uint32_t* chase, uint32_t chase_len, uint32_t n_chase, uint32_t* atom, uint32_t n_atom,
+                    unsigned long long* out, float* sink, void* stream) {
+  if (!n_waves || n_waves > (1u << 20) || !chase || !chase_len || !atom || !out || !sink) return -1;
+  hipLaunchKernelGGL(vxcal_xcd_probe_kernel, dim3(n_waves), dim3(64), 0, (hipStream_t)stream, n_alu, chase, chase_len, n_chase, atom, n_atom, out, sink);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int vxcal_clock_probe(uint32_t ticks, unsigned long long* out, void* stream) {
   if (!out || ticks == 0 || ticks > 100000u) return -1;
   hipLaunchKernelGGL(vxcal_clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks, out);

@@ -607,6 +607,9 @@ struct PersistArgs {
   const uint32_t* tile_order; uint32_t* tile_cost;
   uint32_t shard_rot;             // diagnostic (VXRT_SHARD_ROT): home shard of block b = (b + shard_rot) % QUEUE_SHARDS
   unsigned long long* wave_log;   // STATS only, optional: 16 u64 per wavefront (see vxrt_render_wave_log in the header)
+  // optional, every build (the TIMED kernels too: one store per wavefront when it ends, nothing inside the loop): 2 u64 per wavefront of the main
+  // launch -- [0] the constant 100 MHz clock at its end, [1] rays it started | physical XCD << 56 (vxrt_debug_end_log; tools/xcd_tail.py)
+  unsigned long long* end_log;
   // batch of frames in one launch (vxrt_render_interleaved_batch): the window's tiles repeat `frame_tiles` apart, frame f = tile /
   // frame_tiles is shaded and lit with pbatch[f]; nullptr = one frame
   const ShadeParams* pbatch; uint32_t frame_tiles;
@@ -1280,6 +1283,15 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
       w[9] = (unsigned long long)wl_no3 | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 56);   // [63:56] physical XCD
       w[10] = wl_tn; w[11] = wl_tl; w[12] = __builtin_readcyclecounter() - wl_tstart;
       w[3] = wl_iter; w[4] = wl_node_x; w[5] = wl_node_l; w[6] = wl_leaf_x; w[7] = wl_leaf_l;
+    }
+  }
+  if (!EXACT && A.end_log) {
+    unsigned s = nrays;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) {
+      unsigned long long* w = A.end_log + 2ull * (blockIdx.x * (uint32_t)WG_WAVES + (threadIdx.x >> 6));
+      w[0] = wall_clock64();
+      w[1] = (unsigned long long)s | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 56);
     }
   }
   if (A.counters) {
@@ -2192,6 +2204,7 @@ struct vxrt_accel {
   uint32_t ap_count = 0, ap_key[6] = {0, 0, 0, 0, 0, 0};
   uint64_t ap_cap = 0;
   float max_reflectivity = 0.0f;   // over the instance records: > 0 enables the mirror-bounce path
+  unsigned long long* end_log = nullptr;   // diagnostic (vxrt_debug_end_log): where the main launches leave their wavefronts' end times
   uint32_t levels = 0;             // internal levels on the longest root-to-leaf path (TLAS + BLAS), counted up to RT_SHALLOW_LEVELS + 1
   bool shallow = false;            // levels <= RT_SHALLOW_LEVELS: the timed launches take the SHALLOW instantiations
   int device = 0;
@@ -2464,6 +2477,7 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   PersistArgs A{};
   A.total = (uint32_t)n; A.hits = hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
   A.total_dev = n_dev;
+  A.end_log = a->end_log;
   A.order = order;
   A.counters = stats_counters;
   A.status = st;
@@ -2710,7 +2724,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   PersistArgs A{};
   A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.row_step = row_step; A.total = n_tiles * 64u;
   A.div_tiles_x = fast_div_make(tiles_x); A.div_frame_tiles = fast_div_make(frame_tiles); A.frame_tiles = frame_tiles;
-  A.hits = (HitRec*)c->hitbuf; A.counters = counters; A.status = st; A.wave_log = wave_log;
+  A.hits = (HitRec*)c->hitbuf; A.counters = counters; A.status = st; A.wave_log = wave_log; A.end_log = a->end_log;
   A.utab = a->uvtab; A.vtab = a->uvtab + width;
   if (batch > 1) {
     if (!c->pbatch && hipMalloc((void**)&c->pbatch, VXRT_MAX_BATCH * sizeof(ShadeParams)) != hipSuccess) return fail();
@@ -2768,8 +2782,12 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   // runs, rank 0's pipeline of 8 / 4 / 2 ranks (40.8 K / 81.6 K / 162 K tiles per batch): +5.5 % / +2 % / 0; one GPU's batches of
   // five whole frames (162 K tiles, sets overlapping on two streams): -5 % -- sorted by cost, a band's tiles are no longer
   // traced next to their screen neighbours, and there the tails are filled anyway.
+  static const uint32_t lpt_batch_max = [] { const char* e = getenv("VXRT_LPT_BATCH_MAX"); return e ? (uint32_t)atoll(e) : LPT_BATCH_MAX_TILES; }();   // (measurement knob)
+  // (a set issued on its own -- one frame context: the samples of one vx_start -- has nothing behind it to fill its tail, whatever its size)
+  // (longest tile first also in a large set then: the samples of `rt_host -s 5`, 162 K tiles, 2.25 -> 2.00 ms per vx_start; VXRT_LPT_BATCH_ALONE=0: off)
+  static const int lpt_alone_env = [] { const char* e = getenv("VXRT_LPT_BATCH_ALONE"); return e ? atoi(e) : 1; }();
   const bool lpt = lpt_on && (!stats || wave_log) && n_tiles >= LPT_MIN_TILES &&
-                   (batch == 1 ? a->n_ctx == 1 : (lpt_batch_on && n_tiles <= LPT_BATCH_MAX_TILES));
+                   (batch == 1 ? a->n_ctx == 1 : (lpt_batch_on && (n_tiles <= lpt_batch_max || (lpt_alone_env && a->n_ctx == 1))));
   FrameCtx::Lpt& L = c->lpt[batch];
   if (lpt) {
     if (L.cap < n_tiles) {
@@ -2834,7 +2852,8 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   const bool side_reserve = side_reserve_env >= 0 ? side_reserve_env != 0 : a->n_ctx == 1;
   // frames packed in overlapping sets: the 8-wavefront instantiation (see rt_persistent_kernel); VXRT_PACKED=0/1 forces it
   static const int packed_env = [] { const char* e = getenv("VXRT_PACKED"); return e ? atoi(e) : -1; }();
-  const bool packed = packed_env >= 0 ? packed_env != 0 : (a->n_ctx > 1 && n_tiles >= LPT_MIN_TILES);
+  static const int packed_batch_env = [] { const char* e = getenv("VXRT_PACKED_BATCH"); return e ? atoi(e) : 0; }();   // (measurement knob: sets of frames take it even with one frame context)
+  const bool packed = packed_env >= 0 ? packed_env != 0 : ((a->n_ctx > 1 || (packed_batch_env && batch > 1)) && n_tiles >= LPT_MIN_TILES);
   hipStream_t side = c->side;
   if (side_launch) {
     // the side stream starts behind what is queued on `s` (the previous frame's shading pass reads the hit records this launch writes) --
@@ -3094,6 +3113,16 @@ int vxrt_shade_rays(vxrt_accel_t* a, const float* rays, const vxrt_hit_t* hits, 
 // diagnostic (tests): the control block of frame context `ctx` as the last call left it -- [0] deferral count, [32 + 32 k] the
 // main launch's queue shard k, [32 + 256 + 32 k] the shards of the EXACT launch over the deferred list, [32 + 512 + 32 k] those of
 // the a-priori EXACT launch.  vxrt_trace leaves the block for the next call to clear, so it can be inspected after a trace.
+// diagnostic (tools/xcd_tail.py): from now on every main traversal launch on this layout -- the timed kernels included -- leaves, per wavefront,
+// the constant 100 MHz clock at its end and its ray count | physical XCD << 56 in `log` (device memory, 2 u64 per wavefront, room for 8,192
+// wavefronts: 16 x 8,192 u64; the caller zeroes it between the launches it wants to tell apart, and keeps it alive until they have run); nullptr
+// switches it off again.  The EXACT launches do not write.  Costs the timed kernel one store per wavefront at its end.
+int vxrt_debug_end_log(vxrt_accel_t* a, unsigned long long* log) {
+  if (!a) return -1;
+  a->end_log = log;   // (captured by the launches enqueued from now on; launches already enqueued keep what they were given)
+  return 0;
+}
+
 int vxrt_debug_read_control(vxrt_accel_t* a, uint32_t ctx, uint32_t* out, uint32_t n_dwords, void* stream) {
   if (!a || !out || ctx >= MAX_FRAMES_IN_FLIGHT || n_dwords > CTL_DWORDS || !a->ctx[ctx].ctl) return -1;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;

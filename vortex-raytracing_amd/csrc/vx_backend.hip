@@ -118,7 +118,6 @@ struct vx_device {
   void* q_image = nullptr; uint64_t q_image_size = 0; struct QKey { uint64_t va, size, version; bool operator<(const QKey& o) const { return va < o.va; } }; std::vector<QKey> q_image_key; void* q_rays = nullptr; void* q_hits = nullptr; uint64_t q_rays_cap = 0;
   uint64_t accel_key[14] = {0};
   uint64_t upload_seq = 0;
-
   int init() {
     const char* e = std::getenv("VORTEX_HIP_DEVICE");
     if (!e) e = std::getenv("LOCAL_RANK");
@@ -484,6 +483,9 @@ struct vx_device {
     wait_idle();
     (void)hipSetDevice(hip_dev);
     if (flush_stale(a) != 0) return -1;
+    // (The destination stays ordinary pageable memory.  Registering it with the runtime once per pointer -- so that the copy is one DMA instead of
+    // the runtime's staged copy -- was built and measured in round 5: 0.1735 against 0.168 ms for the 8.3 MB frame, no gain, and a registered
+    // range the host frees behind the backend's back is a hazard: removed again, profiles/r05_b_host_register_ab.txt.)
     if (hipStreamSynchronize(stream) != hipSuccess) return -1;   // (behind any staged upload still in the stream)
     if (size && hipMemcpy(dst, (char*)a->dptr + (va - a->va), size, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return 0;
@@ -670,7 +672,22 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   // samples_per_pixel: the reference's kernel traces the SAME camera ray that many times into the same payload (kernel.cpp:67-80: GenerateRay
   // takes no sample index, the colour accumulation is commented out), so the pixel is the one sample's -- and the run costs spp times the rays
   // and the time.  Honoured as written: the frame is traced spp times (same pixels; MINSTRET and MCYCLE are what a `-s 4` run expects).
+  // The samples of ONE vx_start are one workload, so they go out as one set of launches (the machinery of vxrt_render_batch on identical
+  // frames that all land on the same pixels -- frame stride 0; every sample is traced AND shaded, the last writer of a pixel stores the value
+  // the first one did): the launch's ramp and tail are paid once per run instead of once per sample.  Sets of at most VXRT_MAX_BATCH samples;
+  // the mirror arm (max_depth > 1) keeps one frame per set of launches (its bounce levels are per frame).
   int rc = 0;
+  std::vector<vxrt_shade_params_t> spv;
+  auto samples = [&](auto&& one, auto&& many) {   // one(): a single sample's launches; many(params, n): n samples in one set
+    uint32_t left = ka.samples_per_pixel;
+    if (ka.max_depth > 1 || left == 1) { for (; left && rc == 0; --left) rc = one(); return; }
+    spv.assign(std::min<uint32_t>(left, VXRT_MAX_BATCH), sp);
+    while (left && rc == 0) {
+      const uint32_t n = std::min<uint32_t>(left, VXRT_MAX_BATCH);
+      rc = n == 1 ? one() : many(spv.data(), n);
+      left -= n;
+    }
+  };
   const uint32_t n_dev = (uint32_t)helpers.size() + 1;
   if (n_dev > 1 && row_stride <= 1 && y0 == 0 && y1 == ka.dst_height && (ka.dst_height + 7) / 8 >= n_dev) {
     // VORTEX_HIP_DEVICES: a whole frame is split by interleaved 8-row tile rows over the listed devices (the split bench.py's ranks use);
@@ -682,14 +699,14 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
     for (auto& h : helpers)
       if (prepare_helper(h, sc, ver, bytes, (uint64_t)ka.dst_width * ka.dst_height * 4) != 0) { (void)hipSetDevice(hip_dev); return -1; }
     t_begin = std::chrono::steady_clock::now();
-    for (uint32_t smp = 0; smp < ka.samples_per_pixel && rc == 0; ++smp) {
-      (void)hipSetDevice(hip_dev);
-      rc = vxrt_render_interleaved(accel, ka.dst_width, ka.dst_height, 0, n_dev, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream);
-      for (uint32_t k = 1; k < n_dev && rc == 0; ++k) {
-        Helper& h = helpers[k - 1];
-        (void)hipSetDevice(h.hip_dev);
-        rc = vxrt_render_interleaved(h.accel, ka.dst_width, ka.dst_height, k, n_dev, &sp, (int)shadow, h.fb, nullptr, nullptr, h.d_rays, h.stream);
-      }
+    for (uint32_t k = 0; k < n_dev && rc == 0; ++k) {
+      vxrt_accel_t* ak = k ? helpers[k - 1].accel : accel;
+      uint32_t* fb = k ? helpers[k - 1].fb : dstp;
+      unsigned long long* cnt = k ? helpers[k - 1].d_rays : d_rays;
+      hipStream_t sk = k ? helpers[k - 1].stream : stream;
+      (void)hipSetDevice(k ? helpers[k - 1].hip_dev : hip_dev);
+      samples([&] { return vxrt_render_interleaved(ak, ka.dst_width, ka.dst_height, k, n_dev, &sp, (int)shadow, fb, nullptr, nullptr, cnt, sk); },
+              [&](const vxrt_shade_params_t* pv, uint32_t n) { return vxrt_render_interleaved_batch(ak, ka.dst_width, ka.dst_height, k, n_dev, n, pv, (int)shadow, fb, 0, cnt, sk); });
     }
     for (uint32_t k = 1; k < n_dev && rc == 0; ++k) rc = finish_helper(helpers[k - 1], k, n_dev, ka.dst_width, ka.dst_height, dstp);
     (void)hipSetDevice(hip_dev);
@@ -707,9 +724,12 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
     run_pending = true;
     return 0;
   }
-  for (uint32_t smp = 0; smp < ka.samples_per_pixel && rc == 0; ++smp)
-    rc = row_stride > 1 ? vxrt_render_interleaved(accel, ka.dst_width, ka.dst_height, y0 / 8u, row_stride, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream)
-                        : vxrt_render(accel, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream);
+  if (row_stride > 1)
+    samples([&] { return vxrt_render_interleaved(accel, ka.dst_width, ka.dst_height, y0 / 8u, row_stride, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream); },
+            [&](const vxrt_shade_params_t* pv, uint32_t n) { return vxrt_render_interleaved_batch(accel, ka.dst_width, ka.dst_height, y0 / 8u, row_stride, n, pv, (int)shadow, dstp, 0, d_rays, stream); });
+  else
+    samples([&] { return vxrt_render(accel, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream); },
+            [&](const vxrt_shade_params_t* pv, uint32_t n) { return vxrt_render_rows_batch(accel, ka.dst_width, ka.dst_height, y0, y1, n, pv, (int)shadow, dstp, 0, d_rays, stream); });
   if (rc != 0) { VXLOG("start: launch rejected (shape check)"); (void)hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream); return -1; }
   if (enqueue_readback() != 0) return -1;
   run_pending = true;
