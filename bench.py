@@ -63,6 +63,13 @@ def parse():
                     help="--shard bands: sizes of the sets the timed steps are issued in, e.g. 10,5,3,2 (sum = --steps); auto = sharding.taper(steps); none = equal sets as --batch decides")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per set of launches, and per collective with several GPUs (0 = automatic: up to 5 on one GPU, up to 16 with several, the timed steps split into equal groups; 1 = one frame per set of launches)")
+    ap.add_argument("--sets", default="auto",
+                    help="several GPUs, --shard tilerows: sizes of the sets of frames the timed steps are issued in, e.g. 8,8,4 (sum = --steps; each 1..32); "
+                         "auto = what --batch decides (equal sets), tapered at the end when the run is long enough (see main)")
+    ap.add_argument("--wire", choices=["auto", "rgb24", "rgba32"], default="auto",
+                    help="several GPUs, --shard tilerows: a share's pixels on the link as 3 bytes (0x00RRGGBB without its zero byte; default where the width is a multiple of 4) or as they are")
+    ap.add_argument("--no-leg-4k", dest="leg_4k", action="store_false",
+                    help="several GPUs: skip the second leg (BASELINE configs[3]: the same scene at 3840x2160 split over the ranks, reported under extras.leg_3840x2160)")
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="diagnostic, one GPU: do per frame what rank 0 of an N-GPU run does (its share of the frame, extraction, assembly) without the collective")
     ap.add_argument("--no-shadow", action="store_true")
@@ -522,7 +529,23 @@ def main():
         # (K = 20 -> 2 groups of 10, not 16 + 4)
         n_groups = max(nfl, -(-a.steps // 16))
         B = max(1, min(32, a.batch if a.batch > 0 else -(-a.steps // n_groups)))
-        ig = sharding.InterleavedGather(H, W, rank, world, dev, slots=n_frames, collective=not rehearse, batch=B, single_rank_collective=a.one_rank_group)
+        if a.sets != "auto":
+            set_sizes = [int(x) for x in a.sets.split(",")]
+            if sum(set_sizes) != a.steps or min(set_sizes) < 1 or max(set_sizes) > 32:
+                raise SystemExit("bench.py: --sets must list set sizes of 1..32 frames that add up to --steps")
+            B = max(set_sizes)
+        elif a.batch <= 0 and a.steps >= 2 * world and world > 1:
+            # The last set's gather is what the end of the run exposes (every earlier one travels while the next set is traced), and a
+            # rank's share of a frame is 1/N of it: a last set of N frames puts ONE frame's bytes on each link -- 6.2 MB at 1080p, the same
+            # for every N -- and the steps before it go out in equal sets of at most 16.  20 steps: N = 8 -> 12 + 8, N = 4 -> 16 + 4,
+            # N = 2 -> 9 + 9 + 2.  Rehearsed (rank 0's pipeline without the network, profiles/r05_e_multi_gpu_schedules.txt): these cost
+            # the traversal 0..2 % against two equal sets; three and more sets at N = 8 cost 10 % and more.
+            head = a.steps - world
+            n_head = -(-head // 16)
+            per = -(-head // n_head)
+            set_sizes = [min(per, head - g) for g in range(0, head, per)] + [world]
+            B = max(set_sizes)
+        ig = sharding.InterleavedGather(H, W, rank, world, dev, slots=n_frames, collective=not rehearse, batch=B, single_rank_collective=a.one_rank_group, wire=a.wire)
         frames = [ig.new_frame_buffer(dev) for _ in range(n_frames)]
     elif not multi and a.batch != 1 and nfl > 1:
         # One GPU: whole frames in groups of up to 5 per set of launches (the same entry point with one rank).  Each wavefront then
@@ -640,19 +663,42 @@ def main():
         launch(buf, st=st, k=k, slot=b)
         if ev is not None:
             ev[1].record(st)
-        if multi and not no_gather:
-            # image assembly overlaps the next step's traversal: the gather runs on its own stream
-            gather_stream.wait_stream(st)
+        if not (multi and not no_gather):
+            return None
+        done = torch.cuda.Event()
+        done.record(st)
+
+        def assemble():
+            # image assembly overlaps the next set's traversal: the gather runs on its own stream, behind this set's launches
+            gather_stream.wait_event(done)
             with torch.cuda.stream(gather_stream):
                 if bands:
                     bg.gather(b, k)
                 elif a.shard == "tilerows":
-                    ig.gather(buf, b, via_cpu=(cdev == "cpu"))
+                    ig.gather(buf, b, via_cpu=(cdev == "cpu"), k=(k if B > 1 else None))
                 else:
                     band = buf[y0:y1]
                     sharding.gather_frame(band if cdev != "cpu" else band.cpu(), H, W, rank, world)
                 gdone[b] = torch.cuda.Event()
                 gdone[b].record(gather_stream)
+        return assemble
+
+    def issue(seq, evs_=None, marks=None):
+        """Issues the launch groups seq = [(i, k), ...] in order.  A group's image assembly (packing, collective, unpacking: a dozen calls
+        on the host) is enqueued only after the NEXT group's launches are out (with nfl streams: after the next nfl - 1 groups'), so that
+        the sets that are to run side by side are on the device within microseconds of each other instead of a host call sequence apart
+        (the first set used to have the machine's half to itself for 0.16 ms of a 1.2 ms run)."""
+        pend = []
+        for n, (i, k) in enumerate(seq):
+            fin = step(i, evs_[n] if evs_ else None, k=k)
+            if fin is not None:
+                pend.append(fin)
+            if marks is not None:
+                marks.append(time.perf_counter())
+            while len(pend) >= max(1, nfl):
+                pend.pop(0)()
+        for fin in pend:
+            fin()
 
     # isolated duration of one step's launches (nothing else on the GPU): HIP events on the launch stream
     iso = []
@@ -666,30 +712,33 @@ def main():
     iso_ms = sum(iso) / len(iso)
     def groups(n):     # n steps as launch groups of at most B
         return [min(B, n - g) for g in range(0, n, B)]
-    timed_groups = list(set_sizes) if bands else groups(a.steps)
+    timed_groups = list(set_sizes) if set_sizes else groups(a.steps)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in timed_groups]
     # The GPU raises its clocks over the first tens of milliseconds of sustained load (measured: the frame period of a 20-step
     # run shrinks from 0.52 to 0.49 ms between its first and last step).  A short run would time that ramp, not the path, so the
     # clocks are brought to their sustained state first with untimed frames of the same kind; then the W warmup steps, which run as
     # the timed ones do (same streams, same frames in flight) and directly before them.
     settled = a.settle_frames
-    if bands:
+    # (every stream of the timed region carries work before the region opens: a stream's hardware queue is created at its first use, 5 ms
+    # that a run whose schedule leaves a stream idle until the closing wait_stream would otherwise time)
+    for st_ in streams + ([gather_stream] if multi else []):
+        torch.cuda.Event().record(st_)
+    if set_sizes:
         # the settle phase repeats the timed region's own sequence of sets on the same streams and buffers (a frame context learns
         # its longest-tile-first order per set size from its previous set of that size), then the W warmup steps as a prefix of it
         settled = 0
         while settled < a.settle_frames:
-            for j, k in enumerate(timed_groups):
-                step(j, k=k)
+            issue(list(enumerate(timed_groups)))
             settled += sum(timed_groups)
-        left = a.warmup
+        left, wseq = a.warmup, []
         for j, k in enumerate(timed_groups):
             if left <= 0:
                 break
-            step(j, k=min(k, left))
+            wseq.append((j, min(k, left)))
             left -= min(k, left)
+        issue(wseq)
     else:
-        for i, k in enumerate(groups(a.settle_frames) + groups(a.warmup)):
-            step(i, k=k)
+        issue(list(enumerate(groups(a.settle_frames) + groups(a.warmup))))
     # every frame rendered before the timed region opens (one for the ray count, two counting builds, the isolated launches,
     # the band-planning sets, the clock-settling frames, the W warmup steps): none of them is timed, none of their results is reused
     frames_before = 1 + (2 if world == 1 else (1 if rank == 0 else 0)) + len(iso) + settled + a.warmup + (band_plan["rounds"] * 16 * (world if rehearse else 1) if band_plan else 0)
@@ -702,8 +751,9 @@ def main():
         probe.launch(0, sptr)          # (untimed: behind the warmup steps, before the region's opening synchronisation)
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i, k in enumerate(timed_groups):
-        step(i, evs[i], k=k)
+    host_marks = []
+    issue(list(enumerate(timed_groups)), evs, host_marks)
+    host_marks = [m - t0 for m in host_marks]
     # end of the timed region on the GPU's clock: an event on the first stream behind every stream of the region
     for st_ in streams[1:] + ([gather_stream] if multi else []):
         stream.wait_stream(st_)
@@ -737,7 +787,8 @@ def main():
     span_ms = evs[0][0].elapsed_time(end_ev)
     kern_ms = span_ms / a.steps
     if os.environ.get("VXRT_BENCH_TRACE") and rank == 0:   # start offset of every timed step on the GPU's clock (debugging the timed region itself)
-        print("step starts (ms):", " ".join("%.3f" % evs[0][0].elapsed_time(e0) for e0, _ in evs), "end %.3f" % span_ms, "host %.3f" % (elapsed * 1e3), "issued %.3f" % (t_issued * 1e3), file=sys.stderr)
+        print("step starts (ms):", " ".join("%.3f" % evs[0][0].elapsed_time(e0) for e0, _ in evs), "end %.3f" % span_ms, "host %.3f" % (elapsed * 1e3), "issued %.3f" % (t_issued * 1e3),
+              "host time after each step's calls returned (ms): " + " ".join("%.3f" % (m * 1e3) for m in host_marks), file=sys.stderr)
 
     extras = {}
     random_sample = None
@@ -790,6 +841,58 @@ def main():
                                      "node_fetches": rstats["node_fetches"], "tri_fetches": rstats["tri_fetches"]}
         del rays, hits
 
+    if multi and a.shard == "tilerows" and a.leg_4k and (W, H, a.level) == (1920, 1080, 8) and B > 1:
+        # BASELINE configs[3], the workload it names for 8 GPUs: the same scene at 3840x2160, the framebuffer's tile rows interleaved over
+        # the ranks, one gather per set -- a second leg of the N > 1 line, through the very machinery of the first (the closures above see
+        # the rebound frame size, buffers and assembly).  2 N timed frames as two sets, the last one N / 4 frames (one 1080p frame's bytes
+        # per link), behind a settle phase of its own; value = the whole frame's rays x frames / max-over-ranks time.
+        main_leg = (W, H, ig, frames, gdone, B, frame_stride)
+        try:
+            W, H = 3840, 2160
+            last4 = max(1, world // 4)              # a 3840x2160 frame is four 1080p frames: N / 4 of them put one 1080p frame's bytes on each link
+            B = max(1, min(16, 2 * world - last4))
+            ig = sharding.InterleavedGather(H, W, rank, world, dev, slots=4, collective=not rehearse, batch=B, single_rank_collective=a.one_rank_group, wire=a.wire)
+            frames = [ig.new_frame_buffer(dev) for _ in range(4)]
+            gdone = [None] * len(frames)
+            frame_stride = ig.frame_stride
+            cnt4 = torch.zeros(1, dtype=torch.int64, device=dev)
+            rtapi.render_interleaved(ds.accel, W, H, rank, world, params, frames[0].data_ptr(), shadow, None, None, cnt4.data_ptr(), sptr)
+            torch.cuda.synchronize()
+            rays4 = int(cnt4.item())
+            seq = [(0, B), (1, last4)] if B > 1 else [(0, 1), (1, 1)]
+            for _ in range(4):                      # settle: the leg's own sequence (tile orders are learned per set size and window)
+                issue(seq)
+            torch.cuda.synchronize()
+            if grouped:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            issue(seq)
+            for st_ in streams[1:] + [gather_stream]:
+                stream.wait_stream(st_)
+            torch.cuda.synchronize()
+            if grouped:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el4 = time.perf_counter() - t4
+            if grouped:
+                t = torch.tensor([el4], dtype=torch.float64, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el4 = float(t.item())
+                r = torch.tensor([rays4], dtype=torch.int64, device=cdev)
+                dist.all_reduce(r, op=dist.ReduceOp.SUM)
+                rays4 = int(r.item())
+            assert rtapi.status(sptr) == 0
+            extras["leg_3840x2160"] = {"config": "configs[3]: Sponza-class, 3840x2160, primary + 1 shadow ray, tile rows interleaved over %d ranks" % world,
+                                       "steps": sum(k for _, k in seq), "sets": [k for _, k in seq], "ms_per_step": round(el4 / sum(k for _, k in seq) * 1e3, 4),
+                                       "rays_per_step" + ("_rank0" if rehearse else ""): rays4,
+                                       "mrays_s" + ("_rank0_share_only" if rehearse else ""): round(rays4 * sum(k for _, k in seq) / el4 / 1e6, 1),
+                                       "wire_bytes_per_rank_last_set": ig.wire_bytes(seq[-1][1]), "wire_format": ig.wire}
+        except Exception as e:      # (a failed side leg never takes the bench line with it)
+            extras["leg_3840x2160"] = {"error": repr(e)[:300]}
+        finally:
+            W, H, ig, frames, gdone, B, frame_stride = main_leg
+
     if world == 1 and a.other_configs != "none" and (W, H, a.level) == (1920, 1080, 8):
         import subprocess
         try:
@@ -830,6 +933,9 @@ def main():
             out["config"].update({"shard": "bands", "sets_of_the_timed_steps": timed_groups, "band_plan": band_plan, "rows_rank0": [y0, y1]})
         elif multi:
             out["config"]["shard"] = a.shard
+            if ig is not None:
+                out["config"].update({"sets_of_the_timed_steps": timed_groups, "wire_format": ig.wire,
+                                      "wire_bytes_per_rank_last_set": ig.wire_bytes(timed_groups[-1])})
         prof = load_profile_constants()
         # one step = the launches of vxrt_render: persistent traversal kernel (dominant, > 93 % of the step), the EXACT launches
         # for the rays with NaN-capable slabs, and the shading pass; priced together

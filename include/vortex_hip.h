@@ -279,6 +279,20 @@ int vxrt_render_interleaved_batch_wave_log(vxrt_accel_t* accel, uint32_t width, 
                                            const vxrt_shade_params_t* params, int shadow, uint32_t* dst, uint64_t dst_frame_stride,
                                            unsigned long long* counters, unsigned long long* wave_log, void* stream);
 
+/* Image assembly of a frame split by interleaved tile rows (north_star: "RCCL gather only for final image assembly"), the two ends of
+ * the wire.  Pixels are 0x00RRGGBB (common.h:149-154): the top byte is always zero, so a share travels as 3 bytes per pixel.
+ *   vxrt_wire_pack    rank `rank` of `world`: the tile rows rank, rank + world, ... (tile_rows_per_rank of them, 8 rows each; rows
+ *                     past the frame's end are whatever the padded frame buffer holds) of n_frames frames -- frame f at
+ *                     frames + f * frame_stride, `width` pixels per row -- packed into `wire`:
+ *                     [n_frames][tile_rows_per_rank * 8][width][3] bytes (b, g, r).  width must be a multiple of 4.
+ *   vxrt_wire_unpack  rank 0: the `world` shares, rank r's at wire_all + r * wire_stride_bytes, expanded and interleaved into
+ *                     n_frames frames of tile_rows_per_rank * world * 8 rows (the padded height the shares were rendered into).
+ * One launch each, asynchronous on `stream`; they replace a strided extraction copy and an interleaving copy of 4-byte pixels. */
+int vxrt_wire_pack(const uint32_t* frames, uint64_t frame_stride, uint32_t width, uint32_t tile_rows_per_rank, uint32_t world, uint32_t rank,
+                   uint32_t n_frames, uint8_t* wire, void* stream);
+int vxrt_wire_unpack(const uint8_t* wire_all, uint64_t wire_stride_bytes, uint32_t width, uint32_t tile_rows_per_rank, uint32_t world,
+                     uint32_t n_frames, uint32_t* frames, uint64_t frame_stride, void* stream);
+
 /* The same for a contiguous band of rows [y0, y1) (0 <= y0 <= y1 <= height; any row, tiles are counted from y0): what a rank
  * renders when the frame is split into bands whose heights are balanced by cost (bench.py --shard bands).  dst addresses every
  * frame as a FULL frame does -- pixel (x, y) of frame f at dst[f * dst_frame_stride + x + y * width] -- and only rows [y0, y1)

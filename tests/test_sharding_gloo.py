@@ -48,26 +48,33 @@ def test_interleaved_tile_rows_partition_the_frame_and_reassemble():
         parts = [sh.extract_interleaved(f, h, r, world) for r in range(world)]
         assert all(p.shape == (sh.padded_share_rows(h, world), w) for p in parts)
         assert torch.equal(sh.assemble_interleaved(parts, h, w, world), f)
-        # the per-frame path of bench.py: padded frame buffers, one strided copy per rank, one interleaving copy on rank 0
-        igs = [sh.InterleavedGather(h, w, r, world, "cpu", slots=1, collective=False) for r in range(world)]
-        assert igs[0].padded_height == sh.padded_share_rows(h, world) * world and igs[0].padded_height >= h
-        fp = igs[0].new_frame_buffer("cpu")
-        fp[:h] = f
-        for r in range(world):
-            igs[r].gather(fp, 0)
-            assert torch.equal(igs[r].shares[0][0], parts[r])
-            igs[0].recv[0][r].copy_(igs[r].shares[0])
-        assert torch.equal(igs[0].assemble(0), f)
-        # a batch of frames moves with the same three copies
-        igb = [sh.InterleavedGather(h, w, r, world, "cpu", slots=1, collective=False, batch=3) for r in range(world)]
-        fb = igb[0].new_frame_buffer("cpu")
-        for k in range(3):
-            fb[k, :h] = f + 1000 * k
-        for r in range(world):
-            igb[r].gather(fb, 0)
-            igb[0].recv[0][r].copy_(igb[r].shares[0])
-        got = igb[0].assemble(0)
-        assert got.shape == (3, h, w) and all(torch.equal(got[k], f + 1000 * k) for k in range(3))
+        # the per-frame path of bench.py: padded frame buffers, one packing step per rank, one unpacking step on rank 0 -- in both wire
+        # formats (4-byte pixels as they are; 3 bytes per pixel, the top byte of 0x00RRGGBB being zero)
+        for wire in ("rgba32", "rgb24"):
+            igs = [sh.InterleavedGather(h, w, r, world, "cpu", slots=1, collective=False, wire=wire) for r in range(world)]
+            assert igs[0].padded_height == sh.padded_share_rows(h, world) * world and igs[0].padded_height >= h
+            assert igs[0].wire_bytes() == sh.padded_share_rows(h, world) * w * (4 if wire == "rgba32" else 3)
+            fp = igs[0].new_frame_buffer("cpu")
+            f2 = f + 0x00A50000                         # (a colour in every byte of the 24 that travel)
+            fp[:h] = f2
+            for r in range(world):
+                igs[r].gather(fp, 0)
+                if wire == "rgba32":
+                    assert torch.equal(igs[r].shares[0][0], sh.extract_interleaved(f2, h, r, world))
+                igs[0].recv[0][r].copy_(igs[r].shares[0])
+            assert torch.equal(igs[0].assemble(0), f2)
+            # sets of frames move with the same steps, and a set may be smaller than the slot (the tapered last sets of a run)
+            igb = [sh.InterleavedGather(h, w, r, world, "cpu", slots=1, collective=False, batch=3, wire=wire) for r in range(world)]
+            fb = igb[0].new_frame_buffer("cpu")
+            for k in range(3):
+                fb[k, :h] = f + 1000 * k
+            for nk in (3, 2, 1):
+                for r in range(world):
+                    igb[r].gather(fb, 0, k=nk)
+                    igb[0].recv[0][r].copy_(igb[r].shares[0])
+                got = igb[0].assemble(0, nk)
+                assert got.shape == (nk, h, w) and all(torch.equal(got[k], f + 1000 * k) for k in range(nk))
+    assert sh.InterleavedGather(16, 8, 0, 2, "cpu").wire == "rgb24" and sh.InterleavedGather(16, 6, 0, 2, "cpu").wire == "rgba32"
     # balance: at 1080p over 8 ranks every rank gets 16 or 17 of the 135 tile rows
     n = [len(sh.interleaved_tile_rows(1080, r, 8)) for r in range(8)]
     assert max(n) - min(n) <= 1 and sum(n) == 135
@@ -170,6 +177,10 @@ def _worker(rank, world, port, mode, use_hip, q):
         frame = ig.gather(fb, 0)
         if frame is not None:
             frame = frame.clone()
+        # a smaller set in the same slot (the tapered last sets of a run): its frames only
+        part = ig.gather(fb, 0, k=2)
+        if part is not None:
+            assert part.shape[0] == 2 and torch.equal(part, frame[:2])
     elif mode == "bands_batch":           # bench.py's default with several ranks: unequal bands, received in place, 3 frames per set
         bounds = [0, 2 * h // 3 // 8 * 8, h]
         bg = sh.BandGather(h, w, rank, world, bounds, dev if use_hip else "cpu", [3], via_cpu=True)
@@ -328,4 +339,35 @@ def test_bench_two_ranks_end_to_end(shard):
         assert plan["bounds"][0] == 0 and plan["bounds"][-1] == 1080 and len(plan["bounds"]) == 3 and plan["rounds"] >= 1
         assert d["config"]["sets_of_the_timed_steps"] == [3, 2, 1] and "bands" in d["config"]["parallelism"]
     else:
-        assert d["config"]["frames_per_launch_group"] == 3 and "interleaved" in d["config"]["parallelism"]
+        # 6 steps on 2 ranks: a last set of 2 frames (one frame's bytes per link), the 4 steps before it as one set; 3 bytes per pixel on the wire
+        assert d["config"]["sets_of_the_timed_steps"] == [4, 2] and d["config"]["frames_per_launch_group"] == 4 and "interleaved" in d["config"]["parallelism"]
+        assert d["config"]["wire_format"] == "rgb24" and d["config"]["wire_bytes_per_rank_last_set"] == 2 * 544 * 1920 * 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,world,nk", [(1080, 1920, 8, 3), (1076, 328, 3, 2), (45, 16, 4, 1), (2160, 3840, 8, 1)])
+def test_wire_kernels_pack_and_unpack_what_the_host_path_does(h, w, world, nk):
+    """vxrt_wire_pack / vxrt_wire_unpack (3 bytes per pixel on the link) against the same layout made with torch indexing on host
+    tensors: every rank's wire bytes equal, and the frames rank 0 assembles equal the frames the shares were cut from."""
+    sh = _sharding()
+    g = torch.Generator().manual_seed(h * 31 + w)
+    batch = 3
+    host = [sh.InterleavedGather(h, w, r, world, "cpu", slots=1, collective=False, batch=batch, wire="rgb24") for r in range(world)]
+    dev = [sh.InterleavedGather(h, w, r, world, "cuda:0", slots=1, collective=False, batch=batch, wire="rgb24") for r in range(world)]
+    fb = host[0].new_frame_buffer("cpu")
+    fb[:, :h] = torch.randint(0, 1 << 24, (batch, h, w), generator=g, dtype=torch.int32)      # 0x00RRGGBB
+    fbd = fb.cuda()
+    for r in range(world):
+        host[r].gather(fb, 0, k=nk)
+        dev[r].gather(fbd, 0, k=nk)
+        torch.cuda.synchronize()
+        assert torch.equal(dev[r].shares[0][:nk].cpu(), host[r].shares[0][:nk])
+        host[0].recv[0][r].copy_(host[r].shares[0])
+        dev[0].recv[0][r].copy_(dev[r].shares[0])
+    want = fb[:nk, :h]
+    assert torch.equal(host[0].assemble(0, nk), want)
+    got = dev[0].assemble(0, nk)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), want)
+    # the rows of the padded height that no frame has stay zero (byte 3 of every pixel too)
+    assert int(dev[0].full[0].view(batch, dev[0].padded_height, w)[:nk, h:].abs().sum().item()) == 0

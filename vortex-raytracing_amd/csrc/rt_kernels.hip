@@ -1884,6 +1884,44 @@ __global__ void set_batch_params_kernel(ShadeBatch b, uint32_t n, ShadeParams* _
   if (threadIdx.x < n) dst[threadIdx.x] = b.p[threadIdx.x];
 }
 
+// Image assembly of a frame split by interleaved tile rows (vxrt_wire_pack / vxrt_wire_unpack in the header): 0x00RRGGBB pixels as 3 bytes on
+// the wire.  One thread per 4 pixels = 16 bytes in, 12 bytes out (three aligned words), rows of the share contiguous on the wire.
+__global__ __launch_bounds__(256) void wire_pack_kernel(const uint32_t* __restrict__ frames, uint64_t frame_stride, uint32_t W4, uint32_t per, uint32_t world, uint32_t rank,
+                                                        uint64_t n_quads, uint32_t* __restrict__ wire) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= n_quads) return;
+  const uint32_t xq = (uint32_t)(t % W4);
+  const uint64_t row = t / W4;                       // row of the wire: frame * per * 8 + j * 8 + y
+  const uint32_t rows_per_frame = per * 8u;
+  const uint32_t f = (uint32_t)(row / rows_per_frame), lr = (uint32_t)(row - (uint64_t)f * rows_per_frame);
+  const uint32_t j = lr >> 3, y = lr & 7u;
+  const uint4 p = *(const uint4*)(frames + (size_t)f * frame_stride + ((size_t)(j * world + rank) * 8u + y) * (W4 * 4u) + (size_t)xq * 4u);
+  uint32_t* o = wire + t * 3u;
+  o[0] = (p.x & 0xFFFFFFu) | (p.y << 24);
+  o[1] = ((p.y >> 8) & 0xFFFFu) | (p.z << 16);
+  o[2] = ((p.z >> 16) & 0xFFu) | (p.w << 8);
+}
+__global__ __launch_bounds__(256) void wire_unpack_kernel(const uint32_t* __restrict__ wire_all, uint64_t wire_stride_words, uint32_t W4, uint32_t per, uint32_t world,
+                                                          uint64_t quads_per_rank, uint32_t* __restrict__ frames, uint64_t frame_stride) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= quads_per_rank * world) return;
+  const uint32_t r = (uint32_t)(t / quads_per_rank);
+  const uint64_t q = t - (uint64_t)r * quads_per_rank;
+  const uint32_t xq = (uint32_t)(q % W4);
+  const uint64_t row = q / W4;
+  const uint32_t rows_per_frame = per * 8u;
+  const uint32_t f = (uint32_t)(row / rows_per_frame), lr = (uint32_t)(row - (uint64_t)f * rows_per_frame);
+  const uint32_t j = lr >> 3, y = lr & 7u;
+  const uint32_t* w = wire_all + (size_t)r * wire_stride_words + q * 3u;
+  const uint32_t a = w[0], b = w[1], c = w[2];
+  uint4 p;
+  p.x = a & 0xFFFFFFu;
+  p.y = (a >> 24) | ((b & 0xFFFFu) << 8);
+  p.z = (b >> 16) | ((c & 0xFFu) << 16);
+  p.w = c >> 8;
+  *(uint4*)(frames + (size_t)f * frame_stride + ((size_t)(j * world + r) * 8u + y) * (W4 * 4u) + (size_t)xq * 4u) = p;
+}
+
 __global__ void add_counter_kernel(unsigned long long* c, unsigned long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(c, v); }
 
 // ---------------------------------------------------------------------------------------------
@@ -3117,6 +3155,29 @@ int vxrt_shade_rays(vxrt_accel_t* a, const float* rays, const vxrt_hit_t* hits, 
 // the constant 100 MHz clock at its end and its ray count | physical XCD << 56 in `log` (device memory, 2 u64 per wavefront, room for 8,192
 // wavefronts: 16 x 8,192 u64; the caller zeroes it between the launches it wants to tell apart, and keeps it alive until they have run); nullptr
 // switches it off again.  The EXACT launches do not write.  Costs the timed kernel one store per wavefront at its end.
+int vxrt_wire_pack(const uint32_t* frames, uint64_t frame_stride, uint32_t width, uint32_t per, uint32_t world, uint32_t rank, uint32_t n_frames,
+                   uint8_t* wire, void* stream) {
+  if (!frames || !wire || width == 0 || (width & 3u) != 0 || per == 0 || world == 0 || rank >= world || n_frames == 0) return -1;
+  if (((uintptr_t)frames & 15u) != 0 || ((uintptr_t)wire & 3u) != 0 || (frame_stride & 3u) != 0) return -1;   // (16-byte pixel quads, word stores)
+  const uint64_t n = (uint64_t)n_frames * per * 8u * (width / 4u);
+  if (n > 0xFFFFFFFFull * 256ull) return -1;
+  hipLaunchKernelGGL(wire_pack_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames, frame_stride, width / 4u, per, world, rank, n, (uint32_t*)wire);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int vxrt_wire_unpack(const uint8_t* wire_all, uint64_t wire_stride_bytes, uint32_t width, uint32_t per, uint32_t world, uint32_t n_frames,
+                     uint32_t* frames, uint64_t frame_stride, void* stream) {
+  if (!frames || !wire_all || width == 0 || (width & 3u) != 0 || per == 0 || world == 0 || n_frames == 0) return -1;
+  if (((uintptr_t)frames & 15u) != 0 || ((uintptr_t)wire_all & 3u) != 0 || (frame_stride & 3u) != 0 || (wire_stride_bytes & 3u) != 0) return -1;
+  const uint64_t per_rank = (uint64_t)n_frames * per * 8u * (width / 4u);
+  if (wire_stride_bytes < per_rank * 12u) return -1;
+  const uint64_t n = per_rank * world;
+  if (n > 0xFFFFFFFFull * 256ull) return -1;
+  hipLaunchKernelGGL(wire_unpack_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)wire_all, wire_stride_bytes / 4u, width / 4u, per, world,
+                     per_rank, frames, frame_stride);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int vxrt_debug_end_log(vxrt_accel_t* a, unsigned long long* log) {
   if (!a) return -1;
   a->end_log = log;   // (captured by the launches enqueued from now on; launches already enqueued keep what they were given)

@@ -216,6 +216,22 @@ def rc_accel_build(scene, stream=None):
     return h
 
 
+def wire_pack(frames_ptr, frame_stride, width, tile_rows_per_rank, world, rank, n_frames, wire_ptr, stream=None):
+    """vxrt_wire_pack: this rank's interleaved tile rows of n_frames frames as 3 bytes per pixel."""
+    L = _lib()
+    L.vxrt_wire_pack.restype = C.c_int
+    L.vxrt_wire_pack.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    check(L.vxrt_wire_pack(frames_ptr, frame_stride, width, tile_rows_per_rank, world, rank, n_frames, wire_ptr, stream), "vxrt_wire_pack")
+
+
+def wire_unpack(wire_all_ptr, wire_stride_bytes, width, tile_rows_per_rank, world, n_frames, frames_ptr, frame_stride, stream=None):
+    """vxrt_wire_unpack: the `world` shares expanded and interleaved into n_frames frames of padded height."""
+    L = _lib()
+    L.vxrt_wire_unpack.restype = C.c_int
+    L.vxrt_wire_unpack.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    check(L.vxrt_wire_unpack(wire_all_ptr, wire_stride_bytes, width, tile_rows_per_rank, world, n_frames, frames_ptr, frame_stride, stream), "vxrt_wire_unpack")
+
+
 def accel_info(accel, which):
     """vxrt_accel_info: 0 -> internal levels of the deepest path (counted up to 17), 1 -> 48-entry stacks (depth class <= 16),
     2 -> single identity instance under the TLAS root, 3 -> ldexp decode."""

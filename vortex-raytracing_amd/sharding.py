@@ -110,16 +110,21 @@ def gather_frame(band, height, width, rank, world, group=None):
 
 
 class InterleavedGather:
-    """The per-frame image assembly of an N-rank run with everything that can be prepared once prepared once: frames are rendered
-    into buffers of padded height (padded_share_rows * world rows, so that a rank's share is ONE strided slice whatever
-    height % (8 * world) is), the share, the receive buffers and the assembled frame are preallocated per slot, and a frame costs
-    one strided copy on every rank + one gather + one interleaving copy on rank 0 -- three launches, not one per tile row
-    (1080 rows = 135 tile rows divide by no N > 1: the tile-row loop of extract/assemble_interleaved was the whole frame time).
-    batch > 1: a slot holds `batch` frames ([batch, padded_height, width], what vxrt_render_interleaved_batch fills) and the same
-    three launches move all of them."""
+    """The image assembly of an N-rank run with everything that can be prepared once prepared once: frames are rendered into buffers
+    of padded height (padded_share_rows * world rows, so that a rank's share is ONE strided slice whatever height % (8 * world) is),
+    the share, the receive buffers and the assembled frames are preallocated per slot, and a set of frames costs one packing launch
+    on every rank + one gather + one unpacking launch on rank 0 (1080 rows = 135 tile rows divide by no N > 1: a loop over tile
+    rows was the whole frame time).  batch > 1: a slot holds up to `batch` frames ([batch, padded_height, width], what
+    vxrt_render_interleaved_batch fills); gather(..., k) moves the first k of them -- the sets of a run need not be equally large
+    (bench.py tapers the last sets so that what nothing overlaps any more, the last set's gather, is small).
+
+    wire = "rgb24" (default where the width is a multiple of 4): a share travels as 3 bytes per pixel -- pixels are 0x00RRGGBB
+    (common.h:149-154), the top byte is always zero -- packed and expanded by vxrt_wire_pack / vxrt_wire_unpack (HIP; on CPU tensors,
+    the 2-rank gloo tests, the same layout through torch indexing): a quarter less on the link, which is what the last set's gather
+    leaves exposed.  wire = "rgba32": the 4-byte pixels as they are, strided torch copies (round 4's path)."""
 
     def __init__(self, height, width, rank, world, device, slots=2, dtype=None, group=None, collective=True, batch=1,
-                 single_rank_collective=False):
+                 single_rank_collective=False, wire="auto"):
         import torch
         self.h, self.w, self.rank, self.world, self.group, self.batch = height, width, rank, world, group, batch
         self.per = padded_share_rows(height, world) // TILE        # tile rows per rank, padded
@@ -128,10 +133,21 @@ class InterleavedGather:
         # True: a group of ONE rank still goes through dist.gather (the RCCL call of the N-rank run, exercised on a 1-GPU box)
         self.single_rank_collective = single_rank_collective
         self.dtype = dtype or torch.int32
-        self.shares = [torch.zeros((batch, self.per * TILE, width), dtype=self.dtype, device=device) for _ in range(slots)]
+        if wire == "auto":
+            wire = "rgb24" if (width % 4 == 0 and self.dtype == torch.int32) else "rgba32"
+        if wire not in ("rgb24", "rgba32") or (wire == "rgb24" and (width % 4 != 0 or self.dtype != torch.int32)):
+            raise ValueError("wire format %r needs int32 pixels and a width that is a multiple of 4" % (wire,))
+        self.wire = wire
+        self.device = device
+        rows = self.per * TILE
+        if wire == "rgb24":
+            self.shares = [torch.zeros((batch, rows, width, 3), dtype=torch.uint8, device=device) for _ in range(slots)]
+        else:
+            self.shares = [torch.zeros((batch, rows, width), dtype=self.dtype, device=device) for _ in range(slots)]
         self.recv = self.full = None
         if rank == 0:
-            self.recv = [[torch.zeros((batch, self.per * TILE, width), dtype=self.dtype, device=device) for _ in range(world)] for _ in range(slots)]
+            # one tensor per slot, rank-major, frame-major inside a rank's part for EVERY set size k: the k frames of rank r are recv[slot][r][:k]
+            self.recv = [torch.zeros((world,) + tuple(self.shares[0].shape), dtype=self.shares[0].dtype, device=device) for _ in range(slots)]
             self.full = [torch.zeros((batch, self.per, world, TILE, width), dtype=self.dtype, device=device) for _ in range(slots)]
 
     def new_frame_buffer(self, device):
@@ -145,33 +161,71 @@ class InterleavedGather:
         """Pixels between two frames of a batch buffer (dst_frame_stride of vxrt_render_interleaved_batch)."""
         return self.padded_height * self.w
 
-    def gather(self, frame, slot, via_cpu=False):
-        """frame: buffer from new_frame_buffer this rank rendered its tile rows into.  Returns the assembled frame(s) on rank 0
-        ([height, width] or [batch, height, width], views of a per-slot buffer), None elsewhere."""
+    def wire_bytes(self, k=None):
+        """Bytes one rank puts on the link for a set of k frames."""
+        k = self.batch if k is None else k
+        return k * self.per * TILE * self.w * (3 if self.wire == "rgb24" else 4)
+
+    # -- the two ends of the wire ------------------------------------------------------------------------------------------
+    def _pack(self, frame, share, k):
+        import torch
+        fr = frame.view(self.batch, self.padded_height, self.w)
+        if self.wire == "rgb24":
+            if frame.is_cuda:
+                from . import rtapi
+                rtapi.wire_pack(fr.data_ptr(), self.frame_stride, self.w, self.per, self.world, self.rank, k, share.data_ptr(),
+                                torch.cuda.current_stream(frame.device).cuda_stream)
+            else:   # host tensors (gloo tests): the same bytes through torch indexing
+                src = fr[:k].view(k, self.per, self.world, TILE, self.w)[:, :, self.rank].contiguous()
+                share[:k].view(k, self.per, TILE, self.w, 3).copy_(src.view(torch.uint8).view(k, self.per, TILE, self.w, 4)[..., :3])
+        else:
+            share[:k].view(k, self.per, TILE, self.w).copy_(fr[:k].view(k, self.per, self.world, TILE, self.w)[:, :, self.rank])
+
+    def _unpack(self, slot, k):
+        import torch
+        recv, full = self.recv[slot], self.full[slot]
+        if self.wire == "rgb24":
+            if recv.is_cuda:
+                from . import rtapi
+                rtapi.wire_unpack(recv.data_ptr(), recv.stride(0), self.w, self.per, self.world, k, full.data_ptr(), self.frame_stride,
+                                  torch.cuda.current_stream(recv.device).cuda_stream)
+            else:
+                out = full[:k].view(torch.uint8).view(k, self.per, self.world, TILE, self.w, 4)
+                out[..., :3] = recv[:, :k].view(self.world, k, self.per, TILE, self.w, 3).permute(1, 2, 0, 3, 4, 5)
+                out[..., 3] = 0
+        else:
+            torch.stack([recv[r, :k].view(k, self.per, TILE, self.w) for r in range(self.world)], dim=2, out=full[:k])
+
+    def gather(self, frame, slot, via_cpu=False, k=None):
+        """frame: buffer from new_frame_buffer this rank rendered its tile rows of the first k frames into (k = batch by default).  Returns
+        the assembled frame(s) on rank 0 ([height, width] for batch 1, else [k, height, width]: views of a per-slot buffer), None elsewhere."""
         import torch
         import torch.distributed as dist
+        k = self.batch if k is None else int(k)
+        if not 1 <= k <= self.batch:
+            raise ValueError("a set of %d frames in a slot of %d" % (k, self.batch))
         share = self.shares[slot]
-        share.view(self.batch, self.per, TILE, self.w).copy_(frame.view(self.batch, self.per, self.world, TILE, self.w)[:, :, self.rank])
+        self._pack(frame, share, k)
         if self.collective and (self.world > 1 or self.single_rank_collective):
             if via_cpu:     # gloo rehearsal: collectives on host tensors
-                out = [torch.empty_like(share, device="cpu") for _ in range(self.world)] if self.rank == 0 else None
-                dist.gather(share.cpu(), out, dst=0, group=self.group)
+                out = [torch.empty_like(share[:k], device="cpu") for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(share[:k].cpu(), out, dst=0, group=self.group)
                 if self.rank == 0:
                     for r in range(self.world):
-                        self.recv[slot][r].copy_(out[r])
+                        self.recv[slot][r, :k].copy_(out[r])
             else:
-                dist.gather(share, self.recv[slot] if self.rank == 0 else None, dst=0, group=self.group)
+                dist.gather(share[:k], [self.recv[slot][r, :k] for r in range(self.world)] if self.rank == 0 else None, dst=0, group=self.group)
         elif self.rank == 0:
-            self.recv[slot][0].copy_(share)
-        return self.assemble(slot)
+            self.recv[slot][0, :k].copy_(share[:k])
+        return self.assemble(slot, k)
 
-    def assemble(self, slot):
-        """Rank 0: the frame(s) from the shares received into `slot` (one interleaving copy)."""
-        import torch
+    def assemble(self, slot, k=None):
+        """Rank 0: the frame(s) from the shares received into `slot` (one launch)."""
         if self.rank != 0:
             return None
-        torch.stack([p.view(self.batch, self.per, TILE, self.w) for p in self.recv[slot]], dim=2, out=self.full[slot])
-        out = self.full[slot].view(self.batch, self.padded_height, self.w)[:, : self.h]
+        k = self.batch if k is None else int(k)
+        self._unpack(slot, k)
+        out = self.full[slot].view(self.batch, self.padded_height, self.w)[:k, : self.h]
         return out[0] if self.batch == 1 else out
 
 
