@@ -83,9 +83,10 @@ def parse():
                     help="gloo: rehearsal of the N>1 code path where ranks share one GPU (shares gathered through host memory)")
     ap.add_argument("--one-rank-group", action="store_true",
                     help="diagnostic, one GPU: run the N > 1 code path (process group, interleaved batches, dist.gather, barriers, all_reduce) with a group of ONE rank -- the RCCL calls of the multi-GPU run on a 1-GPU box")
-    ap.add_argument("--other-configs", choices=["none", "short", "full"], default="short",
+    ap.add_argument("--other-configs", choices=["none", "short", "full"], default="full",
                     help="1 GPU only: short host-timed legs of BASELINE.json's other configurations under extras.other_configs (short: bunny-class 1024^2, "
-                         "the diffuse bounce, 3840x2160; full: + the 10M-triangle hairball, 16 spp AO, whose tree takes ~12 s of host time to build)")
+                         "the diffuse bounce, 3840x2160; full, the default: + configs[4], the 10M-triangle hairball with 16 spp AO -- 3 timed frames; its tree "
+                         "takes ~6 s of host time to build)")
     ap.add_argument("--other-configs-child", choices=["short", "full"], default=None, help=argparse.SUPPRESS)
     ap.add_argument("--random-rays", type=int, default=16777216,
                     help="second leg (SURVEY s8d 'random rays vs fixed BVH'): N incoherent rays per GPU through vxrt_trace, reported under extras; 0 = skip")
@@ -190,11 +191,12 @@ def cpu_baseline(scene, vrt, w, h, light, budget_cpu_s, random_sample=None):
             with cf.ThreadPoolExecutor(cores) as ex:
                 hits = np.concatenate([x[0] for x in ex.map(lambda c: po.trace_ref(img, pr[c]), chunks)])
             hit = hits["dist"] < 1e29
-            I = (pr[:, :3] + pr[:, 3:] * hits["dist"].reshape(-1, 1).astype(f)).astype(f)
+            ph, dh = pr[hit], hits["dist"][hit].reshape(-1, 1).astype(f)      # (only the rays that hit: a miss's 1e30 would overflow the squares below)
+            I = (ph[:, :3] + ph[:, 3:] * dh).astype(f)
             L = (np.array(light, f)[None] - I).astype(f)
             dist = np.sqrt((L[:, 0] * L[:, 0] + L[:, 1] * L[:, 1]).astype(f) + (L[:, 2] * L[:, 2]).astype(f)).astype(f)
             Ln = (L * (f(1.0) / dist)[:, None]).astype(f)
-            sr = np.concatenate([(I + (Ln * f(0.001)).astype(f)).astype(f), Ln], 1).astype(f)[hit]
+            sr = np.concatenate([(I + (Ln * f(0.001)).astype(f)).astype(f), Ln], 1).astype(f)
             schunks = np.array_split(np.arange(len(sr)), cores * 4)
             with cf.ThreadPoolExecutor(cores) as ex:     # (the reference traverser has no tmax: an any-hit query to infinity, an upper bound of the GPU's bounded one)
                 list(ex.map(lambda c: po.trace_ref(img, sr[c], any_hit=True), schunks))
@@ -370,7 +372,7 @@ def other_configs(vrt, torch, dev, ds, scene, params, full):
         ph.light_pos[:] = (0.0, 400.0, 0.0)
         out.append(leg("configs[4]: hairball (framed), 1920x1080, 16 spp AO (tmax = 0.25 scene radius)",
                        lambda c: rtapi.render_ao(dh.accel, W, H, 0, H, ph, 16, radius, px.data_ptr(), seed=7, rays_ptr=c, stream=s),
-                       lambda: rtapi.render_ao(dh.accel, W, H, 0, H, ph, 16, radius, px.data_ptr(), seed=7, stream=s), 5, tris=hair.n_tris, host_build_s=round(bs, 1)))
+                       lambda: rtapi.render_ao(dh.accel, W, H, 0, H, ph, 16, radius, px.data_ptr(), seed=7, stream=s), 3, tris=hair.n_tris, host_build_s=round(bs, 1)))
         dh.close()
     return out
 

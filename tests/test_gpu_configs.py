@@ -69,13 +69,13 @@ def _occluded_ref(po, sc, w, h, pp, rhits, y0, y1):
     f = np.float32
     rh = rhits[y0:y1].reshape(-1)
     hit_mask = rh["dist"] < 1e29
-    rays = po.camera_rays(w, h, y0, y1)
-    I = (rays[:, :3] + rays[:, 3:] * rh["dist"].reshape(-1, 1).astype(f)).astype(f)
+    rays = po.camera_rays(w, h, y0, y1)[hit_mask]          # (only the rays that hit: a miss's 1e30 would overflow the squares below)
+    I = (rays[:, :3] + rays[:, 3:] * rh["dist"][hit_mask].reshape(-1, 1).astype(f)).astype(f)
     L = (np.array(pp.light_pos[:], f)[None] - I).astype(f)
     dist = np.sqrt((L[:, 0] * L[:, 0] + L[:, 1] * L[:, 1]).astype(f) + (L[:, 2] * L[:, 2]).astype(f)).astype(f)
     Ln = (L * (f(1.0) / dist)[:, None]).astype(f)
-    srays = np.concatenate([(I + (Ln * f(0.001)).astype(f)).astype(f), Ln], 1).astype(f)[hit_mask]
-    occ = po.trace_mt(po.trace_faithful, sc, srays, tmax=dist[hit_mask], any_hit=True)
+    srays = np.concatenate([(I + (Ln * f(0.001)).astype(f)).astype(f), Ln], 1).astype(f)
+    occ = po.trace_mt(po.trace_faithful, sc, srays, tmax=dist, any_hit=True)
     out = np.zeros(len(rh), bool)
     out[hit_mask] = occ["dist"] < 1e29
     return out.reshape(y1 - y0, w)
@@ -120,8 +120,8 @@ def test_headline_frame_matches_oracle_everywhere(vrt, po, gpu_device, atrium):
 
 def test_the_timed_call_itself_matches_oracle(vrt, po, gpu_device, atrium):
     """What bench.py times: vxrt_render_batch, 1920x1080, 5 frames per set of launches with a light that moves from frame to
-    frame, sets alternating on two streams, no optional outputs.  Two 8-row bands of frames 0 and 4 of the LAST set against the
-    oracle -- the first band holds the v == 0 row, both hold the u == 0 column, i.e. the pixels the EXACT launches trace; every
+    frame, sets alternating on two streams, no optional outputs.  EVERY pixel of frames 0 and 4 of the LAST set against the
+    oracle's whole frames (the v == 0 row and the u == 0 column, i.e. the pixels the EXACT launches trace, included); every
     set equal to the first (contexts and streams cannot matter); and the same frames rendered one by one with the hit-record
     output requested give the same pixels."""
     import torch

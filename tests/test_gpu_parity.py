@@ -283,13 +283,13 @@ def _occlusion_oracle(po, sc, w, h, pp, rhits):
     kernel documents them (origin I + 0.001 L, direction L, tmax |light - I|; shadow_ray in csrc/rt_kernels.hip)."""
     f = np.float32
     hit_mask = rhits["dist"].reshape(-1) < 1e29
-    rays = po.camera_rays(w, h)
-    I = (rays[:, :3] + rays[:, 3:] * rhits["dist"].reshape(-1, 1).astype(f)).astype(f)
+    rays = po.camera_rays(w, h)[hit_mask]                   # (only the rays that hit: a miss's 1e30 would overflow the squares below)
+    I = (rays[:, :3] + rays[:, 3:] * rhits["dist"].reshape(-1)[hit_mask].reshape(-1, 1).astype(f)).astype(f)
     L = (np.array(pp.light_pos[:], f)[None] - I).astype(f)
     dist = np.sqrt((L[:, 0] * L[:, 0] + L[:, 1] * L[:, 1]).astype(f) + (L[:, 2] * L[:, 2]).astype(f)).astype(f)
     Ln = (L * (f(1.0) / dist)[:, None]).astype(f)
-    srays = np.concatenate([(I + (Ln * f(0.001)).astype(f)).astype(f), Ln], 1).astype(f)[hit_mask]
-    occ, _ = po.trace_faithful(sc, srays, tmax=dist[hit_mask], any_hit=True)
+    srays = np.concatenate([(I + (Ln * f(0.001)).astype(f)).astype(f), Ln], 1).astype(f)
+    occ, _ = po.trace_faithful(sc, srays, tmax=dist, any_hit=True)
     out = np.zeros(w * h, bool)
     out[hit_mask] = occ["dist"] < 1e29
     return out.reshape(h, w), hit_mask.reshape(h, w)
