@@ -1312,6 +1312,330 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ray-pool trace kernel (ray buffers only; round 5, VERDICT item 2: incoherent rays compacted through LDS).
+//
+// The persistent kernel above gives every lane ONE ray and runs, per loop iteration, the node body for the lanes that hold a node and the
+// leaf body for the lanes that hold a leaf: with incoherent rays half the lanes of every instruction are masked (lane utilisation 0.50 on the
+// 16 Mi random rays: profiles/r04_zz_pmc_summary_random_rays.txt) -- rays of a wavefront are in different phases, and a refilled lane does not
+// change that.  Here a wavefront owns a POOL of RT_POOL_SLOTS rays (more than it has lanes) whose whole state lives in LDS -- active ray,
+// hit distance, path maximum, current work item, stack -- and every iteration it picks up to 64 slots that are in the SAME phase (a
+// ballot + prefix count over the slots' work items), loads their state, runs that one body at full width and stores the state back.  Lanes
+// are workers, not owners: nothing of a ray lives in registers between two iterations.  Per-ray arithmetic is the persistent kernel's, step
+// by step (same eval_children / order_children / ray_tri, same push order, same `m < hit.dist` rule), so the hit records are the same bits;
+// the schedule is what differs.  One wavefront per workgroup: no barrier couples wavefronts.
+//   * the stack's first RT_POOL_LSTK entries of a slot are in LDS, deeper ones in a global spill area (a lane's scratch cannot follow a ray
+//     from lane to lane); there is no register top;
+//   * an accepted hit is written to the ray's record at once (closest hit: the last accept is the record; records of misses are written
+//     when the ray ends), so barycentrics and indices need no LDS;
+//   * rays outside the fast domain go to the deferral list and the EXACT launch, as in the persistent kernel.
+// ---------------------------------------------------------------------------------------------
+#ifndef RT_POOL_SLOTS
+#define RT_POOL_SLOTS 96        // rays a wavefront holds (64 lanes work on them)
+#endif
+#ifndef RT_POOL_LSTK
+#define RT_POOL_LSTK 5          // stack entries of a slot kept in LDS
+#endif
+#ifndef RT_POOL_WAVES
+#define RT_POOL_WAVES 4         // wavefronts per SIMD the kernel is compiled for (LDS: (15 + 2 * RT_POOL_LSTK) * 4 * RT_POOL_SLOTS bytes per wavefront)
+#endif
+#ifndef RT_POOL_LEAF_MIN
+#define RT_POOL_LEAF_MIN 48     // the leaf body runs once this many slots hold a leaf (or nothing else can run)
+#endif
+#ifndef RT_POOL_NODE_KEEP
+#define RT_POOL_NODE_KEEP 44    // a node pass goes on with the same slots while at least this many of its lanes are still at a node (65: one step per pass)
+#endif
+#ifndef RT_POOL_REFILL_MIN
+#define RT_POOL_REFILL_MIN 16   // finished / empty slots are serviced (records of misses written, new rays started) once there are this many
+#endif
+enum { PF_OX = 0, PF_OY, PF_OZ, PF_IX, PF_IY, PF_IZ, PF_HITD, PF_PATHM, PF_CUR, PF_JOB, PF_FLAGS, PF_DX, PF_DY, PF_DZ, PF_BLAS, PF_STK };
+#define PF_SP_SHIFT 8           // PF_FLAGS: per-ray flag bits in [7:0], stack entries in [15:8]
+
+template <bool LDEXP, bool SHALLOW>
+__global__ __launch_bounds__(64, RT_POOL_WAVES) void rt_pool_trace_kernel(SceneDev sc, PersistArgs A, uint2* __restrict__ spill) {
+  constexpr int S = RT_POOL_SLOTS, L = RT_POOL_LSTK;
+  static_assert(S >= 64 && S <= 128, "a lane classifies at most two slots");
+  constexpr int CAP = SHALLOW ? 3 * RT_SHALLOW_LEVELS : 3 * RT_MAX_LEVELS + L;   // entries a ray's stack may hold
+  constexpr int OVF = CAP - L;
+  __shared__ uint32_t pool[PF_STK + 2 * L][S];
+  __shared__ uint32_t list[64];
+  const uint32_t lane = threadIdx.x;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  uint2* const my_spill = spill + (size_t)blockIdx.x * S * OVF;
+  const uint32_t n_jobs = A.total_dev ? min(*A.total_dev, A.total) : A.total;
+  const uint32_t per_shard = A.total_dev ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
+  const uint32_t root_desc = sc.tlas_root;
+  const uint32_t xcc_id = RT_XCC_HOME ? (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) : blockIdx.x;
+  const uint32_t shard = (xcc_id + A.shard_rot) % QUEUE_SHARDS;
+  uint32_t tries = 0, loc_next = 0, loc_end = 0;
+  bool queue_empty = false;
+  unsigned nrays = 0;
+  for (uint32_t s = lane; s < (uint32_t)S; s += 64u) { pool[PF_CUR][s] = DESC_IDLE; pool[PF_FLAGS][s] = 0u; }
+  __syncthreads();
+
+  // ---- per-slot state of the lane's current slot, in registers for the length of one pass ----
+  uint32_t slot = 0, cur = DESC_IDLE, job = 0, flags = 0, sp = 0;
+  float arx = 0, ary = 0, arz = 0, aix = 0, aiy = 0, aiz = 0, hitd = 0, path_m = 0;
+  auto push = [&](uint32_t d, float m) {
+    if (sp < (uint32_t)L) { pool[PF_STK + 2 * sp][slot] = d; pool[PF_STK + 2 * sp + 1][slot] = __float_as_uint(m); }
+    else my_spill[(size_t)slot * OVF + (sp - L)] = make_uint2(d, __float_as_uint(m));
+    ++sp;
+  };
+  auto pop_next = [&]() {      // next pending work item with m < hit.dist, or the end of the ray
+    cur = DESC_DONE;
+    while (sp > 0u) {
+      --sp;
+      uint32_t d; float m;
+      if (sp < (uint32_t)L) { d = pool[PF_STK + 2 * sp][slot]; m = __uint_as_float(pool[PF_STK + 2 * sp + 1][slot]); }
+      else { const uint2 e = my_spill[(size_t)slot * OVF + (sp - L)]; d = e.x; m = __uint_as_float(e.y); }
+      if (m < hitd) { cur = d; path_m = m; break; }
+    }
+  };
+  auto defer = [&]() {
+    const uint32_t q = atomicAdd(A.defer_count, 1u);
+    if (q < A.defer_cap) A.defer_list[q] = job;
+    cur = DESC_IDLE;
+  };
+  auto world_ray = [&](float& ox, float& oy, float& oz, float& dx, float& dy, float& dz) {
+    const float* rp = A.rays + (size_t)job * 6;
+    ox = rp[0]; oy = rp[1]; oz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5];
+  };
+  // TLAS leaf (rt_traversal.cpp:109-121): the instance record, the ray in object space
+  auto enter_instance = [&](uint32_t blasIdx, float ox, float oy, float oz, float dx, float dy, float dz, bool counted) {
+    const uint32_t* bp = sc.blas + (size_t)blasIdx * (RT_BLAS_STRIDE / 4);
+    uint32_t bw[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) bw[i] = bp[i];
+    const float m00 = __uint_as_float(bw[1]), m01 = __uint_as_float(bw[2]), m02 = __uint_as_float(bw[3]), m03 = __uint_as_float(bw[4]);
+    const float m10 = __uint_as_float(bw[5]), m11 = __uint_as_float(bw[6]), m12 = __uint_as_float(bw[7]), m13 = __uint_as_float(bw[8]);
+    const float m20 = __uint_as_float(bw[9]), m21 = __uint_as_float(bw[10]), m22 = __uint_as_float(bw[11]), m23 = __uint_as_float(bw[12]);
+    arx = m00 * ox + m01 * oy + m02 * oz + m03;   // :231-261
+    ary = m10 * ox + m11 * oy + m12 * oz + m13;
+    arz = m20 * ox + m21 * oy + m22 * oz + m23;
+    const float cdx = m00 * dx + m01 * dy + m02 * dz;
+    const float cdy = m10 * dx + m11 * dy + m12 * dz;
+    const float cdz = m20 * dx + m21 * dy + m22 * dz;
+    aix = 1.0f / cdx; aiy = 1.0f / cdy; aiz = 1.0f / cdz;
+    if (!ray_in_fast_domain(arx, ary, arz, aix, aiy, aiz)) { if (counted) nrays--; defer(); return; }   // (the EXACT launch counts the ray when it starts it again)
+    flags &= ~F_WORLD;
+    pool[PF_DX][slot] = __float_as_uint(cdx); pool[PF_DY][slot] = __float_as_uint(cdy); pool[PF_DZ][slot] = __float_as_uint(cdz);
+    pool[PF_BLAS][slot] = blasIdx;
+    cur = sc.blas_root[blasIdx];
+  };
+  auto load_state = [&]() {
+    cur = pool[PF_CUR][slot]; job = pool[PF_JOB][slot];
+    const uint32_t f = pool[PF_FLAGS][slot]; flags = f & 0xFFu; sp = f >> PF_SP_SHIFT;
+    arx = __uint_as_float(pool[PF_OX][slot]); ary = __uint_as_float(pool[PF_OY][slot]); arz = __uint_as_float(pool[PF_OZ][slot]);
+    aix = __uint_as_float(pool[PF_IX][slot]); aiy = __uint_as_float(pool[PF_IY][slot]); aiz = __uint_as_float(pool[PF_IZ][slot]);
+    hitd = __uint_as_float(pool[PF_HITD][slot]); path_m = __uint_as_float(pool[PF_PATHM][slot]);
+  };
+  auto store_ray = [&]() {
+    pool[PF_OX][slot] = __float_as_uint(arx); pool[PF_OY][slot] = __float_as_uint(ary); pool[PF_OZ][slot] = __float_as_uint(arz);
+    pool[PF_IX][slot] = __float_as_uint(aix); pool[PF_IY][slot] = __float_as_uint(aiy); pool[PF_IZ][slot] = __float_as_uint(aiz);
+  };
+  auto store_walk = [&]() {
+    pool[PF_CUR][slot] = cur; pool[PF_FLAGS][slot] = flags | (sp << PF_SP_SHIFT);
+    pool[PF_HITD][slot] = __float_as_uint(hitd); pool[PF_PATHM][slot] = __float_as_uint(path_m);
+  };
+
+  for (;;) {
+    // ---- what phase is every slot in?  (a lane looks at slots lane and lane + 64) ----
+    const uint32_t c0 = pool[PF_CUR][lane];
+    const uint32_t c1 = lane + 64u < (uint32_t)S ? pool[PF_CUR][lane + 64u] : DESC_IDLE;
+    enum { P_NODE, P_LEAF, P_INST, P_SERVICE };
+    int pass = -1;
+    unsigned long long m0, m1;
+    // (the masks of the phases are formed only as far as the decision needs them: a full node pass, the common case, costs two compares)
+    const unsigned long long node0 = __ballot(is_node_desc(c0)), node1 = __ballot(is_node_desc(c1));
+    const uint32_t n_node = (uint32_t)(__popcll(node0) + __popcll(node1));
+    if (n_node >= 64u) { pass = P_NODE; m0 = node0; m1 = node1; }
+    else {
+      const unsigned long long leaf0 = __ballot(is_leaf_desc(c0)), leaf1 = __ballot(is_leaf_desc(c1));
+      const uint32_t n_leaf = (uint32_t)(__popcll(leaf0) + __popcll(leaf1));
+      if (n_leaf >= (uint32_t)RT_POOL_LEAF_MIN) { pass = P_LEAF; m0 = leaf0; m1 = leaf1; }
+      else {
+        const bool more_jobs = !(queue_empty && loc_next == loc_end);
+        const unsigned long long slots1 = S < 128 ? ((1ull << (S - 64)) - 1ull) : ~0ull;
+        const unsigned long long srv0 = __ballot(c0 == DESC_DONE || (more_jobs && c0 == DESC_IDLE));
+        const unsigned long long srv1 = __ballot(c1 == DESC_DONE || (more_jobs && c1 == DESC_IDLE)) & slots1;
+        const uint32_t n_service = (uint32_t)(__popcll(srv0) + __popcll(srv1));
+        const unsigned long long inst0 = __ballot(is_inst_desc(c0)), inst1 = __ballot(is_inst_desc(c1));
+        if (n_service >= (uint32_t)RT_POOL_REFILL_MIN) { pass = P_SERVICE; m0 = srv0; m1 = srv1; }
+        else if (inst0 | inst1) { pass = P_INST; m0 = inst0; m1 = inst1; }
+        else if (n_node) { pass = P_NODE; m0 = node0; m1 = node1; }
+        else if (n_leaf) { pass = P_LEAF; m0 = leaf0; m1 = leaf1; }
+        else if (n_service) { pass = P_SERVICE; m0 = srv0; m1 = srv1; }
+        else break;                                    // every slot empty, nothing left in the queue
+      }
+    }
+    const uint32_t k0 = (uint32_t)__popcll(m0), n_sel = min(64u, k0 + (uint32_t)__popcll(m1));
+    // (one wavefront per workgroup: its LDS instructions execute in order, so the list written here is what the reads below see -- the
+    // compiler must only keep them in program order; no s_barrier and, above all, no wait for the global loads and stores in flight)
+    __builtin_amdgcn_wave_barrier();
+    if ((m0 >> lane) & 1ull) list[(uint32_t)__popcll(m0 & lt_mask)] = lane;
+    if ((m1 >> lane) & 1ull) { const uint32_t r = k0 + (uint32_t)__popcll(m1 & lt_mask); if (r < 64u) list[r] = lane + 64u; }
+    __builtin_amdgcn_wave_barrier();
+    const bool act = lane < n_sel;
+    slot = act ? list[lane] : 0u;
+
+    if (pass == P_NODE) {
+      if (act) load_state();
+      // a lane keeps its slot while enough of the pass's lanes are still at a node: the pool's cost -- finding the slots, loading and storing
+      // their state -- is paid once for several steps, at the price of the lanes that have meanwhile reached a leaf or the end waiting masked
+      for (;;) {
+      if (act && is_node_desc(cur)) {
+        const bool top = (cur >> 30) == DK_TLAS;
+        if (top && !(flags & F_WORLD)) {               // back at TLAS level after an instance (multi-instance scenes only)
+          float dx, dy, dz;
+          world_ray(arx, ary, arz, dx, dy, dz);
+          aix = 1.0f / dx; aiy = 1.0f / dy; aiz = 1.0f / dz;
+          flags |= F_WORLD;
+          store_ray();
+        }
+        const uint32_t ni = cur & PAYLOAD_MASK;
+        const uint4* np = sc.nodes_c + (size_t)ni * CNODE_VEC4;
+        const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+        const uint32_t* ref_node = nullptr;
+        if (LDEXP) ref_node = top ? sc.ref_tlas + (size_t)ni * RT_NODE_DWORDS : sc.ref_bvh + (size_t)(ni - sc.n_tlas) * RT_NODE_DWORDS;
+        Cand c[4];
+        eval_children<false, LDEXP>(q0, q1, q2, q3, ref_node, arx, ary, arz, aix, aiy, aiz, hitd, c);
+        order_children(c);
+        if (c[0].d < __builtin_inff()) {
+          bool more = true;
+          if (sp + 3u > (uint32_t)CAP) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
+          if (more && c[3].d < __builtin_inff()) push(c[3].desc, vmax_nonan(path_m, c[3].d));   // far first (:98-103)
+          if (more && c[2].d < __builtin_inff()) push(c[2].desc, vmax_nonan(path_m, c[2].d));
+          if (more && c[1].d < __builtin_inff()) push(c[1].desc, vmax_nonan(path_m, c[1].d));
+          cur = c[0].desc;
+          path_m = vmax_nonan(path_m, c[0].d);
+        } else pop_next();
+      }
+      if ((uint32_t)__popcll(__ballot(act && is_node_desc(cur))) < (uint32_t)RT_POOL_NODE_KEEP) break;
+      }
+      if (act) store_walk();
+    } else if (pass == P_LEAF) {
+      if (act) {
+        load_state();
+        uint32_t leftFirst = cur & LEAF_FIRST_MASK, triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
+        if (triCount == 0u) { const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS; leftFirst = rn[4]; triCount = rn[5]; }
+        const float cdx = __uint_as_float(pool[PF_DX][slot]), cdy = __uint_as_float(pool[PF_DY][slot]), cdz = __uint_as_float(pool[PF_DZ][slot]);
+        const uint32_t blasIdx = pool[PF_BLAS][slot];
+        bool stop = false;
+        float4 n0, n1, n2;
+        { const float4* tp0 = sc.tri_w + (size_t)leftFirst * 3; n0 = tp0[0]; n1 = tp0[1]; n2 = tp0[2]; }
+        for (uint32_t i = 0; i < triCount; ++i) {
+          const uint32_t triIdx = leftFirst + i;
+          const float4 t0 = n0, t1 = n1, t2 = n2;
+          if (i + 1u < triCount) { const float4* tn = sc.tri_w + (size_t)(triIdx + 1u) * 3; n0 = tn[0]; n1 = tn[1]; n2 = tn[2]; }
+          float bx, by, bz;
+          const float d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
+          if (d < hitd) {
+            hitd = d;
+            flags |= F_FOUND;
+            HitRec h; h.dist = d; h.bx = bx; h.by = by; h.bz = 1 - bx - by; h.blasIdx = blasIdx; h.triIdx = triIdx;   // rt_traversal.cpp:311-313
+            A.hits[job] = h;                           // the record of the best hit so far: the last accept stands
+            if (flags & F_ANYHIT) { stop = true; break; }
+            if (!(path_m < hitd)) break;               // the reference abandons this subtree
+          }
+        }
+        if (stop) { sp = 0; cur = DESC_DONE; } else pop_next();
+        store_walk();
+      }
+    } else if (pass == P_INST) {
+      if (act) {
+        load_state();
+        float ox, oy, oz, dx, dy, dz;
+        world_ray(ox, oy, oz, dx, dy, dz);
+        enter_instance(cur & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz, true);
+        store_ray();
+        store_walk();
+      }
+    } else {
+      // ---- service: rays that ended leave (a miss gets its record now), empty slots take new rays ----
+      bool empty = false;
+      if (act) {
+        load_state();
+        if (cur == DESC_DONE) {
+          if (!(flags & F_FOUND)) { HitRec h; h.dist = RT_LARGE_FLOAT; h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0; A.hits[job] = h; }
+          cur = DESC_IDLE;
+        }
+        empty = true;
+      }
+      const unsigned long long want = __ballot(empty);
+      uint32_t n_want = (uint32_t)__popcll(want);
+      uint32_t given = 0;                               // lanes want & ((1 << given) - 1) ... have their ray
+      while (n_want > given && !queue_empty) {
+        if (loc_next == loc_end) {                     // reserve the next chunk (the persistent kernel's queue: home shard = physical XCD, then the others)
+          while (tries < QUEUE_SHARDS) {
+            const uint32_t sid = (shard + tries) % QUEUE_SHARDS;
+            const uint32_t s_lo = sid * per_shard;
+            uint32_t in_range;
+            asm volatile("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0 ; RTGUARD shard_range" : "=s"(in_range)
+                         : "s"(__builtin_amdgcn_readfirstlane(s_lo)), "s"(__builtin_amdgcn_readfirstlane(n_jobs)) : "scc");
+            if (!in_range) { ++tries; continue; }
+            const uint32_t s_n = min(per_shard, n_jobs - s_lo);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(A.queue + sid * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
+            base = __shfl(base, 0);
+            if (base < s_n) { loc_next = s_lo + base; loc_end = s_lo + min(base + (uint32_t)RT_CHUNK, s_n); break; }
+            ++tries;
+          }
+          if (tries >= QUEUE_SHARDS) { queue_empty = true; break; }
+        }
+        const uint32_t take = min(n_want - given, loc_end - loc_next);
+        const uint32_t rank = (uint32_t)__popcll(want & lt_mask);
+        if (empty && rank >= given && rank < given + take) {
+          job = loc_next + (rank - given);
+          if (A.order) job = A.order[job];
+          float ox, oy, oz, dx, dy, dz;
+          world_ray(ox, oy, oz, dx, dy, dz);
+          const float tmax_ = A.tmax ? A.tmax[job] : RT_LARGE_FLOAT;
+          arx = ox; ary = oy; arz = oz;
+          aix = 1.0f / dx; aiy = 1.0f / dy; aiz = 1.0f / dz;
+          flags = F_WORLD | (A.any_hit ? F_ANYHIT : 0u);
+          sp = 0;
+          if (!ray_in_fast_domain(ox, oy, oz, aix, aiy, aiz)) defer();
+          else {
+            hitd = tmax_ > RT_LARGE_FLOAT ? RT_LARGE_FLOAT : tmax_;
+            path_m = -__builtin_inff();
+            cur = root_desc;
+            nrays++;
+            if (is_inst_desc(root_desc)) {
+              const bool no_neg_zero = __float_as_uint(ox) != 0x80000000u && __float_as_uint(oy) != 0x80000000u && __float_as_uint(oz) != 0x80000000u;
+              if (sc.ident_root && no_neg_zero) {       // (see start_ray of the persistent kernel: the object-space ray IS the world ray)
+                flags &= ~F_WORLD;
+                pool[PF_DX][slot] = __float_as_uint(dx); pool[PF_DY][slot] = __float_as_uint(dy); pool[PF_DZ][slot] = __float_as_uint(dz);
+                pool[PF_BLAS][slot] = root_desc & PAYLOAD_MASK;
+                cur = sc.blas_root[root_desc & PAYLOAD_MASK];
+              } else enter_instance(root_desc & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz, true);
+            }
+          }
+          pool[PF_JOB][slot] = job;
+          store_ray();
+          empty = false;                               // (this lane's slot is taken -- or went to the deferral list and stays empty for the next pass)
+        }
+        given += take; loc_next += take;
+      }
+      if (act) store_walk();
+    }
+  }
+
+  if (A.end_log) {
+    unsigned s = nrays;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) {
+      unsigned long long* w = A.end_log + 2ull * (blockIdx.x & 8191u);
+      w[0] = wall_clock64();
+      w[1] = (unsigned long long)s | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 56);
+    }
+  }
+  if (A.counters) {
+    unsigned s = nrays;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0 && s) atomicAdd(A.counters, (unsigned long long)s);
+  }
+}
+
 // Tile order for the next frame of a context: within each queue shard's band of tiles (a contiguous part of the
 // frame, whose tiles share BVH nodes in the L2 of the XCD that works on it), most expensive first; cost = 100 MHz
 // clocks the tile occupied its wavefront in the frame just traced.  A launch ends when its last tile ends, and a
@@ -2219,6 +2543,7 @@ struct FrameCtx {
   uint32_t* ao_list = nullptr; uint32_t* ao_hdr = nullptr;   // pixels with a hit; [0] their number, [1] rays of the current batch
   float* ao_rays = nullptr; float* ao_tmax = nullptr; HitRec* ao_hits = nullptr; uint64_t ao_cap = 0, ao_ray_cap = 0;
   uint32_t* bin_hist = nullptr; uint32_t* bin_keys = nullptr; uint32_t* bin_order = nullptr; uint64_t bin_cap = 0, bin_ray_cap = 0;   // secondary-ray binning
+  void* pool_spill = nullptr; uint64_t pool_spill_bytes = 0;   // ray-pool trace kernel: the part of the slots' stacks that does not fit LDS
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr;
   bool busy = false, inited = false, done_recorded = false;
@@ -2264,7 +2589,7 @@ static void accel_free(vxrt_accel* a) {
       (void)hipFree(l.rays); (void)hipFree(l.hits); (void)hipFree(l.parent); (void)hipFree(l.term); (void)hipFree(l.col);
       (void)hipFree(l.srays); (void)hipFree(l.stmax); (void)hipFree(l.shits);
     }
-    (void)hipFree(c.pbatch);
+    (void)hipFree(c.pbatch); (void)hipFree(c.pool_spill);
     if (c.side) (void)hipStreamDestroy(c.side);
     if (c.ev_in) (void)hipEventDestroy(c.ev_in);
     if (c.ev_side) (void)hipEventDestroy(c.ev_side);
@@ -2534,6 +2859,25 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   X.total_dev = nullptr;   // the EXACT launch takes its count from the deferral list
   X.order = nullptr;
   ShadeParams p{};
+  // incoherent rays: the ray-pool kernel (rt_pool_trace_kernel; VXRT_POOL=0/1 forces the choice), timed builds only
+  static const int pool_env = [] { const char* e = getenv("VXRT_POOL"); return e ? atoi(e) : 0; }();
+  if (pool_env > 0 && !stats_counters) {
+#define LAUNCH_POOL(LD, SH) do { \
+      const uint32_t g = persistent_grid(rt_pool_trace_kernel<LD, SH>, n, 64); \
+      const uint64_t need = (uint64_t)g * RT_POOL_SLOTS * ((SH ? 3 * RT_SHALLOW_LEVELS : 3 * RT_MAX_LEVELS + RT_POOL_LSTK) - RT_POOL_LSTK) * sizeof(uint2); \
+      if (c->pool_spill_bytes < need) { \
+        if (hipStreamSynchronize(s) != hipSuccess) return -1; \
+        (void)hipFree(c->pool_spill); c->pool_spill = nullptr; c->pool_spill_bytes = 0; \
+        if (hipMalloc(&c->pool_spill, need) != hipSuccess) return -1; \
+        c->pool_spill_bytes = need; \
+      } \
+      hipLaunchKernelGGL((rt_pool_trace_kernel<LD, SH>), dim3(g), dim3(64), 0, s, a->dev, A, (uint2*)c->pool_spill); \
+      hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, 0, LD, true>), dim3(std::max<uint32_t>(EXACT_GRID, persistent_grid(rt_persistent_kernel<JOB_TRACE, 0, LD, true>, n / 8, 256))), dim3(256), 0, s, a->dev, p, X); } while (0)
+    if (a->shallow) { if (a->dev.exact_decode) LAUNCH_POOL(true, true); else LAUNCH_POOL(false, true); }
+    else            { if (a->dev.exact_decode) LAUNCH_POOL(true, false); else LAUNCH_POOL(false, false); }
+#undef LAUNCH_POOL
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
 #define LAUNCH_T(ST, LD, SH) do { \
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, false, false, SH>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, false, false, SH>, n)), dim3(RT_WG_THREADS), 0, s, a->dev, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, true>), dim3(std::max<uint32_t>(EXACT_GRID, persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, true>, n / 8, 256))), dim3(256), 0, s, a->dev, p, X); } while (0)
