@@ -445,6 +445,9 @@ int vxrt_debug_read_control(vxrt_accel_t* accel, uint32_t ctx, uint32_t* out, ui
  * wavefront, at its end.  The pointer is captured by the launches enqueued after the call (no synchronisation): the caller keeps the
  * memory alive until they have run. */
 int vxrt_debug_end_log(vxrt_accel_t* accel, unsigned long long* log);
+/* Diagnostic (tools/trace_phases.py): vxrt_trace_stats launches keep vxrt_render_wave_log's 16 u64 per wavefront in `log` (device
+ * memory, 16 x 8,192 u64) from now on; NULL switches it off. */
+int vxrt_debug_trace_wave_log(vxrt_accel_t* accel, unsigned long long* log);
 /* diagnostic (tools/tile_tail.py): what frame context `ctx` learned for sets of `batch` frames -- per-tile cost (loop iterations of the
  * wavefront that traced it in the last launch; start clocks, durations and steal distances behind them after a wave-log launch) and the
  * tile order derived from it.  Returns the capacity in tiles. */

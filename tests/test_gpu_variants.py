@@ -46,9 +46,10 @@ def test_ray_pool_trace_kernel_stays_bit_equal(vrt, gpu_device):
     runs ONE body over up to 64 slots in the same phase) lost its A/B on the 16 Mi random rays (profiles/r05_f_ray_pool.txt) and is not
     the default; VXRT_POOL=1 selects it.  A child process runs the ray-buffer parity tests through it -- reference fixtures, first
     accepted candidates, random rays, degenerate rays and bounds, deep chains, the fuzz cases -- so that the code cannot rot."""
-    env = dict(os.environ, VXRT_POOL="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"),
-                        "-x", "-q", "-k", "trace or any_hit or random_rays or degenerate or depth_class or overflow_status or exact_launch or identity_instance or fuzz or mirror or ambient"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
-    assert " passed" in r.stdout
+    for which in ("1", "2"):       # 1: the ray pool in LDS; 2: two rays per lane in registers (rt_pair_trace_kernel), the same A/B, the same fate
+        env = dict(os.environ, VXRT_POOL=which)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"),
+                            "-x", "-q", "-k", "trace or any_hit or random_rays or degenerate or depth_class or overflow_status or exact_launch or identity_instance or fuzz or mirror or ambient"],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, (which, r.stdout[-3000:], r.stderr[-1500:])
+        assert " passed" in r.stdout

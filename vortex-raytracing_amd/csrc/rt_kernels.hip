@@ -474,6 +474,12 @@ __device__ __forceinline__ void ao_sample_ray(uint32_t x, uint32_t y, uint32_t W
 #ifndef RT_CHUNK
 #define RT_CHUNK 64         // jobs reserved per global atomic (one 8x8 tile)
 #endif
+#ifndef RT_TRACE_NT
+#define RT_TRACE_NT 0       // ray buffers: rays loaded and hit records stored with the streaming hint
+#endif
+#ifndef RT_TRACE_CHUNK
+#define RT_TRACE_CHUNK 64   // ray buffers: jobs reserved per global atomic (rays have no screen neighbours to keep together)
+#endif
 #ifndef RT_XCC_HOME
 #define RT_XCC_HOME 1         // a wavefront's home queue shard is its physical XCD (0 = blockIdx % 8, which names a group of blocks that share an XCD, not the XCD)
 #endif
@@ -699,6 +705,9 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   }
   const uint32_t root_desc = (USE_TOP && n_top) ? sc.tlas_root_top : sc.tlas_root;
   const uint32_t* const blas_roots = (USE_TOP && n_top) ? sc.blas_root_top : sc.blas_root;
+  // single-instance scenes: the BLAS root every ray starts at, fetched once per wavefront (a scalar) instead of once per ray -- a dependent
+  // load less on the way from a job to its first node step
+  const uint32_t root_blas_desc = is_inst_desc(root_desc) ? blas_roots[root_desc & PAYLOAD_MASK] : DESC_DONE;
 
   // ---- per-lane ray state in registers ----
   float arx = 0, ary = 0, arz = 0, aix = 0, aiy = 0, aiz = 0;   // active ray: origin, 1/direction
@@ -761,7 +770,10 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     tmax_ = RT_LARGE_FLOAT;
     if (JOB == JOB_TRACE) {
       const float* rp = A.rays + (size_t)job * 6;
-      ox = rp[0]; oy = rp[1]; oz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5];
+      if (RT_TRACE_NT) {   // (a ray is read once, by one lane: streamed past the caches that hold the tree)
+        ox = __builtin_nontemporal_load(rp); oy = __builtin_nontemporal_load(rp + 1); oz = __builtin_nontemporal_load(rp + 2);
+        dx = __builtin_nontemporal_load(rp + 3); dy = __builtin_nontemporal_load(rp + 4); dz = __builtin_nontemporal_load(rp + 5);
+      } else { ox = rp[0]; oy = rp[1]; oz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5]; }
       if (A.tmax) tmax_ = A.tmax[job];
     } else {
       uint32_t x, y;
@@ -853,7 +865,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
         flags &= ~F_WORLD;
         CTX(0) = __float_as_uint(dx); CTX(1) = __float_as_uint(dy); CTX(2) = __float_as_uint(dz);
         CTX(8) = root_desc & PAYLOAD_MASK;
-        cur = blas_roots[root_desc & PAYLOAD_MASK];
+        cur = root_blas_desc;
       } else enter_instance(root_desc & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz);
     }
   };
@@ -924,10 +936,11 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             if (!in_range) { ++tries; continue; }
             const uint32_t s_n = min(per_shard, n_jobs - s_lo);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(A.queue + sid * QUEUE_STRIDE, (uint32_t)RT_CHUNK);
+            constexpr uint32_t CHUNK = (JOB == JOB_TRACE && !EXACT) ? (uint32_t)RT_TRACE_CHUNK : (uint32_t)RT_CHUNK;
+            if (lane == 0) base = atomicAdd(A.queue + sid * QUEUE_STRIDE, CHUNK);
             base = __shfl(base, 0);
             if (base < s_n) {
-              loc_next = s_lo + base; loc_end = s_lo + min(base + (uint32_t)RT_CHUNK, s_n);
+              loc_next = s_lo + base; loc_end = s_lo + min(base + CHUNK, s_n);
               break;
             }
             // handed out: tell the workgroup's other wavefronts
@@ -1191,7 +1204,12 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           h.dist = hitd; h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;   // rt_traversal.cpp:311-313
           h.blasIdx = CTX(6); h.triIdx = CTX(7);
         }
-        *hit_slot() = h;
+        if (RT_TRACE_NT) {
+          uint32_t* hp = (uint32_t*)hit_slot();
+          __builtin_nontemporal_store(__float_as_uint(h.dist), hp); __builtin_nontemporal_store(__float_as_uint(h.bx), hp + 1);
+          __builtin_nontemporal_store(__float_as_uint(h.by), hp + 2); __builtin_nontemporal_store(__float_as_uint(h.bz), hp + 3);
+          __builtin_nontemporal_store(h.blasIdx, hp + 4); __builtin_nontemporal_store(h.triIdx, hp + 5);
+        } else *hit_slot() = h;
         cur = DESC_IDLE;
       } else if (JOB == JOB_RENDER_GI) {
         // one diffuse bounce, in the lane (see JOB_RENDER_GI above).  Every step is the code of the pass it replaces:
@@ -1629,6 +1647,254 @@ __global__ __launch_bounds__(64, RT_POOL_WAVES) void rt_pool_trace_kernel(SceneD
       w[1] = (unsigned long long)s | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 56);
     }
   }
+  if (A.counters) {
+    unsigned s = nrays;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0 && s) atomicAdd(A.counters, (unsigned long long)s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two rays per lane (ray buffers only; round 5, VERDICT item 2, second form: the state stays in REGISTERS).
+//
+// What masks half the lanes of the persistent kernel on incoherent rays is the phase: every iteration runs the node body for the lanes whose
+// ray is at a node (39.5 of 64 on the random rays) and, when enough have gathered, the leaf body for those at a leaf (22.7 of 64); the others
+// wait.  The ray-pool kernel above cures that by moving every ray's state through LDS, which costs more than it saves.  Here a lane OWNS two
+// rays: the active one in the registers the bodies work on, the parked one in a second set.  Before a body runs, a lane whose active ray is
+// not in that body's phase but whose parked ray is exchanges the two (v_swap_b32 under the lane's execution mask: 14 instructions for the
+// wavefront, whoever swaps) -- so the node body sees a lane unless NEITHER of its rays is at a node.  Nothing moves through memory: each
+// ray keeps its own stack rows in LDS and scratch (selected by the half the lane is working on), an accepted hit goes straight to the
+// ray's record.  Per-ray arithmetic is the persistent kernel's, step by step; only the interleaving of independent rays differs.
+// ---------------------------------------------------------------------------------------------
+#ifndef RT_PAIR_LSTK
+#define RT_PAIR_LSTK 5          // stack entries of each of a lane's two rays kept in LDS
+#endif
+#ifndef RT_PAIR_WAVES
+#define RT_PAIR_WAVES 5         // wavefronts per SIMD the kernel is compiled for
+#endif
+#ifndef RT_PAIR_LEAF_MIN
+#define RT_PAIR_LEAF_MIN 32     // the leaf body runs once this many lanes hold a leaf in either ray (or no lane holds a node)
+#endif
+#ifndef RT_PAIR_DEAD_MAX
+#define RT_PAIR_DEAD_MAX 32     // of the wavefront's 128 ray slots: finished / empty ones are serviced once there are this many
+#endif
+
+template <bool LDEXP, bool SHALLOW>
+__global__ __launch_bounds__(64, RT_PAIR_WAVES) void rt_pair_trace_kernel(SceneDev sc, PersistArgs A) {
+  constexpr int L = RT_PAIR_LSTK;
+  constexpr int CAP = SHALLOW ? 3 * RT_SHALLOW_LEVELS : 3 * RT_MAX_LEVELS + L;
+  constexpr int OVF = CAP - L;
+  __shared__ uint2 s_stk[2][L][64];
+  __shared__ uint32_t s_ctx[2][4][64];     // per ray: object-space direction (triangle tests), instance index
+  const uint32_t lane = threadIdx.x;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const uint32_t n_jobs = A.total_dev ? min(*A.total_dev, A.total) : A.total;
+  const uint32_t per_shard = A.total_dev ? (((n_jobs + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u) : A.per_shard;
+  const uint32_t root_desc = sc.tlas_root;
+  const uint32_t root_blas_desc = is_inst_desc(root_desc) ? sc.blas_root[root_desc & PAYLOAD_MASK] : DESC_DONE;
+  const uint32_t xcc_id = RT_XCC_HOME ? (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) : blockIdx.x;
+  const uint32_t shard = (xcc_id + A.shard_rot) % QUEUE_SHARDS;
+  uint32_t tries = 0, loc_next = 0, loc_end = 0;
+  bool queue_empty = false;
+  unsigned nrays = 0;
+  // the active ray (what the bodies work on) and the parked one; `half` = which of the lane's two stack / context rows the active ray owns
+  float arx = 0, ary = 0, arz = 0, aix = 0, aiy = 0, aiz = 0, hitd = 0, path_m = 0;
+  uint32_t cur = DESC_IDLE, job = 0, flags = 0, sp = 0, half = 0;
+  float q_arx = 0, q_ary = 0, q_arz = 0, q_aix = 0, q_aiy = 0, q_aiz = 0, q_hitd = 0, q_path_m = 0;
+  uint32_t q_cur = DESC_IDLE, q_job = 0, q_flags = 0, q_sp = 0, q_half = 1;
+  uint2 ovf[2 * OVF];
+#define PSWAPF(a, b) asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b))
+  auto swap_rays = [&]() {       // (called under a divergent condition: the lanes that take the branch exchange their two rays)
+    PSWAPF(arx, q_arx); PSWAPF(ary, q_ary); PSWAPF(arz, q_arz); PSWAPF(aix, q_aix); PSWAPF(aiy, q_aiy); PSWAPF(aiz, q_aiz);
+    PSWAPF(hitd, q_hitd); PSWAPF(path_m, q_path_m); PSWAPF(cur, q_cur); PSWAPF(job, q_job); PSWAPF(flags, q_flags); PSWAPF(sp, q_sp); PSWAPF(half, q_half);
+  };
+  auto push = [&](uint32_t d, float m) {
+    if (sp < (uint32_t)L) s_stk[half][sp][lane] = make_uint2(d, __float_as_uint(m));
+    else ovf[half * OVF + (sp - L)] = make_uint2(d, __float_as_uint(m));
+    ++sp;
+  };
+  auto pop_next = [&]() {
+    cur = DESC_DONE;
+    while (sp > 0u) {
+      --sp;
+      const uint2 e = sp < (uint32_t)L ? s_stk[half][sp][lane] : ovf[half * OVF + (sp - L)];
+      if (__uint_as_float(e.y) < hitd) { cur = e.x; path_m = __uint_as_float(e.y); break; }
+    }
+  };
+  auto defer = [&]() {
+    const uint32_t q = atomicAdd(A.defer_count, 1u);
+    if (q < A.defer_cap) A.defer_list[q] = job;
+    cur = DESC_IDLE;
+  };
+  auto world_ray = [&](float& ox, float& oy, float& oz, float& dx, float& dy, float& dz) {
+    const float* rp = A.rays + (size_t)job * 6;
+    ox = rp[0]; oy = rp[1]; oz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5];
+  };
+  auto enter_instance = [&](uint32_t blasIdx, float ox, float oy, float oz, float dx, float dy, float dz) {   // rt_traversal.cpp:109-121, :231-261
+    const uint32_t* bp = sc.blas + (size_t)blasIdx * (RT_BLAS_STRIDE / 4);
+    uint32_t bw[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) bw[i] = bp[i];
+    const float m00 = __uint_as_float(bw[1]), m01 = __uint_as_float(bw[2]), m02 = __uint_as_float(bw[3]), m03 = __uint_as_float(bw[4]);
+    const float m10 = __uint_as_float(bw[5]), m11 = __uint_as_float(bw[6]), m12 = __uint_as_float(bw[7]), m13 = __uint_as_float(bw[8]);
+    const float m20 = __uint_as_float(bw[9]), m21 = __uint_as_float(bw[10]), m22 = __uint_as_float(bw[11]), m23 = __uint_as_float(bw[12]);
+    arx = m00 * ox + m01 * oy + m02 * oz + m03;
+    ary = m10 * ox + m11 * oy + m12 * oz + m13;
+    arz = m20 * ox + m21 * oy + m22 * oz + m23;
+    const float cdx = m00 * dx + m01 * dy + m02 * dz;
+    const float cdy = m10 * dx + m11 * dy + m12 * dz;
+    const float cdz = m20 * dx + m21 * dy + m22 * dz;
+    aix = 1.0f / cdx; aiy = 1.0f / cdy; aiz = 1.0f / cdz;
+    if (!ray_in_fast_domain(arx, ary, arz, aix, aiy, aiz)) { nrays--; defer(); return; }   // (the EXACT launch counts the ray when it starts it again)
+    flags &= ~F_WORLD;
+    s_ctx[half][0][lane] = __float_as_uint(cdx); s_ctx[half][1][lane] = __float_as_uint(cdy); s_ctx[half][2][lane] = __float_as_uint(cdz);
+    s_ctx[half][3][lane] = blasIdx;
+    cur = sc.blas_root[blasIdx];
+  };
+  auto dead = [&](uint32_t d, bool more_jobs) { return d == DESC_DONE || (more_jobs && d == DESC_IDLE); };
+
+  for (;;) {
+    // ================= service: rays that ended leave (a miss gets its record), empty slots take new rays =================
+    const bool more_jobs = !(queue_empty && loc_next == loc_end);
+    const uint32_t n_dead = (uint32_t)(__popcll(__ballot(dead(cur, more_jobs))) + __popcll(__ballot(dead(q_cur, more_jobs))));
+    const bool any_work = __ballot(is_work_desc(cur) || is_work_desc(q_cur)) != 0ull;
+    if (n_dead >= (uint32_t)RT_PAIR_DEAD_MAX || (!any_work && n_dead)) {
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {        // the active rays, then (everything exchanged) the parked ones; two exchanges restore the order
+        if (cur == DESC_DONE) {
+          if (!(flags & F_FOUND)) { HitRec m; m.dist = RT_LARGE_FLOAT; m.bx = 0; m.by = 0; m.bz = 0; m.blasIdx = 0; m.triIdx = 0; A.hits[job] = m; }
+          cur = DESC_IDLE;
+        }
+        const unsigned long long want = __ballot(cur == DESC_IDLE);
+        const uint32_t n_want = (uint32_t)__popcll(want);
+        uint32_t given = 0;
+        while (n_want > given && !queue_empty) {
+          if (loc_next == loc_end) {
+            while (tries < QUEUE_SHARDS) {
+              const uint32_t sid = (shard + tries) % QUEUE_SHARDS;
+              const uint32_t s_lo = sid * per_shard;
+              uint32_t in_range;
+              asm volatile("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0 ; RTGUARD shard_range" : "=s"(in_range)
+                           : "s"(__builtin_amdgcn_readfirstlane(s_lo)), "s"(__builtin_amdgcn_readfirstlane(n_jobs)) : "scc");
+              if (!in_range) { ++tries; continue; }
+              const uint32_t s_n = min(per_shard, n_jobs - s_lo);
+              uint32_t base = 0;
+              if (lane == 0) base = atomicAdd(A.queue + sid * QUEUE_STRIDE, (uint32_t)RT_TRACE_CHUNK);
+              base = __shfl(base, 0);
+              if (base < s_n) { loc_next = s_lo + base; loc_end = s_lo + min(base + (uint32_t)RT_TRACE_CHUNK, s_n); break; }
+              ++tries;
+            }
+            if (tries >= QUEUE_SHARDS) { queue_empty = true; break; }
+          }
+          const uint32_t take = min(n_want - given, loc_end - loc_next);
+          const uint32_t rank = (uint32_t)__popcll(want & lt_mask);
+          if (cur == DESC_IDLE && ((want >> lane) & 1ull) && rank >= given && rank < given + take) {
+            job = loc_next + (rank - given);
+            if (A.order) job = A.order[job];
+            float ox, oy, oz, dx, dy, dz;
+            world_ray(ox, oy, oz, dx, dy, dz);
+            const float tmax_ = A.tmax ? A.tmax[job] : RT_LARGE_FLOAT;
+            arx = ox; ary = oy; arz = oz;
+            aix = 1.0f / dx; aiy = 1.0f / dy; aiz = 1.0f / dz;
+            flags = F_WORLD | (A.any_hit ? F_ANYHIT : 0u);
+            sp = 0;
+            if (!ray_in_fast_domain(ox, oy, oz, aix, aiy, aiz)) defer();
+            else {
+              hitd = tmax_ > RT_LARGE_FLOAT ? RT_LARGE_FLOAT : tmax_;
+              path_m = -__builtin_inff();
+              cur = root_desc;
+              nrays++;
+              if (is_inst_desc(root_desc)) {
+                const bool no_neg_zero = __float_as_uint(ox) != 0x80000000u && __float_as_uint(oy) != 0x80000000u && __float_as_uint(oz) != 0x80000000u;
+                if (sc.ident_root && no_neg_zero) {     // (see start_ray of the persistent kernel: the object-space ray IS the world ray)
+                  flags &= ~F_WORLD;
+                  s_ctx[half][0][lane] = __float_as_uint(dx); s_ctx[half][1][lane] = __float_as_uint(dy); s_ctx[half][2][lane] = __float_as_uint(dz);
+                  s_ctx[half][3][lane] = root_desc & PAYLOAD_MASK;
+                  cur = root_blas_desc;
+                } else enter_instance(root_desc & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz);
+              }
+            }
+          }
+          given += take; loc_next += take;
+        }
+        swap_rays();
+      }
+    }
+    if (__ballot(is_work_desc(cur) || is_work_desc(q_cur)) == 0ull) {
+      if (queue_empty && loc_next == loc_end) break;
+      continue;
+    }
+
+    // ================= instance steps (TLAS leaves of multi-instance scenes): whichever of a lane's rays holds one =================
+    if (__ballot(is_inst_desc(cur) || is_inst_desc(q_cur)) != 0ull) {
+      if (!is_inst_desc(cur) && is_inst_desc(q_cur)) swap_rays();
+      if (is_inst_desc(cur)) {
+        float ox, oy, oz, dx, dy, dz;
+        world_ray(ox, oy, oz, dx, dy, dz);
+        enter_instance(cur & PAYLOAD_MASK, ox, oy, oz, dx, dy, dz);
+      }
+    }
+    // ================= node body: a lane takes part unless NEITHER of its rays is at a node =================
+    if (!is_node_desc(cur) && is_node_desc(q_cur)) swap_rays();
+    if (is_node_desc(cur)) {
+      const bool top = (cur >> 30) == DK_TLAS;
+      if (top && !(flags & F_WORLD)) {                 // back at TLAS level after an instance (multi-instance scenes only)
+        float dx, dy, dz;
+        world_ray(arx, ary, arz, dx, dy, dz);
+        aix = 1.0f / dx; aiy = 1.0f / dy; aiz = 1.0f / dz;
+        flags |= F_WORLD;
+      }
+      const uint32_t ni = cur & PAYLOAD_MASK;
+      const uint4* np = sc.nodes_c + (size_t)ni * CNODE_VEC4;
+      const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+      const uint32_t* ref_node = nullptr;
+      if (LDEXP) ref_node = top ? sc.ref_tlas + (size_t)ni * RT_NODE_DWORDS : sc.ref_bvh + (size_t)(ni - sc.n_tlas) * RT_NODE_DWORDS;
+      Cand c[4];
+      eval_children<false, LDEXP>(q0, q1, q2, q3, ref_node, arx, ary, arz, aix, aiy, aiz, hitd, c);
+      order_children(c);
+      if (c[0].d < __builtin_inff()) {
+        bool more = true;
+        if (sp + 3u > (uint32_t)CAP) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
+        if (more && c[3].d < __builtin_inff()) push(c[3].desc, vmax_nonan(path_m, c[3].d));   // far first (:98-103)
+        if (more && c[2].d < __builtin_inff()) push(c[2].desc, vmax_nonan(path_m, c[2].d));
+        if (more && c[1].d < __builtin_inff()) push(c[1].desc, vmax_nonan(path_m, c[1].d));
+        cur = c[0].desc;
+        path_m = vmax_nonan(path_m, c[0].d);
+      } else pop_next();
+    }
+    // ================= leaf body: once enough lanes hold a leaf in either ray, or no lane has a node left =================
+    const unsigned long long leafm = __ballot(is_leaf_desc(cur) || is_leaf_desc(q_cur));
+    if (leafm != 0ull && ((uint32_t)__popcll(leafm) >= (uint32_t)RT_PAIR_LEAF_MIN ||
+                          __ballot(is_node_desc(cur) || is_node_desc(q_cur) || is_inst_desc(cur) || is_inst_desc(q_cur)) == 0ull)) {
+      if (!is_leaf_desc(cur) && is_leaf_desc(q_cur)) swap_rays();
+      if (is_leaf_desc(cur)) {
+        uint32_t leftFirst = cur & LEAF_FIRST_MASK, triCount = (cur >> LEAF_FIRST_BITS) & LEAF_MAX_INLINE;
+        if (triCount == 0u) { const uint32_t* rn = sc.ref_bvh + (size_t)leftFirst * RT_NODE_DWORDS; leftFirst = rn[4]; triCount = rn[5]; }
+        const float cdx = __uint_as_float(s_ctx[half][0][lane]), cdy = __uint_as_float(s_ctx[half][1][lane]), cdz = __uint_as_float(s_ctx[half][2][lane]);
+        const uint32_t blasIdx = s_ctx[half][3][lane];
+        bool stop = false;
+        float4 n0, n1, n2;
+        { const float4* tp0 = sc.tri_w + (size_t)leftFirst * 3; n0 = tp0[0]; n1 = tp0[1]; n2 = tp0[2]; }
+        for (uint32_t i = 0; i < triCount; ++i) {
+          const uint32_t triIdx = leftFirst + i;
+          const float4 t0 = n0, t1 = n1, t2 = n2;
+          if (i + 1u < triCount) { const float4* tn = sc.tri_w + (size_t)(triIdx + 1u) * 3; n0 = tn[0]; n1 = tn[1]; n2 = tn[2]; }
+          float bx, by, bz;
+          const float d = ray_tri(arx, ary, arz, cdx, cdy, cdz, t0, t1, t2, bx, by, bz);
+          if (d < hitd) {
+            hitd = d;
+            flags |= F_FOUND;
+            HitRec hr; hr.dist = d; hr.bx = bx; hr.by = by; hr.bz = 1 - bx - by; hr.blasIdx = blasIdx; hr.triIdx = triIdx;   // rt_traversal.cpp:311-313
+            A.hits[job] = hr;                          // the record of the best hit so far: the last accept stands
+            if (flags & F_ANYHIT) { stop = true; break; }
+            if (!(path_m < hitd)) break;               // the reference abandons this subtree
+          }
+        }
+        if (stop) { sp = 0; cur = DESC_DONE; } else pop_next();
+      }
+    }
+  }
+#undef PSWAPF
   if (A.counters) {
     unsigned s = nrays;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
@@ -2567,6 +2833,7 @@ struct vxrt_accel {
   uint32_t ap_count = 0, ap_key[6] = {0, 0, 0, 0, 0, 0};
   uint64_t ap_cap = 0;
   float max_reflectivity = 0.0f;   // over the instance records: > 0 enables the mirror-bounce path
+  unsigned long long* trace_wave_log = nullptr;   // diagnostic (vxrt_debug_trace_wave_log): per-wavefront log of the counting build's ray-buffer launches
   unsigned long long* end_log = nullptr;   // diagnostic (vxrt_debug_end_log): where the main launches leave their wavefronts' end times
   uint32_t levels = 0;             // internal levels on the longest root-to-leaf path (TLAS + BLAS), counted up to RT_SHALLOW_LEVELS + 1
   bool shallow = false;            // levels <= RT_SHALLOW_LEVELS: the timed launches take the SHALLOW instantiations
@@ -2843,6 +3110,7 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   A.end_log = a->end_log;
   A.order = order;
   A.counters = stats_counters;
+  A.wave_log = stats_counters ? a->trace_wave_log : nullptr;
   A.status = st;
   A.per_shard = ((A.total + QUEUE_SHARDS - 1) / QUEUE_SHARDS + 63u) & ~63u;
   if (ensure_defer(c, A.total, s) != 0) return -1;
@@ -2861,7 +3129,16 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   ShadeParams p{};
   // incoherent rays: the ray-pool kernel (rt_pool_trace_kernel; VXRT_POOL=0/1 forces the choice), timed builds only
   static const int pool_env = [] { const char* e = getenv("VXRT_POOL"); return e ? atoi(e) : 0; }();
-  if (pool_env > 0 && !stats_counters) {
+  if (pool_env == 2 && !stats_counters) {     // two rays per lane (rt_pair_trace_kernel)
+#define LAUNCH_PAIR(LD, SH) do { \
+      hipLaunchKernelGGL((rt_pair_trace_kernel<LD, SH>), dim3(persistent_grid(rt_pair_trace_kernel<LD, SH>, n / 2, 64)), dim3(64), 0, s, a->dev, A); \
+      hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, 0, LD, true>), dim3(std::max<uint32_t>(EXACT_GRID, persistent_grid(rt_persistent_kernel<JOB_TRACE, 0, LD, true>, n / 8, 256))), dim3(256), 0, s, a->dev, p, X); } while (0)
+    if (a->shallow) { if (a->dev.exact_decode) LAUNCH_PAIR(true, true); else LAUNCH_PAIR(false, true); }
+    else            { if (a->dev.exact_decode) LAUNCH_PAIR(true, false); else LAUNCH_PAIR(false, false); }
+#undef LAUNCH_PAIR
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+  if (pool_env == 1 && !stats_counters) {
 #define LAUNCH_POOL(LD, SH) do { \
       const uint32_t g = persistent_grid(rt_pool_trace_kernel<LD, SH>, n, 64); \
       const uint64_t need = (uint64_t)g * RT_POOL_SLOTS * ((SH ? 3 * RT_SHALLOW_LEVELS : 3 * RT_MAX_LEVELS + RT_POOL_LSTK) - RT_POOL_LSTK) * sizeof(uint2); \
@@ -3520,6 +3797,14 @@ int vxrt_wire_unpack(const uint8_t* wire_all, uint64_t wire_stride_bytes, uint32
   hipLaunchKernelGGL(wire_unpack_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)wire_all, wire_stride_bytes / 4u, width / 4u, per, world,
                      per_rank, frames, frame_stride);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// diagnostic (tools/trace_phases.py): the counting build's ray-buffer launches (vxrt_trace_stats) keep vxrt_render_wave_log's 16 u64 per wavefront in
+// `log` from now on (device memory, 16 x 8,192 u64; nullptr: off) -- loop iterations, runs of the node / leaf body and the lanes active in them
+int vxrt_debug_trace_wave_log(vxrt_accel_t* a, unsigned long long* log) {
+  if (!a) return -1;
+  a->trace_wave_log = log;
+  return 0;
 }
 
 int vxrt_debug_end_log(vxrt_accel_t* a, unsigned long long* log) {
