@@ -16,7 +16,7 @@ trace, pmcs = args[0], args[1:]
 
 
 def short(n):
-    m = re.search(r"rt_persistent_kernel<(\d), (\d), (true|false), (true|false)(, (true|false))?>", n)   # <JOB, STATS, LDEXP, EXACT, PACKED>
+    m = re.search(r"rt_persistent_kernel<(\d), (\d), (true|false), (true|false)(, (true|false))?(, (true|false))?>", n)   # <JOB, STATS, LDEXP, EXACT, PACKED, SHALLOW>
     if m:
         return None if m.group(4) == "true" else "rt_persistent_kernel<%s, %s, %s, false, %s>" % (m.group(1), m.group(2), m.group(3), m.group(6) or "false")   # (EXACT launches: a handful of rays)
     if "rc_persistent_kernel" in n:

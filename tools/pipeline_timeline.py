@@ -9,7 +9,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[-n:]
 t0 = int(rows[0]["Start_Timestamp"])
 def short(name):
-    m = re.search(r"rt_persistent_kernel<(\d), (\d), (\w+), (\w+)>", name)
+    m = re.search(r"rt_persistent_kernel<(\d), (\d), (\w+), (\w+)[,>]", name)
     if m:
         return ("EXACT " if m.group(4) == "true" else "MAIN  ") + "job%s" % m.group(1)
     m = re.search(r"(\w+_kernel|\w+)(<|\()", name)

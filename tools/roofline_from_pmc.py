@@ -48,7 +48,7 @@ for line in open(summary):
 step = {k: v for k, v in data.items() if re.search(r"rt_persistent_kernel<1, (0|false), ", k) or "rt_shade_kernel<false>" in k}
 # (the main launch: not EXACT; the instantiation the summary was taken with -- tools/pmc_passes.sh forces the PACKED one, which is what
 # the default bench times)
-mains = [k for k in step if re.search(r"rt_persistent_kernel<1, (0|false), false, false(, (true|false|0|1))?>", k)]
+mains = [k for k in step if re.search(r"rt_persistent_kernel<1, (0|false), false, false(, (true|false|0|1))*>", k)]   # <JOB, STATS, LDEXP, EXACT[, PACKED[, SHALLOW]]>
 main = max(mains, key=lambda k: step[k].get("SQ_INSTS_VALU", 0.0) * step[k].get("_n_SQ_INSTS_VALU", 0))
 n_main = step[main]["_n_SQ_INSTS_VALU"]
 

@@ -12,7 +12,7 @@ groups = int(sys.argv[2])
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 import re
 # main launch of a frame job: rt_persistent_kernel<JOB 0|1, STATS 0, LDEXP, EXACT false, PACKED any>
-main = [r for r in rows if re.search(r"rt_persistent_kernel<[01], 0, (true|false), false(, (true|false))?>", r["Kernel_Name"])]
+main = [r for r in rows if re.search(r"rt_persistent_kernel<[01], 0, (true|false), false(, (true|false))*>", r["Kernel_Name"])]
 shade = [r for r in rows if "rt_shade_kernel<false>" in r["Kernel_Name"]]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 m, s = main[-groups:], shade[-groups:]
