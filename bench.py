@@ -537,15 +537,9 @@ def main():
                 raise SystemExit("bench.py: --sets must list set sizes of 1..32 frames that add up to --steps")
             B = max(set_sizes)
         elif a.batch <= 0 and a.steps >= 2 * world and world > 1:
-            # The last set's gather is what the end of the run exposes (every earlier one travels while the next set is traced), and a
-            # rank's share of a frame is 1/N of it: a last set of N frames puts ONE frame's bytes on each link -- 6.2 MB at 1080p, the same
-            # for every N -- and the steps before it go out in equal sets of at most 16.  20 steps: N = 8 -> 12 + 8, N = 4 -> 16 + 4,
-            # N = 2 -> 9 + 9 + 2.  Rehearsed (rank 0's pipeline without the network, profiles/r05_e_multi_gpu_schedules.txt): these cost
-            # the traversal 0..2 % against two equal sets; three and more sets at N = 8 cost 10 % and more.
-            head = a.steps - world
-            n_head = -(-head // 16)
-            per = -(-head // n_head)
-            set_sizes = [min(per, head - g) for g in range(0, head, per)] + [world]
+            # a last set of N frames (one frame's bytes per link whatever N is), the steps before it in equal sets of at most 16:
+            # sharding.auto_sets; what each schedule costs rank 0's pipeline is in profiles/r05_e_multi_gpu_schedules.txt
+            set_sizes = sharding.auto_sets(a.steps, world)
             B = max(set_sizes)
         ig = sharding.InterleavedGather(H, W, rank, world, dev, slots=n_frames, collective=not rehearse, batch=B, single_rank_collective=a.one_rank_group, wire=a.wire)
         frames = [ig.new_frame_buffer(dev) for _ in range(n_frames)]

@@ -108,6 +108,23 @@ def test_band_plans_cover_the_frame_and_balance_a_known_cost():
     assert sh.taper(20) == [10, 5, 2, 2, 1]
 
 
+def test_the_schedule_of_an_n_rank_run_ends_with_one_frames_bytes_per_link():
+    """bench.py --sets auto: the last set is N frames (a rank's share of a frame is 1/N of it: one frame's bytes per link whatever N is),
+    the steps before it go out in equal sets of at most 16; runs too short for that, and one rank, get equal sets."""
+    sh = _sharding()
+    assert sh.auto_sets(20, 8) == [12, 8] and sh.auto_sets(20, 4) == [16, 4] and sh.auto_sets(20, 2) == [9, 9, 2]
+    assert sh.auto_sets(200, 8) == [16] * 12 + [8] and sh.auto_sets(6, 2) == [4, 2] and sh.auto_sets(16, 8) == [8, 8]
+    assert sh.auto_sets(20, 1) == [10, 10] and sh.auto_sets(10, 8) == [5, 5] and sh.auto_sets(1, 4) == [1]
+    for steps in range(1, 70):
+        for world in (1, 2, 3, 4, 8):
+            sets = sh.auto_sets(steps, world)
+            assert sum(sets) == steps and min(sets) >= 1 and max(sets) <= max(16, world)
+            if world > 1 and steps >= 2 * world:
+                assert sets[-1] == world
+                ig = sh.InterleavedGather(1080, 1920, 0, world, "cpu", slots=1, collective=False, batch=1)
+                assert ig.wire_bytes(sets[-1]) == sets[-1] * sh.padded_share_rows(1080, world) * 1920 * 3      # = one padded frame's worth of rgb24
+
+
 def test_band_gather_places_every_band_without_a_copy_of_the_frame():
     """BandGather without the network: rank 0's buffer IS the final image, every other rank's buffer is its band alone, and the render
     target of a rank (pointer, frame stride) addresses its buffer like a full frame."""

@@ -282,6 +282,23 @@ def rebalance_bands(bounds, times, height, align=TILE, damping=1.0, min_rows=TIL
     return new
 
 
+def auto_sets(steps, world, max_set=16):
+    """Sizes of the sets of frames an N-rank run issues its `steps` timed frames in (bench.py --sets auto, tile rows interleaved over the
+    ranks).  Every set's gather travels while the next set is traced, except the LAST one's, which the end of the run exposes: the last set
+    is `world` frames -- a rank's share of a frame is 1/world of it, so that is ONE frame's bytes per link whatever the world size -- and
+    the steps before it go out in equal sets of at most `max_set`.  Runs too short for that (steps < 2 * world) and single ranks get
+    equal sets.  sum == steps; every size in 1..max(max_set, world)."""
+    steps, world = int(steps), int(world)
+    if world > 1 and steps >= 2 * world:
+        head = steps - world
+        n_head = -(-head // max_set)
+        per = -(-head // n_head)
+        return [min(per, head - g) for g in range(0, head, per)] + [world]
+    n_groups = max(2 if steps > 1 else 1, -(-steps // max_set))
+    per = -(-steps // n_groups)
+    return [min(per, steps - g) for g in range(0, steps, per)]
+
+
 def taper(steps, first_max=16, last=1, ratio=0.5):
     """Sizes of the sets of frames a run of `steps` frames is issued in when every set ends with a collective: large sets first
     (a rank's share of a frame is small against its GPU, many frames per launch keep it full), geometrically smaller ones towards
