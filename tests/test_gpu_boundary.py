@@ -34,6 +34,41 @@ def test_rtu_test_frame_through_vx_api(vrt, po, gpu_device):
     tr.close()
 
 
+def test_mcycle_is_the_runs_time_on_the_device(vrt, gpu_device):
+    """vx_mpm_query(MCYCLE) (stub/perf.cpp:195-227 divides by it) = the run's duration x the shader clock, and the duration is taken on the
+    device (first traversal launch's start -> the run's last kernel, 100 MHz clock): a host that sleeps between vx_start and vx_ready_wait
+    does not lengthen it, while the host-side clock of the same run (stat 6) does see the sleep.  Both kernels of the boundary: the RTU
+    frame and the software twin; a reference-quirks run has no device clock and reports the host's (stat 5)."""
+    import time
+    w, h = 320, 200
+    for twin in (False, True):
+        if twin:
+            tr = vrt.tracer.RaycastTracer(w, h)
+            tr.init(vrt.scene.rc_procedural("cornell"))
+            tr.setup(vrt.scene.rc_camera_like_rtu(w, h), (0.0, 10.0, -10.0, 1.0, 1.0, 1.0, 0.4, 0.4, 0.4, 0.4, 0.35, 0.25))
+        else:
+            tr = vrt.tracer.Tracer(w, h)
+            tr.init(vrt.scene.procedural("blob", 4, 0, 1))
+            tr.setup()
+        tr.run()                                         # (first run: layout build, code load)
+        d = tr.dev
+        n_dev0 = d.hip_stat(4)
+        d.start(tr.krnl, tr.args)
+        d.ready_wait(vrt.runtime.VX_MAX_TIMEOUT)
+        quick = d.mpm_query(vrt.runtime.VX_CSR_MCYCLE, 0)
+        d.start(tr.krnl, tr.args)
+        time.sleep(0.25)                                 # the host is busy elsewhere while the device runs and finishes
+        d.ready_wait(vrt.runtime.VX_MAX_TIMEOUT)
+        slept = d.mpm_query(vrt.runtime.VX_CSR_MCYCLE, 0)
+        host_us = d.hip_stat(6)
+        assert d.hip_stat(4) == n_dev0 + 2 and d.hip_stat(5) == 0
+        assert host_us >= 250000                          # the host's clock saw the sleep ...
+        assert quick > 0 and slept > 0
+        assert slept < 5 * 10**7                          # ... the device's did not: 250 ms at >= 1 GHz would be > 2.5e8 cycles
+        assert slept < 50 * quick                         # and the two runs of one frame took comparable time on the device
+        tr.close()
+
+
 def test_row_window_dcrs_shard_a_frame(vrt, po, gpu_device):
     """Backend extension DCRs 0x7F0/0x7F1: each 'rank' renders its row band; bands tile the frame."""
     sc = vrt.scene.procedural("cornell")
@@ -299,7 +334,9 @@ def test_reference_quirks_dcr_renders_what_the_rtu_would_on_this_address_space(v
     want_canon, _, _ = po.render(sc, w, h)
     assert np.array_equal(canon, want_canon)
     tr.dev.dcr_write(0x7F4, 1)
+    n_host0 = tr.dev.hip_stat(5)
     quirk = tr.run()
+    assert tr.dev.mpm_query(vrt.runtime.VX_CSR_MCYCLE, 0) > 0 and tr.dev.hip_stat(5) == n_host0 + 1   # (no device clock in this mode: the host's)
     tr.dev.dcr_write(0x7F4, 0)
     again = tr.run()
     assert np.array_equal(again, canon)             # the mode is a switch, nothing sticks

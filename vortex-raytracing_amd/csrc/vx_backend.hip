@@ -26,11 +26,16 @@ extern "C" uint32_t* vxrt_status_word_device(void);   // rt_kernels.hip
 
 // rays counter and status word of a run into host memory the device can write (see vx_device::enqueue_readback)
 // ... and clears the counter for the next run: a run is its own launches + this one.  (Rounds 2-3 opened a run with a fill of the counter and
-// an event record and closed it with a second event record -- three more packets on the stream, ~10 us each between a frame's launches; the
-// run's duration for MCYCLE is now taken on the host, from vx_start to the moment ready_wait sees the stream drained.)
-__global__ void vx_readback_kernel(unsigned long long* __restrict__ rays, const uint32_t* __restrict__ status, unsigned long long* __restrict__ host) {
+// an event record and closed it with a second event record -- three more packets on the stream, ~10 us each between a frame's launches.)
+// The run's clock (MCYCLE) is taken on the device without those packets: the first workgroup of each main traversal launch lowers *clock to
+// the constant 100 MHz clock at its start (vxrt_accel_run_clock); this kernel, the run's last, reads the same clock: host[2] = the earliest
+// start, host[3] = now, and *clock goes back to ~0 for the next run.  A run without such a launch (reference-quirks kernels) leaves ~0 in
+// host[2] and its duration is the host's (vx_start -> drained stream).
+__global__ void vx_readback_kernel(unsigned long long* __restrict__ rays, const uint32_t* __restrict__ status, unsigned long long* __restrict__ clock,
+                                   unsigned long long* __restrict__ host) {
   host[0] = *rays;
   host[1] = (unsigned long long)*status;
+  if (clock) { host[2] = *clock; host[3] = (unsigned long long)wall_clock64(); *clock = ~0ull; }
   *rays = 0ull;
   __threadfence_system();
 }
@@ -106,7 +111,10 @@ struct vx_device {
   std::vector<void*> slabs;
   std::vector<void*> free_slots;
   uint64_t n_accel_builds = 0, n_hip_mallocs = 0;   // vx_hip_device_stat
-  float last_ms = 0.f;
+  float last_ms = 0.f;                // the last run's duration: the device's clock when the run has one, else the host's
+  float last_host_ms = 0.f;           // vx_start -> the moment ready_wait saw the stream drained (vx_hip_device_stat 6, in us)
+  uint64_t n_dev_clock_runs = 0, n_host_clock_runs = 0;   // vx_hip_device_stat 4 / 5
+  unsigned long long* d_clock = nullptr;   // the run's clock on the device (vxrt_accel_run_clock)
   std::chrono::steady_clock::time_point t_begin{};   // vx_start of the pending run
   hipDeviceProp_t prop{};
   // acceleration layout of the scene last started, rebuilt only when one of the four traversal
@@ -145,6 +153,7 @@ struct vx_device {
     total_mem = prop.totalGlobalMem;
     if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
     if (hipMalloc((void**)&d_rays, sizeof(unsigned long long)) != hipSuccess || hipMemset(d_rays, 0, sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMalloc((void**)&d_clock, sizeof(unsigned long long)) != hipSuccess || hipMemset(d_clock, 0xFF, sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipHostMalloc((void**)&h_back, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return -1;
     if (hipHostMalloc((void**)&stage, kStageSlot * kStageSlots, hipHostMallocDefault) != hipSuccess) return -1;
     for (int i = 0; i < 8; ++i) h_back[i] = 0;
@@ -268,7 +277,7 @@ struct vx_device {
     uint32_t* st = vxrt_status_word_device();
     if (!st) return -1;
     h.h_back[1] = 0;
-    hipLaunchKernelGGL(vx_readback_kernel, dim3(1), dim3(1), 0, h.stream, h.d_rays, (const uint32_t*)st, h.h_back);
+    hipLaunchKernelGGL(vx_readback_kernel, dim3(1), dim3(1), 0, h.stream, h.d_rays, (const uint32_t*)st, (unsigned long long*)nullptr, h.h_back);
     if (hipGetLastError() != hipSuccess) return -1;
     return hipEventRecord(h.done, h.stream) == hipSuccess ? 0 : -1;
   }
@@ -284,6 +293,7 @@ struct vx_device {
     for (auto& kv : allocs) if (kv.second.dptr && !kv.second.pooled) (void)hipFree(kv.second.dptr);
     for (void* sl : slabs) (void)hipFree(sl);
     if (d_rays) (void)hipFree(d_rays);
+    if (d_clock) (void)hipFree(d_clock);
     if (q_image) (void)hipFree(q_image);
     if (q_rays) (void)hipFree(q_rays);
     if (q_hits) (void)hipFree(q_hits);
@@ -413,14 +423,20 @@ struct vx_device {
     uint32_t* st = vxrt_status_word_device();
     if (!st) return -1;
     h_back[1] = 0;
-    hipLaunchKernelGGL(vx_readback_kernel, dim3(1), dim3(1), 0, stream, d_rays, (const uint32_t*)st, h_back);
+    h_back[2] = ~0ull;
+    hipLaunchKernelGGL(vx_readback_kernel, dim3(1), dim3(1), 0, stream, d_rays, (const uint32_t*)st, d_clock, h_back);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
 
   void finish_run() {
     if (!run_pending) return;
     run_pending = false;
-    last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); have_timing = true;
+    last_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); have_timing = true;
+    // the device's own clock when the run left one (100 MHz ticks between the first main launch's start and the run's last kernel); a run
+    // split over several GPUs keeps the host's clock: it ends with copies between devices whose clocks are not one clock
+    const bool dev_clock = fanned <= 1 && h_back[2] != ~0ull && h_back[3] > h_back[2];
+    last_ms = dev_clock ? (float)((double)(h_back[3] - h_back[2]) * 1e-5) : last_host_ms;
+    ++(dev_clock ? n_dev_clock_runs : n_host_clock_runs);
     last_rays = h_back[0];   // copied back by the stream at the end of the run (enqueue_readback)
     if (fanned > 1) for (auto& h : helpers) last_rays += h.h_back[0];   // (their streams' events were joined by `stream` before its own readback)
   }
@@ -607,6 +623,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
     if (accel) { (void)vxrt_accel_destroy(accel); accel = nullptr; }
     ++n_accel_builds;
     if (vxrt_accel_build(&sc, stream, &accel) != 0) { VXLOG("start: scene rejected (malformed BVH: index out of range, wrong node kind or child not after parent)"); return -1; }
+    (void)vxrt_accel_run_clock(accel, d_clock);
     std::memcpy(accel_key, key, sizeof key);
   }
 
@@ -663,7 +680,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
     if (rc == 0) rc = vxrt_shade_rays(accel, (const float*)q_rays, (const vxrt_hit_t*)q_hits, nr, &sp, nullptr, dstp + (size_t)y0 * ka.dst_width, stream);
     h_back[4] = nr;   // (pinned; the stream reads it after this call returns)
     if (rc == 0 && hipMemcpyAsync(d_rays, &h_back[4], sizeof(unsigned long long), hipMemcpyHostToDevice, stream) != hipSuccess) rc = -1;
-    if (rc != 0) { VXLOG("start: reference-quirks launch rejected"); (void)hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream); return -1; }
+    if (rc != 0) { VXLOG("start: reference-quirks launch rejected"); (void)hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream); (void)hipMemsetAsync(d_clock, 0xFF, sizeof(unsigned long long), stream); return -1; }
     if (enqueue_readback() != 0) return -1;
     run_pending = true;
     return 0;
@@ -715,7 +732,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
       VXLOG("start: launch on %u devices rejected", n_dev);
       for (auto& h : helpers) { (void)hipSetDevice(h.hip_dev); (void)hipStreamSynchronize(h.stream); (void)hipMemsetAsync(h.d_rays, 0, sizeof(unsigned long long), h.stream); }
       (void)hipSetDevice(hip_dev);
-      (void)hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream);
+      (void)hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream); (void)hipMemsetAsync(d_clock, 0xFF, sizeof(unsigned long long), stream);
       return -1;
     }
     if (enqueue_readback() != 0) return -1;
@@ -730,7 +747,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
   else
     samples([&] { return vxrt_render(accel, ka.dst_width, ka.dst_height, y0, y1, &sp, (int)shadow, dstp, nullptr, nullptr, d_rays, stream); },
             [&](const vxrt_shade_params_t* pv, uint32_t n) { return vxrt_render_rows_batch(accel, ka.dst_width, ka.dst_height, y0, y1, n, pv, (int)shadow, dstp, 0, d_rays, stream); });
-  if (rc != 0) { VXLOG("start: launch rejected (shape check)"); (void)hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream); return -1; }
+  if (rc != 0) { VXLOG("start: launch rejected (shape check)"); (void)hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), stream); (void)hipMemsetAsync(d_clock, 0xFF, sizeof(unsigned long long), stream); return -1; }
   if (enqueue_readback() != 0) return -1;
   run_pending = true;
   return 0;
@@ -800,6 +817,7 @@ int vx_device::start_raycast(uint64_t args_va) {
     if (rc_accel) { (void)vxrc_accel_destroy(rc_accel); rc_accel = nullptr; }
     ++n_accel_builds;
     if (vxrc_accel_build(&sc, stream, &rc_accel) != 0) { VXLOG("start: raycast scene rejected (malformed BVH2: child / triangle index out of range or child not after parent)"); return -1; }
+    (void)vxrc_accel_run_clock(rc_accel, d_clock);
     std::memcpy(rc_key, key, sizeof key);
   }
   t_begin = std::chrono::steady_clock::now();
@@ -860,6 +878,9 @@ extern "C" int vx_hip_device_stat(vx_device_h hdevice, uint32_t which, uint64_t*
   case 1: *value = d->n_hip_mallocs; return 0;
   case 2: *value = d->n_fanned_runs; return 0;          // runs split over the devices of VORTEX_HIP_DEVICES
   case 3: *value = d->helpers.size() + 1; return 0;     // devices behind this vx_device
+  case 4: *value = d->n_dev_clock_runs; return 0;       // joined runs whose MCYCLE came from the device's clock
+  case 5: *value = d->n_host_clock_runs; return 0;      // ... from the host's (reference-quirks runs, runs split over several GPUs)
+  case 6: *value = (uint64_t)((double)d->last_host_ms * 1e3); return 0;   // the last joined run on the HOST's clock, microseconds
   }
   return -1;
 }

@@ -113,7 +113,8 @@ class Device:
             self.handle = None
 
     def hip_stat(self, which):
-        """vx_hip_device_stat: 0 = acceleration layouts built, 1 = hipMalloc calls for buffers, 2 = runs split over several GPUs, 3 = GPUs behind the device"""
+        """vx_hip_device_stat: 0 = acceleration layouts built, 1 = hipMalloc calls for buffers, 2 = runs split over several GPUs, 3 = GPUs behind the device,
+        4 / 5 = joined runs whose MCYCLE came from the device's clock / the host's, 6 = the last joined run on the host's clock (us)"""
         v = C.c_uint64()
         check(hip_lib().vx_hip_device_stat(self.handle, which, C.byref(v)), "vx_hip_device_stat")
         return int(v.value)
