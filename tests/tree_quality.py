@@ -61,7 +61,9 @@ def gpu_rate(scene_or_ds, w, h, light, frames=40):
     ms = (time.time() - t0) / frames * 1e3
     st = vrt.rtapi.render_stats(ds.accel, w, h, 0, h, p, px.data_ptr(), 1, s)
     out = {"mrays_s_serial": round(rays / ms / 1e3, 1), "ms_per_frame": round(ms, 4), "frame_node_fetches_per_ray": round(st["node_fetches"] / st["rays"], 3),
-           "frame_tri_fetches_per_ray": round(st["tri_fetches"] / st["rays"], 3), "pixels_crc": int(px.to(torch.int64).sum().item())}
+           "frame_tri_fetches_per_ray": round(st["tri_fetches"] / st["rays"], 3), "pixels_crc": int(px.to(torch.int64).sum().item()),
+           "accel_info_levels_shallow_ident_ldexp": [vrt.rtapi.accel_info(ds.accel, k) for k in range(4)],
+           "frame_stats": {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in st.items() if isinstance(v, (int, float, np.integer, np.floating))}}
     ds.close()
     return out
 

@@ -3,7 +3,7 @@
 // Reference: tests/regression/raytracing/bvh.cpp:30-264 -- BVH::build (binned SAH, binary), the collapse to 4-wide nodes and
 // the quantiser, all host code run once per mesh at scene load; triangles are reordered in place so that a leaf is a range
 // (bvh.cpp:126-128).  csrc/scene_builder.cpp is this package's CPU counterpart (threaded SAH, the quality builder).  This file
-// is the builder for geometry that changes per frame: some sixty short launches over data that never leaves HBM.
+// is the builder for geometry that changes per frame: some hundred and fifty short launches over data that never leaves HBM.
 //
 //   1. centroid bounds              one pass, wavefront reduction + 6 atomics per workgroup
 //   2. 63-bit Morton keys           21 bits per axis of the triangle's box centre (extended order)
@@ -12,6 +12,10 @@
 //                                   the Morton order" (nearest = smallest surface area of the union), boxes and the SAH dynamic
 //                                   programme of the 4-wide collapse computed as the nodes are made; the last 1,024 clusters in
 //                                   one workgroup.  (Rounds 1-2: Karras' binary radix tree + a bottom-up box pass.)
+//   4b. the binary tree optimised by parallel reinsertion (round 5; Meister & Bittner 2018): four iterations of "every node looks for the
+//      place where it would cost least, the largest gains that do not touch each other's links are applied, boxes refitted bottom-up",
+//      the last refit recomputing the dynamic programme.  6.7 ms per million triangles in all against 1.5 ms without; the headline
+//      frame on the tree 8.4 Grays/s against 7.95 (the CPU builder's optimised tree: 8.8).  VXRT_BVH_REINSERT=0 switches it off.
 //   5. collapse to 4-wide + quantise + emit, level by level, following the dynamic programme's choices; every child gets its
 //      range of the final triangle order from its parent; a subtree marked as a leaf (<= leaf_max triangles, and cheaper as
 //      a leaf) lists its triangles there.  Children are allocated after their parent, which is what vxrt_accel_build's
@@ -40,6 +44,14 @@
 
 namespace {
 
+constexpr int BB_RI_MAX_ITERS = 32;  // reinsertion iterations at most (step 4b)
+constexpr int BB_RI_LISTS = 512;     // heights the refit of step 4b follows (a binary tree deeper than that is reported, not emitted)
+#ifndef BB_CHILD_ORDER
+#define BB_CHILD_ORDER 0
+#endif
+#ifndef BB_RI_ITERS
+#define BB_RI_ITERS 4
+#endif
 constexpr int BB_MAX_LEVELS = 34;   // launches of the collapse pass; a tree deeper than RT_MAX_LEVELS is reported, not emitted half-way
 
 struct Box3 { float lx, ly, lz, hx, hy, hz; };
@@ -471,6 +483,281 @@ __global__ __launch_bounds__(1024) void bb_ploc_tail_kernel(const Cluster* __res
   if (threadIdx.x == 0) { st[ST_N] = (uint32_t)m; st[ST_NEXT] = next; st[ST_FORCED] = forced ? 1u : 0u; st[ST_ROUNDS] = rounds; }
 }
 
+// ---- 4b. the binary tree optimised by reinsertion, every node at once ----
+// (Meister & Bittner, "Parallel reinsertion for bounding volume hierarchy optimization", 2018; csrc/scene_builder.cpp runs the serial form
+// of Bittner et al. 2013 on the CPU tree.)  One iteration:
+//   search   every node `in` (not the root, not a child of the root) looks for the node `out` next to which it would cost least: cut out
+//            together with its parent p (p's other child takes p's place), p re-used as the new parent of (out, in).  The gain is what the
+//            cut saves -- p's area and the shrinking of the ancestors below the common ancestor ("pivot") -- minus what the insertion adds:
+//            area(out + in) and the growth of out's ancestors below the pivot.  The walk goes up from p pivot by pivot and searches the
+//            subtree on the other side of each with branch and bound (a subtree whose best case cannot beat the best gain so far is left).
+//   lock     a node with a positive gain claims the six nodes whose child / parent links its move rewrites (in, p, p's other child, p's
+//            parent, out, out's parent) with atomicMax of (gain, in): the larger gain wins a contested node, nothing depends on timing.
+//   resolve  a claimant that holds all six is a winner -- unless an ancestor of its `out` is a winner with a larger key: two disjoint
+//            subtrees that each move into the other would close a cycle cut off from the root; of any such ring the member below
+//            the largest key stands back, so no ring closes.
+//   apply    winners rewrite their links (disjoint by the locks).
+//   refit    boxes bottom-up (one thread per leaf walks up; the second to arrive at a node computes it); the last refit also recomputes
+//            the counts and the dynamic programme of step 4 for the collapse.
+// Node ids keep their classes (root 0, internal < n-1, leaves >= n-1): a move re-uses p.
+constexpr int BB_RI_STACK = 48;
+constexpr uint32_t BB_NONE = 0xffffffffu;
+
+struct RiArgs {
+  BNode* rec;
+  uint32_t* parent;               // 2n-1
+  unsigned long long* lock;       // 2n-1: (gain bits << 32) | claimant
+  unsigned long long* best;       // 2n-1: (gain bits << 32) | out; 0 = no move
+  uint8_t* win0; uint8_t* win;    // 2n-1 each
+  uint32_t* arrived;              // n-1: refit counters
+  uint32_t* moves;                // [it]: moves applied in iteration it
+  uint32_t n;                     // triangles
+  uint32_t it, mod;
+  uint32_t leaf_max; float tri_cost;
+};
+
+__device__ __forceinline__ void ri_load(const BNode* __restrict__ rec, uint32_t id, Box3& b, uint32_t& l, uint32_t& r) {
+  const float4* q = (const float4*)(rec + id);
+  const float4 a = q[0], c = q[1];
+  b.lx = a.x; b.ly = a.y; b.lz = a.z; l = __float_as_uint(a.w);
+  b.hx = c.x; b.hy = c.y; b.hz = c.z; r = __float_as_uint(c.w);
+}
+__device__ __forceinline__ float ri_area(const Box3& b) { return box_area(b.lx, b.ly, b.lz, b.hx, b.hy, b.hz); }
+__device__ __forceinline__ Box3 ri_union(const Box3& a, const Box3& b) {
+  Box3 u;
+  u.lx = fminf(a.lx, b.lx); u.ly = fminf(a.ly, b.ly); u.lz = fminf(a.lz, b.lz);
+  u.hx = fmaxf(a.hx, b.hx); u.hy = fmaxf(a.hy, b.hy); u.hz = fmaxf(a.hz, b.hz);
+  return u;
+}
+
+__global__ __launch_bounds__(256) void bb_ri_parents_kernel(RiArgs A) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) A.parent[0] = BB_NONE;
+  if (i >= A.n - 1u) return;
+  const float4* q = (const float4*)(A.rec + i);
+  A.parent[__float_as_uint(q[0].w)] = i;
+  A.parent[__float_as_uint(q[1].w)] = i;
+}
+
+__global__ __launch_bounds__(256) void bb_ri_search_kernel(RiArgs A) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_nodes = 2u * A.n - 1u;
+  if (x >= n_nodes) return;
+  A.lock[x] = 0ull;
+  unsigned long long res = 0ull;
+  const uint32_t p = x ? A.parent[x] : 0u;
+  if (x != 0u && p != 0u && (A.mod <= 1u || x % A.mod == A.it % A.mod)) {
+    Box3 bi; uint32_t t0, t1;
+    ri_load(A.rec, x, bi, t0, t1);
+    const float a_in = ri_area(bi);
+    Box3 bp; uint32_t pl, pr;
+    ri_load(A.rec, p, bp, pl, pr);
+    float d_rem = ri_area(bp);        // saved by the cut so far: p itself, then the shrinking of the path below the pivot
+    float best = 0.0f; uint32_t best_out = BB_NONE;
+    uint32_t sn[BB_RI_STACK]; float si[BB_RI_STACK];
+    uint32_t prev = x, pivot = p, pvl = pl, pvr = pr;
+    Box3 pbox = bp;                   // the pivot's box as it is
+    Box3 path; bool have_path = false;   // the box of the path's node below the pivot after the cut
+    for (;;) {
+      const uint32_t sib = pvl == prev ? pvr : pvl;
+      Box3 bs; uint32_t sl, sr;
+      ri_load(A.rec, sib, bs, sl, sr);
+      // the subtree on the other side of the pivot
+      if (d_rem - a_in > best) {
+        int sp = 0;
+        uint32_t node = sib; float ind = 0.0f; Box3 bn = bs; uint32_t nl = sl, nr = sr;
+        for (;;) {
+          const float direct = ri_area(ri_union(bn, bi));
+          const float gain = d_rem - ind - direct;
+          if (gain > best && !(pivot == p && node == sib)) { best = gain; best_out = node; }   // (next to its own sibling: where it is)
+          const float ind2 = ind + direct - ri_area(bn);
+          if (nl != BB_NONE && d_rem - ind2 - a_in > best) {
+            if (sp < BB_RI_STACK) { sn[sp] = nr; si[sp] = ind2; ++sp; }
+            node = nl; ind = ind2;
+            ri_load(A.rec, node, bn, nl, nr);
+            continue;
+          }
+          bool got = false;
+          while (sp > 0) {
+            --sp;
+            if (d_rem - si[sp] - a_in > best) { node = sn[sp]; ind = si[sp]; got = true; break; }
+          }
+          if (!got) break;
+          ri_load(A.rec, node, bn, nl, nr);
+        }
+      }
+      // one level up: the pivot becomes part of the path
+      const Box3 shrunk = have_path ? ri_union(path, bs) : bs;   // (p itself is replaced by its other child)
+      if (pivot != p) d_rem += ri_area(pbox) - ri_area(shrunk);
+      path = shrunk; have_path = true;
+      prev = pivot;
+      pivot = A.parent[pivot];
+      if (pivot == BB_NONE) break;
+      ri_load(A.rec, pivot, pbox, pvl, pvr);
+    }
+    if (best_out != BB_NONE && best > 0.0f) res = ((unsigned long long)__float_as_uint(best) << 32) | best_out;
+  }
+  A.best[x] = res;
+}
+
+// the six nodes whose links the move of x rewrites
+struct RiMove { uint32_t p, sib, gp, out, po; };
+__device__ __forceinline__ RiMove ri_move(const RiArgs& A, uint32_t x, unsigned long long b) {
+  RiMove m;
+  m.p = A.parent[x];
+  const float4* q = (const float4*)(A.rec + m.p);
+  const uint32_t l = __float_as_uint(q[0].w), r = __float_as_uint(q[1].w);
+  m.sib = l == x ? r : l;
+  m.gp = A.parent[m.p];
+  m.out = (uint32_t)b;
+  m.po = A.parent[m.out];
+  return m;
+}
+
+__global__ __launch_bounds__(256) void bb_ri_lock_kernel(RiArgs A) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= 2u * A.n - 1u) return;
+  const unsigned long long b = A.best[x];
+  if (A.moves) { const unsigned long long want = __ballot(b != 0ull); if ((threadIdx.x & 63u) == 0u && want) atomicAdd(A.moves + BB_RI_MAX_ITERS + A.it, (uint32_t)__popcll(want)); }
+  if (!b) return;
+  const RiMove m = ri_move(A, x, b);
+  const unsigned long long key = (b & 0xffffffff00000000ull) | x;
+  atomicMax(A.lock + x, key); atomicMax(A.lock + m.p, key); atomicMax(A.lock + m.sib, key);
+  atomicMax(A.lock + m.gp, key); atomicMax(A.lock + m.out, key); atomicMax(A.lock + m.po, key);
+}
+
+__global__ __launch_bounds__(256) void bb_ri_resolve_kernel(RiArgs A, int pass) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= 2u * A.n - 1u) return;
+  const unsigned long long b = A.best[x];
+  if (pass == 0) {
+    bool w = false;
+    if (b) {
+      const RiMove m = ri_move(A, x, b);
+      const unsigned long long key = (b & 0xffffffff00000000ull) | x;
+      w = A.lock[x] == key && A.lock[m.p] == key && A.lock[m.sib] == key && A.lock[m.gp] == key && A.lock[m.out] == key && A.lock[m.po] == key;
+    }
+    A.win0[x] = w ? 1 : 0;
+    return;
+  }
+  bool w = A.win0[x] != 0;
+  if (w) {
+    const unsigned long long key = (b & 0xffffffff00000000ull) | x;
+    for (uint32_t a = A.parent[(uint32_t)b]; a != BB_NONE; a = A.parent[a])
+      if (A.win0[a] && ((A.best[a] & 0xffffffff00000000ull) | a) > key) { w = false; break; }
+  }
+  A.win[x] = w ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void bb_ri_apply_kernel(RiArgs A) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool w = x < 2u * A.n - 1u && A.win[x] != 0;
+  if (w) {
+    const RiMove m = ri_move(A, x, A.best[x]);
+    uint32_t* g = (uint32_t*)(A.rec + m.gp);            // words 3 / 7: left / right
+    if (g[3] == m.p) g[3] = m.sib; else g[7] = m.sib;
+    A.parent[m.sib] = m.gp;
+    uint32_t* o = (uint32_t*)(A.rec + m.po);            // (po may be gp: read after the write above)
+    if (o[3] == m.out) o[3] = m.p; else o[7] = m.p;
+    A.parent[m.p] = m.po;
+    uint32_t* pp = (uint32_t*)(A.rec + m.p);
+    pp[3] = m.out; pp[7] = x;
+    A.parent[m.out] = m.p;
+  }
+  const unsigned long long any = __ballot(w);
+  if (A.moves && (threadIdx.x & 63u) == 0u && any) atomicAdd(A.moves + A.it, (uint32_t)__popcll(any));   // (VXRT_BVH_VERBOSE only: 25,000 atomics on one word cost 0.15 ms)
+}
+
+// Refit, bottom-up by height: list k holds the nodes whose two children are done after pass k-1 (a node is put on a list by the second of
+// its children to finish: one atomic counter per node).  Children are computed in an earlier LAUNCH than their parent -- the kernel boundary
+// is what makes their boxes visible (device-scope fences inside one walk-up kernel cost 5.8 ms per refit of a million triangles: an L2
+// write-back per step).  The first passes are launches of their own; once the lists are short one workgroup finishes all remaining heights
+// with workgroup barriers between them.  FULL: counts and the dynamic programme of step 4 as well as the boxes.
+__device__ __forceinline__ void ri_append(uint32_t* __restrict__ list, uint32_t* __restrict__ count, bool ready, uint32_t node) {
+  const unsigned long long m = __ballot(ready);
+  if (!m) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  if (ready) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = node;
+}
+
+__global__ __launch_bounds__(256) void bb_ri_refit_leaves_kernel(RiArgs A, uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t p = BB_NONE; bool ready = false;
+  if (j < A.n) {
+    p = A.parent[A.n - 1u + j];
+    if (p != BB_NONE) ready = atomicAdd(A.arrived + p, 1u) == 1u;
+  }
+  ri_append(out, counts, ready, p);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void ri_refit_node(const RiArgs& A, uint32_t cur) {
+  const float4* me = (const float4*)(A.rec + cur);
+  const uint32_t l = __float_as_uint(me[0].w), r = __float_as_uint(me[1].w);
+  const float4* pl = (const float4*)(A.rec + l);
+  const float4* pr = (const float4*)(A.rec + r);
+  if (FULL) {
+    const float4 a0 = pl[0], a1 = pl[1], a2 = pl[2], a3 = pl[3], b0 = pr[0], b1 = pr[1], b2 = pr[2], b3 = pr[3];
+    Cluster a, b;
+    a.lx = a0.x; a.ly = a0.y; a.lz = a0.z; a.hx = a1.x; a.hy = a1.y; a.hz = a1.z; a.f1 = a2.x; a.f2 = a2.y; a.f3 = a2.z; a.f4 = a2.w; a.count = __float_as_uint(a3.x); a.id = l;
+    b.lx = b0.x; b.ly = b0.y; b.lz = b0.z; b.hx = b1.x; b.hy = b1.y; b.hz = b1.z; b.f1 = b2.x; b.f2 = b2.y; b.f3 = b2.z; b.f4 = b2.w; b.count = __float_as_uint(b3.x); b.id = r;
+    uint32_t plan;
+    const Cluster c = bb_merge(a, b, cur, A.leaf_max, A.tri_cost, plan);
+    bb_store_node(A.rec, c, l, r, plan);
+  } else {
+    const float4 a0 = pl[0], a1 = pl[1], b0 = pr[0], b1 = pr[1];
+    float4* o = (float4*)(A.rec + cur);
+    o[0] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), __uint_as_float(l));
+    o[1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), __uint_as_float(r));
+  }
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(256) void bb_ri_refit_pass_kernel(RiArgs A, const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
+  const uint32_t m = counts[0];
+  for (uint32_t base = blockIdx.x * blockDim.x; base < m; base += gridDim.x * blockDim.x) {   // (whole wavefronts run every iteration: ri_append votes)
+    const uint32_t i = base + threadIdx.x;
+    uint32_t p = BB_NONE; bool ready = false;
+    if (i < m) {
+      const uint32_t cur = in[i];
+      ri_refit_node<FULL>(A, cur);
+      p = A.parent[cur];
+      if (p != BB_NONE) ready = atomicAdd(A.arrived + p, 1u) == 1u;
+    }
+    ri_append(out, counts + 1, ready, p);
+  }
+}
+
+// all remaining heights in one workgroup; lists alternate between the two buffers; counts[k] = length of list k
+template <bool FULL>
+__global__ __launch_bounds__(1024) void bb_ri_refit_tail_kernel(RiArgs A, uint32_t* __restrict__ l0, uint32_t* __restrict__ l1, uint32_t* __restrict__ counts, uint32_t first, uint32_t max_lists) {
+  uint32_t k = first;
+  for (;;) {
+    const uint32_t m = counts[k];
+    if (m == 0u || k + 1u >= max_lists) break;     // (every thread reads the same value: counts[k] was complete at the last barrier)
+    const uint32_t* in = (k & 1u) ? l1 : l0;
+    uint32_t* out = (k & 1u) ? l0 : l1;
+    for (uint32_t base = 0; base < m; base += blockDim.x) {
+      const uint32_t i = base + threadIdx.x;
+      uint32_t p = BB_NONE; bool ready = false;
+      if (i < m) {
+        const uint32_t cur = in[i];
+        ri_refit_node<FULL>(A, cur);
+        p = A.parent[cur];
+        if (p != BB_NONE) ready = atomicAdd(A.arrived + p, 1u) == 1u;
+      }
+      ri_append(out, counts + k + 1u, ready, p);
+    }
+    __threadfence_block();
+    __syncthreads();
+    ++k;
+  }
+}
+
 // ---- 5. collapse + quantise + emit ----
 // smallest e with extent / 255 <= 2^e (bvh.cpp:215-264 picks ceil(log2(extent / 255))), from the float's own exponent: exact
 __device__ __forceinline__ int bb_pick_exp(float extent) {
@@ -507,6 +794,7 @@ struct CollapseArgs {
   uint32_t level;
   const uint32_t* vals;     // sorted position -> primitive
   uint32_t* order;          // BLAS build: final position -> primitive (the gather's index); nullptr = TLAS build (a leaf names its instance)
+  uint32_t child_order;     // 0: slots as the binary tree hands them out, 1: largest surface area first, 2: smallest first
 };
 
 struct BRec { Box3 box; uint32_t left, right, count, plan; };
@@ -627,6 +915,21 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
         }
       }
     }
+    // slot order = the order in which the frame's occlusion rays visit the children (any-hit, rt_kernels.hip: slot order, no sorting by
+    // distance): largest surface area first (Nah & Manocha, "SATO: surface area traversal order for shadow ray tracing", 2014) -- the
+    // child most likely to hold an occluder is tried first.  Closest-hit rays sort by distance; for them the slot order only decides ties.
+    if (A.child_order != 0u) {
+      float key[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float ar = box_area(cr[k].box.lx, cr[k].box.ly, cr[k].box.lz, cr[k].box.hx, cr[k].box.hy, cr[k].box.hz);
+        key[k] = (uint32_t)k < nc ? (A.child_order == 1u ? ar : -ar) : -__builtin_inff();
+      }
+#define BB_CSWAP(i, j) do { if (key[j] > key[i]) { const float tk = key[i]; key[i] = key[j]; key[j] = tk; const uint32_t tc = c[i]; c[i] = c[j]; c[j] = tc; \
+        const uint32_t ts = slots[i]; slots[i] = slots[j]; slots[j] = ts; const BRec tr = cr[i]; cr[i] = cr[j]; cr[j] = tr; } } while (0)
+      BB_CSWAP(0, 1); BB_CSWAP(2, 3); BB_CSWAP(0, 2); BB_CSWAP(1, 3); BB_CSWAP(1, 2);
+#undef BB_CSWAP
+    }
     uint32_t ni = 0, nl = 0, lmax = 0;   // children that go on: internal ones; leaves among them and their largest
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -731,7 +1034,7 @@ __global__ __launch_bounds__(256) void bb_gather_kernel(const uint32_t* __restri
 // hipMalloc / hipFree pairs per build); vxrt_bvh_release_scratch() returns it.
 struct Arena {
   void* base = nullptr; size_t cap = 0; size_t used = 0; int dev = -1;
-  uint32_t* pinned = nullptr;   // 128 host words for the read-backs (cluster count between chunks of rounds, counters at the end)
+  uint32_t* pinned = nullptr;   // 256 host words for the read-backs (cluster count between chunks of rounds, counters at the end)
   template <class T> T* get(size_t count) {
     const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
     if (used + bytes > cap) return nullptr;
@@ -747,7 +1050,7 @@ bool arena_reserve(size_t bytes) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (g_arena.base && (g_arena.dev != dev || g_arena.cap < bytes)) { (void)hipFree(g_arena.base); g_arena.base = nullptr; g_arena.cap = 0; }
-  if (!g_arena.pinned && hipHostMalloc((void**)&g_arena.pinned, 128 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { g_arena.pinned = nullptr; return false; }
+  if (!g_arena.pinned && hipHostMalloc((void**)&g_arena.pinned, 256 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { g_arena.pinned = nullptr; return false; }
   if (!g_arena.base) {
     if (hipMalloc(&g_arena.base, bytes) != hipSuccess) { g_arena.base = nullptr; g_arena.cap = 0; return false; }
     g_arena.cap = bytes; g_arena.dev = dev;
@@ -768,11 +1071,11 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   hipStream_t s = (hipStream_t)stream;
   const uint32_t n = n_tris;
   std::lock_guard<std::mutex> lk(g_arena_mu);   // (builds on one device are serialised on the scratch arena)
-  const uint32_t n_counters = 8 + BB_MAX_LEVELS + 2;
+  const uint32_t n_counters = 8 + BB_MAX_LEVELS + 2 + 2 * BB_RI_MAX_ITERS;   // (... then, VXRT_BVH_VERBOSE: the moves of each reinsertion iteration and the nodes that wanted one)
   size_t tmp_bytes = 0;
   if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0u, 63u, s) != hipSuccess) return -1;
   const uint32_t blocks = (n + 255u) / 256u;
-  const size_t per_tri = 2 * 8 + 2 * 4 + 2 * sizeof(BNode) + 2 * sizeof(Cluster) + 1 + 2 * 16 + 4 + (d_triEx ? 64 : 36);
+  const size_t per_tri = 2 * 8 + 2 * 4 + 2 * sizeof(BNode) + 2 * sizeof(Cluster) + 1 + 2 * 16 + 4 + (d_triEx ? 64 : 36) + (2 * 4 + 2 * 8 + 2 * 8 + 4 + 4);
   if (!arena_reserve((size_t)n * per_tri + (size_t)blocks * 16 + tmp_bytes + 64 * 1024)) return -1;
   Arena& sc = g_arena;
   int* cb = sc.get<int>(8);
@@ -793,9 +1096,14 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   uint4* q1 = sc.get<uint4>(n);
   uint32_t* order = sc.get<uint32_t>(n);
   uint32_t* gather = sc.get<uint32_t>((size_t)n * (d_triEx ? 16 : 9));
+  uint32_t* ri_parent = sc.get<uint32_t>(2 * (size_t)n);
+  unsigned long long* ri_lock = sc.get<unsigned long long>(2 * (size_t)n);
+  unsigned long long* ri_best = sc.get<unsigned long long>(2 * (size_t)n);
+  uint8_t* ri_win = sc.get<uint8_t>(4 * (size_t)n);
+  uint32_t* ri_arrived = sc.get<uint32_t>((size_t)n + BB_RI_LISTS);   // refit: one counter per internal node, then the lengths of the lists
   void* tmp = sc.get<uint8_t>(tmp_bytes ? tmp_bytes : 16);
   if (!cb || !counters || !st || !seq || !keys0 || !keys1 || !vals0 || !vals1 || !rec || !cl0 || !cl1 || !dec || !tile_counts || !tile_base || !q0 || !q1 ||
-      !order || !gather || !tmp || !sc.pinned) return -1;
+      !order || !gather || !tmp || !sc.pinned || !ri_parent || !ri_lock || !ri_best || !ri_win || !ri_arrived) return -1;
   const uint32_t wide = blocks < 4096u ? blocks : 4096u;
   // (VXRT_BVH_TRI_COST: the triangle's cost against the node record's 52, for measurements; the default is the format's byte ratio)
   static const float tri_cost_env = [] { const char* e = getenv("VXRT_BVH_TRI_COST"); return e ? (float)atof(e) : BB_TRI_COST; }();
@@ -828,10 +1136,50 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   }
   hipLaunchKernelGGL(bb_ploc_tail_kernel, dim3(1), dim3(1024), 0, s, (const Cluster*)cur, st, rec, leaf_max, tri_cost);
 
+  // the binary tree optimised by reinsertion (step 4b).  VXRT_BVH_REINSERT = "iterations[:mod]" (0 = the PLOC tree as it is)
+  static const int ri_iters = [] { const char* e = getenv("VXRT_BVH_REINSERT"); return e ? atoi(e) : BB_RI_ITERS; }();
+  static const int ri_mod = [] { const char* e = getenv("VXRT_BVH_REINSERT"); const char* c = e ? strchr(e, ':') : nullptr; return c ? atoi(c + 1) : 1; }();
+  bool ri_ran = false;
+  if (!boxes && ri_iters > 0 && n >= 16u) {
+    RiArgs R;
+    R.rec = rec; R.parent = ri_parent; R.lock = ri_lock; R.best = ri_best; R.win0 = ri_win; R.win = ri_win + 2 * (size_t)n; R.arrived = ri_arrived;
+    R.moves = getenv("VXRT_BVH_VERBOSE") ? counters + 8 + BB_MAX_LEVELS + 2 : nullptr; R.n = n; R.it = 0; R.mod = (uint32_t)(ri_mod > 1 ? ri_mod : 1); R.leaf_max = leaf_max; R.tri_cost = tri_cost;
+    const uint32_t nb2 = (2u * n + 255u) / 256u;
+    uint32_t* wl0 = (uint32_t*)cl0; uint32_t* wl1 = (uint32_t*)cl1;   // (the cluster arrays are free after the clustering)
+    uint32_t ri_wide = 2;                                             // passes as launches of their own: until a list is at most ~2,048 nodes long in a balanced tree
+    while (ri_wide < 24u && (n >> ri_wide) > 2048u) ++ri_wide;
+    hipLaunchKernelGGL(bb_ri_parents_kernel, dim3(blocks), dim3(256), 0, s, R);
+    const int iters = ri_iters < BB_RI_MAX_ITERS ? ri_iters : BB_RI_MAX_ITERS;
+    for (int it = 0; it < iters; ++it) {
+      R.it = (uint32_t)it;
+      hipLaunchKernelGGL(bb_ri_search_kernel, dim3(nb2), dim3(256), 0, s, R);
+      hipLaunchKernelGGL(bb_ri_lock_kernel, dim3(nb2), dim3(256), 0, s, R);
+      hipLaunchKernelGGL(bb_ri_resolve_kernel, dim3(nb2), dim3(256), 0, s, R, 0);
+      hipLaunchKernelGGL(bb_ri_resolve_kernel, dim3(nb2), dim3(256), 0, s, R, 1);
+      hipLaunchKernelGGL(bb_ri_apply_kernel, dim3(nb2), dim3(256), 0, s, R);
+      if (hipMemsetAsync(ri_arrived, 0, ((size_t)n + BB_RI_LISTS) * 4, s) != hipSuccess) return -1;
+      const bool full = it + 1 == iters;
+      uint32_t* counts = ri_arrived + n;             // counts[k]: nodes on list k (height k + 1)
+      hipLaunchKernelGGL(bb_ri_refit_leaves_kernel, dim3(blocks), dim3(256), 0, s, R, wl0, counts);
+      uint32_t k = 0;
+      for (; k < ri_wide; ++k) {                     // list k holds at most n / (k + 2) nodes
+        const uint32_t cap = n / (k + 2u) + 1u, g = (cap + 255u) / 256u < 2048u ? (cap + 255u) / 256u : 2048u;
+        const uint32_t* in = (k & 1u) ? wl1 : wl0; uint32_t* out = (k & 1u) ? wl0 : wl1;
+        if (full) hipLaunchKernelGGL(bb_ri_refit_pass_kernel<true>, dim3(g), dim3(256), 0, s, R, in, out, counts + k);
+        else hipLaunchKernelGGL(bb_ri_refit_pass_kernel<false>, dim3(g), dim3(256), 0, s, R, in, out, counts + k);
+      }
+      if (full) hipLaunchKernelGGL(bb_ri_refit_tail_kernel<true>, dim3(1), dim3(1024), 0, s, R, wl0, wl1, counts, k, (uint32_t)BB_RI_LISTS);
+      else hipLaunchKernelGGL(bb_ri_refit_tail_kernel<false>, dim3(1), dim3(1024), 0, s, R, wl0, wl1, counts, k, (uint32_t)BB_RI_LISTS);
+    }
+    ri_ran = true;
+  }
+
   // collapse, level by level; sixteen levels, then as many more as the item counts ask for
   CollapseArgs A;
   A.rec = rec; A.n = n; A.tri_offset = tri_offset; A.node_capacity = node_capacity;
   A.nodes = (uint32_t*)d_nodes; A.counters = counters; A.vals = vals1; A.order = boxes ? nullptr : order;
+  static const uint32_t child_order_env = [] { const char* e = getenv("VXRT_BVH_CHILD_ORDER"); return e ? (uint32_t)atoi(e) : (uint32_t)BB_CHILD_ORDER; }();
+  A.child_order = child_order_env;
   const uint32_t cwide = blocks < 1024u ? blocks : 1024u;
   uint32_t L = 0;
   for (;;) {
@@ -859,18 +1207,27 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   }
   uint32_t* hc = sc.pinned;   // counters, then the clustering state, then the root's record
   if (hipMemcpyAsync(hc, counters, n_counters * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-  if (hipMemcpyAsync(hc + 64, st, ST_WORDS * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-  if (hipMemcpyAsync(hc + 80, rec, sizeof(BNode), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;   // record 0: the root (or the only leaf)
+  if (hipMemcpyAsync(hc + 192, st, ST_WORDS * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipMemcpyAsync(hc + 208, rec, sizeof(BNode), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;   // record 0: the root (or the only leaf)
+  hc[191] = 2u;
+  if (ri_ran && hipMemcpyAsync(hc + 191, ri_arrived, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;   // the root's counter of the last refit
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   if (hipGetLastError() != hipSuccess) return -1;
   BNode hroot;
-  memcpy(&hroot, hc + 80, sizeof hroot);
+  memcpy(&hroot, hc + 208, sizeof hroot);
+  static const bool verbose = getenv("VXRT_BVH_VERBOSE") != nullptr;
+  if (verbose && !boxes) {
+    fprintf(stderr, "[bvh_builder] n %u, reinsertion moves per iteration (made / wanted):", n);
+    for (int it = 0; it < BB_RI_MAX_ITERS && it < ri_iters; ++it) fprintf(stderr, " %u/%u", hc[8 + BB_MAX_LEVELS + 2 + it], hc[8 + BB_MAX_LEVELS + 2 + BB_RI_MAX_ITERS + it]);
+    fprintf(stderr, "; nodes %u, depth %u\n", hc[0], hc[3]);
+  }
   if (info) {
     info->n_nodes = hc[0]; info->n_leaves = hc[1]; info->max_leaf = hc[2]; info->max_depth = hc[3];
     info->bounds[0] = hroot.lx; info->bounds[1] = hroot.ly; info->bounds[2] = hroot.lz;
     info->bounds[3] = hroot.hx; info->bounds[4] = hroot.hy; info->bounds[5] = hroot.hz;
   }
-  if (hc[64 + ST_N] != 1u || hc[64 + ST_NEXT] != 0u) return -1;   // the clustering did not end in one root with every id used
+  if (hc[191] != 2u) return -2;                                 // the last refit did not reach the root: a binary tree of more than BB_RI_LISTS levels
+  if (hc[192 + ST_N] != 1u || hc[192 + ST_NEXT] != 0u) return -1;   // the clustering did not end in one root with every id used
   if (hc[4] != 0u) return -1;                                  // capacity or exponent range exhausted
   if (hc[8 + BB_MAX_LEVELS] != 0u) return -2;                  // deeper than the collapse pass goes
   if (hc[3] >= (uint32_t)RT_MAX_LEVELS) return -2;             // deeper than the reference's trail (rt_traversal.h:8): use the SAH builder

@@ -462,6 +462,9 @@ __device__ __forceinline__ void ao_sample_ray(uint32_t x, uint32_t y, uint32_t W
 #ifndef RT_TRI_LDS_MIN
 #define RT_TRI_LDS_MIN 8
 #endif
+#ifndef RT_OCCLUSION_SLOT_ORDER
+#define RT_OCCLUSION_SLOT_ORDER 0
+#endif
 #ifndef RT_UNORDERED_OCCLUSION
 #define RT_UNORDERED_OCCLUSION 1
 #endif
@@ -1077,9 +1080,16 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             if (sp + 4 > STACK_CAP) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
             cur = v0 ? c[0].desc : (v1 ? c[1].desc : (v2 ? c[2].desc : c[3].desc));
             if (more) {
+#if RT_OCCLUSION_SLOT_ORDER
+              // pushed last = visited next: the children are visited in slot order, which a builder may choose (largest surface area first)
+              if (v3 && (v0 || v1 || v2)) push(c[3].desc, c[3].d);
+              if (v2 && (v0 || v1)) push(c[2].desc, c[2].d);
+              if (v1 && v0) push(c[1].desc, c[1].d);
+#else
               if (v1 && v0) push(c[1].desc, c[1].d);
               if (v2 && (v0 || v1)) push(c[2].desc, c[2].d);
               if (v3 && (v0 || v1 || v2)) push(c[3].desc, c[3].d);
+#endif
             }
           } else {
             pop_next();

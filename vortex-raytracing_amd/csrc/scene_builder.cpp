@@ -60,6 +60,7 @@ static int kCollapse = 1;   // 1: build the binary SAH tree to the bottom, optim
                             // changes nothing (9 % fewer nodes, the same bytes per ray and frame rate); with the reinsertion passes +7.8 %
 static int kOptimize = 2;   // passes of insertion-based optimisation of the binary tree before the collapse (1 pass +6.9 %, 2 +7.8 %, 3 the same). VXS_OPTIMIZE
 static int kVerbose = 0;      // VXS_VERBOSE
+static int kChildOrder = 0;   // slots of a wide node: 0 as the binary tree hands them out, 1 largest surface area first, 2 smallest first.  VXS_CHILD_ORDER
 static int kOptimizeLocal = -1;  // 0: every node over the whole tree, serially (13 s per million triangles; the quality the rounds are measured against);
                                  // otherwise (default): rounds, coarse to fine, in place and in parallel (build_collapsed).  VXS_OPTIMIZE_LOCAL
 static double kOptimizeFraction = 1.0;   // share of the nodes, largest first, a pass takes. VXS_OPTIMIZE_FRACTION
@@ -406,6 +407,16 @@ private:
         c[pick] = y.left; slots[pick] = ja;
         c[nc] = y.right; slots[nc] = j - ja;
         ++nc;
+      }
+      // slot order = the order in which the frame's occlusion rays (any-hit, unordered: rt_kernels.hip) visit the children.
+      // kChildOrder 2: smallest surface area first -- a small box the ray enters is cheap to search and likely to hold an occluder
+      // (measured against as-built and largest-first: profiles/r05_g_child_order.txt); closest-hit rays sort by distance, for them
+      // the slot order decides ties only
+      if (kChildOrder != 0 && width_ == 4) {
+        float key[4];
+        for (uint32_t k = 0; k < nc; ++k) key[k] = kChildOrder == 1 ? -bn[c[k]].box.half_area() : bn[c[k]].box.half_area();
+        for (uint32_t i = 1; i < nc; ++i)        // (insertion sort, stable: equal areas keep the order the binary tree gave them)
+          for (uint32_t j = i; j > 0 && key[j] < key[j - 1]; --j) { std::swap(key[j], key[j - 1]); std::swap(c[j], c[j - 1]); }
       }
       const uint32_t first = (uint32_t)nodes_.size();
       for (uint32_t k = 0; k < nc; ++k) nodes_.emplace_back();
@@ -1829,6 +1840,7 @@ static void read_knobs() {
   if (const char* e = std::getenv("VXS_THREADS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) kThreads = v; }
   if (const char* e = std::getenv("VXS_LEAF_K")) kLeafK = (float)std::atof(e);
   if (const char* e = std::getenv("VXS_LEAF_MAX")) kLeafMax = std::atoi(e);
+  if (const char* e = std::getenv("VXS_CHILD_ORDER")) kChildOrder = std::atoi(e);
 }
 
 // decode an image file the way the scene ingest does (PNG, PPM/PGM -> 0x00RRGGBB); out may be NULL to query the size
