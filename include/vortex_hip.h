@@ -471,7 +471,7 @@ int vx_hip_buffer_device_ptr(vx_buffer_h hbuffer, void** dev_ptr);
 /* Host-side counters of a hip-backend device: which 0 = acceleration layouts built by vx_start so far (one per scene upload,
  * not one per run), 1 = hipMalloc calls made for buffers (buffers up to 4 KB share slabs), 2 = runs split over more than one GPU,
  * 3 = GPUs behind this device, 4 / 5 = joined runs whose MCYCLE came from the device's clock / from the host's, 6 = the last joined run on
- * the host's clock (vx_start -> the stream seen drained), microseconds.
+ * the host's clock (vx_start -> the stream seen drained), microseconds, 7 = runs whose shares were gathered through RCCL.
  *
  * vx_mpm_query(MCYCLE) = the last run's duration x the shader clock.  The duration is taken on the DEVICE: from the start of the run's
  * first traversal launch to its last kernel, on the constant 100 MHz clock (vxrt_accel_run_clock) -- a host that does other work between
@@ -483,7 +483,12 @@ int vx_hip_buffer_device_ptr(vx_buffer_h hbuffer, void** dev_ptr);
  * scene's seven buffers (refreshed when one is uploaded again) and their own acceleration layout.  vx_start of a whole frame traces tile
  * rows k, k+n, ... on the k-th listed device and copies them into the first device's output buffer, behind which the run's last kernel
  * waits: vx_ready_wait, vx_copy_from_dev and vx_mpm_query (MINSTRET = rays of all shares) behave as with one GPU.  A run the host restricted
- * itself (DCR 0x7F0-0x7F3), a reference-quirks run and the software twin's kernel stay on the first device. */
+ * itself (DCR 0x7F0-0x7F3), a reference-quirks run and the software twin's kernel stay on the first device.
+ *   VORTEX_HIP_GATHER=rccl       the shares travel through RCCL instead of peer copies (north_star: "RCCL gather over xGMI only for final
+ * image assembly", from the C host): one communicator per distinct listed GPU (ncclCommInitAll, librccl.so.1 loaded with dlopen at
+ * vx_dev_open), per run every share packed into contiguous bytes on its own GPU, ONE group of ncclSend / ncclRecv pairs, the first device
+ * placing the received shares into the output buffer's rows.  Default ("copy"): hipMemcpy2DAsync between the devices.  stat 7 counts
+ * the runs gathered through RCCL. */
 int vx_hip_device_stat(vx_device_h hdevice, uint32_t which, uint64_t* value);
 
 const char* vxrt_version(void);

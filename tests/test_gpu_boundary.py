@@ -413,6 +413,44 @@ def test_vortex_hip_devices_splits_a_frame_behind_one_vx_device(vrt, po, gpu_dev
 
 
 @pytest.mark.gpu
+def test_vortex_hip_devices_gathered_through_rccl(vrt, po, gpu_device, monkeypatch):
+    """VORTEX_HIP_GATHER=rccl (north_star: "host code stays in C ... RCCL gather over xGMI only for final image assembly"): the shares of a frame
+    split over VORTEX_HIP_DEVICES reach the first device's output buffer through ONE group of ncclSend / ncclRecv pairs issued by the C++
+    backend itself (librccl.so.1 bound with dlopen, one communicator per distinct GPU: ncclCommInitAll) instead of peer copies.  RCCL refuses
+    the same GPU twice in one communicator, so on the one-GPU box the communicator has ONE rank and the two extra shares -- packed on their own
+    streams, from their own framebuffers -- travel as RCCL's self send / receive pairs: the same calls, group, packing and placing as between
+    GPUs, and all this box can exercise.  Same frame, same ray count as one device, run after run; ragged last tile row (61 = 7 x 8 + 5)."""
+    w, h = 136, 61
+    sc = vrt.scene.procedural("blob", 3, 0, 2)
+    want = po.render_ex(sc, w, h, shadow=1)[0]
+    monkeypatch.setenv("VORTEX_HIP_DEVICES", "0,0,0")
+    monkeypatch.setenv("VORTEX_HIP_GATHER", "rccl")
+    tr = vrt.tracer.Tracer(w, h)
+    tr.init(sc)
+    monkeypatch.delenv("VORTEX_HIP_DEVICES")
+    monkeypatch.delenv("VORTEX_HIP_GATHER")
+    tr.setup(shadow=True)
+    assert tr.dev.hip_stat(3) == 3
+    for i in range(4):
+        tr.bufs["out"].write(np.full(w * h * 4, 0x5A, np.uint8))
+        assert np.array_equal(tr.run(), want)
+        assert tr.dev.hip_stat(7) == i + 1 and tr.dev.hip_stat(2) == i + 1
+    rays = tr.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0)
+    one = vrt.tracer.Tracer(w, h)
+    one.init(sc)
+    one.setup(shadow=True)
+    assert np.array_equal(one.run(), want) and rays == one.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0) and one.dev.hip_stat(7) == 0
+    one.close()
+    # a frame of another size on the same device: the landing buffers grow
+    tr.close()
+    monkeypatch.setenv("VORTEX_HIP_GATHER", "tcp")
+    monkeypatch.setenv("VORTEX_HIP_DEVICES", "0,0")
+    with pytest.raises(vrt.runtime.VxError):
+        vrt.runtime.Device()
+    monkeypatch.delenv("VORTEX_HIP_DEVICES")
+    monkeypatch.delenv("VORTEX_HIP_GATHER")
+
+
 def test_vortex_hip_devices_rejects_a_malformed_list(vrt, gpu_device, monkeypatch):
     for bad in ("0;1", "x", "0,99"):
         monkeypatch.setenv("VORTEX_HIP_DEVICES", bad)

@@ -21,6 +21,8 @@
 #include <vector>
 #include "../../include/vortex_hip.h"
 #include "rt_types.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl.so.1 is loaded with dlopen when VORTEX_HIP_GATHER=rccl asks for it
 
 extern "C" uint32_t* vxrt_status_word_device(void);   // rt_kernels.hip
 
@@ -86,6 +88,37 @@ struct Helper {
   uint32_t* fb = nullptr; uint64_t fb_bytes = 0;
   unsigned long long* d_rays = nullptr;
   unsigned long long* h_back = nullptr;   // pinned, portable: [0] rays of the share, [1] that device's status word
+  // VORTEX_HIP_GATHER=rccl: the share packed into contiguous bytes on its own device, sent to the first device through RCCL
+  uint8_t* wire = nullptr; uint64_t wire_bytes = 0;
+  hipEvent_t packed = nullptr;        // behind the packing copies on `stream`
+  int rank = 0;                       // the communicator rank of this helper's GPU (0 = it shares the first device)
+};
+
+// RCCL from the C host (north_star: "host code stays in C ... RCCL gather over xGMI only for final image assembly"): the handful of entry
+// points the gather needs, bound at run time so that a backend that never sets VORTEX_HIP_GATHER=rccl does not load the 1 GB library.
+struct RcclApi {
+  void* so = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool load() {
+    if (so) return true;
+    so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!so) return false;
+    CommInitAll = (decltype(CommInitAll))dlsym(so, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(so, "ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))dlsym(so, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(so, "ncclGroupEnd");
+    Send = (decltype(Send))dlsym(so, "ncclSend");
+    Recv = (decltype(Recv))dlsym(so, "ncclRecv");
+    GetErrorString = (decltype(GetErrorString))dlsym(so, "ncclGetErrorString");
+    return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+  }
 };
 
 struct vx_device {
@@ -95,6 +128,13 @@ struct vx_device {
   hipEvent_t ev_scene = nullptr;      // on `stream`, behind the uploads a helper's mirror copies read
   uint32_t fanned = 0;                // devices the pending run was split over (1 = this one alone)
   uint64_t n_fanned_runs = 0;         // vx_hip_device_stat 2
+  // VORTEX_HIP_GATHER=rccl: one communicator per DISTINCT listed GPU (ncclCommInitAll; rank 0 = the first device); the shares reach the
+  // first device's output buffer as one group of ncclSend / ncclRecv pairs per run instead of peer copies
+  RcclApi rccl;
+  std::vector<int> comm_devs;         // rank -> HIP device
+  std::vector<ncclComm_t> comms;      // rank -> communicator
+  uint8_t* wire0 = nullptr; uint64_t wire0_bytes = 0;   // the first device's landing buffer: the shares side by side
+  uint64_t n_rccl_runs = 0;           // vx_hip_device_stat 7
   bool run_pending = false;
   bool have_timing = false;
   std::map<uint64_t, Alloc> allocs;   // keyed by va
@@ -181,6 +221,22 @@ struct vx_device {
         hipError_t pe = hipDeviceEnablePeerAccess(h.hip_dev, 0);
         if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
       }
+      const char* g = std::getenv("VORTEX_HIP_GATHER");
+      if (g && std::strcmp(g, "rccl") == 0) {
+        if (!rccl.load()) { VXLOG("VORTEX_HIP_GATHER=rccl: librccl.so.1 could not be loaded (%s)", dlerror()); return -1; }
+        comm_devs.push_back(hip_dev);
+        for (auto& h : helpers) {
+          size_t r = 0;
+          while (r < comm_devs.size() && comm_devs[r] != h.hip_dev) ++r;
+          if (r == comm_devs.size()) comm_devs.push_back(h.hip_dev);
+          h.rank = (int)r;
+          if (hipSetDevice(h.hip_dev) != hipSuccess || hipEventCreateWithFlags(&h.packed, hipEventDisableTiming) != hipSuccess) return -1;
+        }
+        comms.assign(comm_devs.size(), nullptr);
+        const ncclResult_t nr = rccl.CommInitAll(comms.data(), (int)comm_devs.size(), comm_devs.data());
+        if (nr != ncclSuccess) { VXLOG("VORTEX_HIP_GATHER=rccl: ncclCommInitAll over %zu devices: %s", comm_devs.size(), rccl.GetErrorString(nr)); comms.clear(); return -1; }
+        if (hipSetDevice(hip_dev) != hipSuccess) return -1;
+      } else if (g && *g && std::strcmp(g, "copy") != 0) { VXLOG("VORTEX_HIP_GATHER: 'rccl' or 'copy', got '%s'", g); return -1; }
     }
     return 0;
   }
@@ -194,6 +250,8 @@ struct vx_device {
     if (h.d_rays) (void)hipFree(h.d_rays);
     if (h.h_back) (void)hipHostFree(h.h_back);
     if (h.done) (void)hipEventDestroy(h.done);
+    if (h.packed) (void)hipEventDestroy(h.packed);
+    if (h.wire) (void)hipFree(h.wire);
     if (h.stream) (void)hipStreamDestroy(h.stream);
     h = Helper{};
   }
@@ -245,6 +303,98 @@ struct vx_device {
     return 0;
   }
 
+  // share k of n: `full` whole tile rows (8 rows each) and, when the frame's last tile row is the share's and is cut short, `tail` more bytes
+  struct Share { uint32_t full; size_t tail, last_off, bytes; };
+  static Share share_of(uint32_t k, uint32_t n, uint32_t width, uint32_t height) {
+    const size_t row = (size_t)width * 4, band = row * 8;
+    const uint32_t tile_rows = (height + 7) / 8;
+    const uint32_t mine = tile_rows > k ? (tile_rows - k + n - 1) / n : 0;
+    Share s{mine, 0, 0, 0};
+    const uint32_t last = k + (mine ? (mine - 1) * n : 0);
+    if (mine && (last + 1) * 8 > height) { --s.full; s.tail = row * (height - last * 8); s.last_off = band * last; }
+    s.bytes = band * s.full + s.tail;
+    return s;
+  }
+
+  // VORTEX_HIP_GATHER=rccl: every helper packs its share (tile rows k, k+n, ... of its framebuffer) into contiguous bytes on its own GPU; ONE
+  // group of ncclSend (helper's GPU) / ncclRecv (first GPU) pairs moves the shares; the first device's stream copies them from its landing
+  // buffer into the rows of the output buffer.  Helpers on the first device's own GPU (the one-GPU tests list a device twice) send to rank 0
+  // from rank 0: RCCL's self send/recv, same calls.  Sends of one communicator go to one stream (the first device's, or the first helper's on
+  // that GPU), behind the packing's event.
+  int gather_rccl(uint32_t n, uint32_t width, uint32_t height, uint32_t* dst) {
+    const size_t row = (size_t)width * 4, band = row * 8, pitch = band * n;
+    uint64_t total = 0;
+    for (uint32_t k = 1; k < n; ++k) total += share_of(k, n, width, height).bytes;
+    if (wire0_bytes < total) {
+      if (hipSetDevice(hip_dev) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return -1;
+      if (wire0) (void)hipFree(wire0);
+      wire0 = nullptr; wire0_bytes = 0;
+      if (hipMalloc((void**)&wire0, total) != hipSuccess) return -1;
+      ++n_hip_mallocs;
+      wire0_bytes = total;
+    }
+    std::vector<hipStream_t> send_stream(comm_devs.size(), nullptr);
+    send_stream[0] = stream;
+    for (uint32_t k = 1; k < n; ++k) {
+      Helper& h = helpers[k - 1];
+      const Share sh = share_of(k, n, width, height);
+      if (hipSetDevice(h.hip_dev) != hipSuccess) return -1;
+      if (h.wire_bytes < sh.bytes) {
+        if (hipStreamSynchronize(h.stream) != hipSuccess) return -1;
+        if (h.wire) (void)hipFree(h.wire);
+        h.wire = nullptr; h.wire_bytes = 0;
+        if (hipMalloc((void**)&h.wire, sh.bytes ? sh.bytes : 16) != hipSuccess) return -1;
+        ++n_hip_mallocs;
+        h.wire_bytes = sh.bytes ? sh.bytes : 16;
+      }
+      hipError_t ce = hipSuccess;
+      if (sh.full) ce = hipMemcpy2DAsync(h.wire, band, (const char*)h.fb + band * k, pitch, band, sh.full, hipMemcpyDeviceToDevice, h.stream);
+      if (ce == hipSuccess && sh.tail) ce = hipMemcpyAsync(h.wire + band * sh.full, (const char*)h.fb + sh.last_off, sh.tail, hipMemcpyDeviceToDevice, h.stream);
+      if (ce != hipSuccess || hipEventRecord(h.packed, h.stream) != hipSuccess) { VXLOG("packing device %d's share: %s", h.hip_dev, hipGetErrorString(ce)); return -1; }
+      if (!send_stream[(size_t)h.rank]) send_stream[(size_t)h.rank] = h.stream;
+      if (send_stream[(size_t)h.rank] != h.stream) {      // (the sends of one communicator share a stream)
+        if (hipSetDevice(comm_devs[(size_t)h.rank]) != hipSuccess || hipStreamWaitEvent(send_stream[(size_t)h.rank], h.packed, 0) != hipSuccess) return -1;
+      }
+    }
+    ncclResult_t nr = rccl.GroupStart();
+    uint64_t off = 0;
+    for (uint32_t k = 1; k < n && nr == ncclSuccess; ++k) {
+      Helper& h = helpers[k - 1];
+      const Share sh = share_of(k, n, width, height);
+      if (!sh.bytes) continue;
+      (void)hipSetDevice(h.hip_dev);
+      nr = rccl.Send(h.wire, sh.bytes, ncclUint8, 0, comms[(size_t)h.rank], send_stream[(size_t)h.rank]);
+      (void)hipSetDevice(hip_dev);
+      if (nr == ncclSuccess) nr = rccl.Recv(wire0 + off, sh.bytes, ncclUint8, h.rank, comms[0], stream);
+      off += sh.bytes;
+    }
+    const ncclResult_t ne = rccl.GroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) { VXLOG("RCCL gather of the frame's shares: %s", rccl.GetErrorString(nr)); return -1; }
+    if (hipSetDevice(hip_dev) != hipSuccess) return -1;
+    off = 0;
+    for (uint32_t k = 1; k < n; ++k) {
+      const Share sh = share_of(k, n, width, height);
+      hipError_t ce = hipSuccess;
+      if (sh.full) ce = hipMemcpy2DAsync((char*)dst + band * k, pitch, wire0 + off, band, band, sh.full, hipMemcpyDeviceToDevice, stream);
+      if (ce == hipSuccess && sh.tail) ce = hipMemcpyAsync((char*)dst + sh.last_off, wire0 + off + band * sh.full, sh.tail, hipMemcpyDeviceToDevice, stream);
+      if (ce != hipSuccess) { VXLOG("placing device %d's share: %s", helpers[k - 1].hip_dev, hipGetErrorString(ce)); return -1; }
+      off += sh.bytes;
+    }
+    // the shares' ray counts and status words, and the events the first device's stream waits for (as with peer copies)
+    uint32_t* st = vxrt_status_word_device();
+    if (!st) return -1;
+    for (uint32_t k = 1; k < n; ++k) {
+      Helper& h = helpers[k - 1];
+      if (hipSetDevice(h.hip_dev) != hipSuccess) return -1;
+      h.h_back[1] = 0;
+      hipLaunchKernelGGL(vx_readback_kernel, dim3(1), dim3(1), 0, h.stream, h.d_rays, (const uint32_t*)st, (unsigned long long*)nullptr, h.h_back);
+      if (hipGetLastError() != hipSuccess || hipEventRecord(h.done, h.stream) != hipSuccess) return -1;
+    }
+    ++n_rccl_runs;
+    return 0;
+  }
+
   // tile rows k, k+n, ... of the helper's framebuffer into the same rows of the first device's output buffer, then the share's ray
   // count and that device's status word into pinned memory, then the event the first device's stream waits for
   int finish_helper(Helper& h, uint32_t k, uint32_t n, uint32_t width, uint32_t height, uint32_t* dst) {
@@ -285,8 +435,12 @@ struct vx_device {
   ~vx_device() {
     (void)hipSetDevice(hip_dev);
     if (stream) (void)hipStreamSynchronize(stream);   // simx dtor waits for the run (vortex.cpp:69-71)
+    for (auto& h : helpers) { (void)hipSetDevice(h.hip_dev); if (h.stream) (void)hipStreamSynchronize(h.stream); }
+    for (ncclComm_t c : comms) if (c) (void)rccl.CommDestroy(c);
+    comms.clear();
     for (auto& h : helpers) free_helper(h);
     (void)hipSetDevice(hip_dev);
+    if (wire0) (void)hipFree(wire0);
     if (ev_scene) (void)hipEventDestroy(ev_scene);
     if (accel) (void)vxrt_accel_destroy(accel);
     if (rc_accel) (void)vxrc_accel_destroy(rc_accel);
@@ -725,7 +879,8 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
       samples([&] { return vxrt_render_interleaved(ak, ka.dst_width, ka.dst_height, k, n_dev, &sp, (int)shadow, fb, nullptr, nullptr, cnt, sk); },
               [&](const vxrt_shade_params_t* pv, uint32_t n) { return vxrt_render_interleaved_batch(ak, ka.dst_width, ka.dst_height, k, n_dev, n, pv, (int)shadow, fb, 0, cnt, sk); });
     }
-    for (uint32_t k = 1; k < n_dev && rc == 0; ++k) rc = finish_helper(helpers[k - 1], k, n_dev, ka.dst_width, ka.dst_height, dstp);
+    if (!comms.empty()) { if (rc == 0) rc = gather_rccl(n_dev, ka.dst_width, ka.dst_height, dstp); }
+    else for (uint32_t k = 1; k < n_dev && rc == 0; ++k) rc = finish_helper(helpers[k - 1], k, n_dev, ka.dst_width, ka.dst_height, dstp);
     (void)hipSetDevice(hip_dev);
     for (auto& h : helpers) if (rc == 0 && hipStreamWaitEvent(stream, h.done, 0) != hipSuccess) rc = -1;
     if (rc != 0) {
@@ -881,6 +1036,7 @@ extern "C" int vx_hip_device_stat(vx_device_h hdevice, uint32_t which, uint64_t*
   case 4: *value = d->n_dev_clock_runs; return 0;       // joined runs whose MCYCLE came from the device's clock
   case 5: *value = d->n_host_clock_runs; return 0;      // ... from the host's (reference-quirks runs, runs split over several GPUs)
   case 6: *value = (uint64_t)((double)d->last_host_ms * 1e3); return 0;   // the last joined run on the HOST's clock, microseconds
+  case 7: *value = d->n_rccl_runs; return 0;            // runs whose shares were gathered through RCCL (VORTEX_HIP_GATHER=rccl)
   }
   return -1;
 }

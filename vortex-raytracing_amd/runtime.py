@@ -114,7 +114,7 @@ class Device:
 
     def hip_stat(self, which):
         """vx_hip_device_stat: 0 = acceleration layouts built, 1 = hipMalloc calls for buffers, 2 = runs split over several GPUs, 3 = GPUs behind the device,
-        4 / 5 = joined runs whose MCYCLE came from the device's clock / the host's, 6 = the last joined run on the host's clock (us)"""
+        4 / 5 = joined runs whose MCYCLE came from the device's clock / the host's, 6 = the last joined run on the host's clock (us), 7 = runs whose shares were gathered through RCCL (VORTEX_HIP_GATHER=rccl)"""
         v = C.c_uint64()
         check(hip_lib().vx_hip_device_stat(self.handle, which, C.byref(v)), "vx_hip_device_stat")
         return int(v.value)
