@@ -462,6 +462,9 @@ __device__ __forceinline__ void ao_sample_ray(uint32_t x, uint32_t y, uint32_t W
 #ifndef RT_TRI_LDS_MIN
 #define RT_TRI_LDS_MIN 8
 #endif
+#ifndef RT_OCCLUSION_ORDER
+#define RT_OCCLUSION_ORDER 0      // 0: slot order (the default); 1 / 2: measurement variants (profiles/r05_g_gpu_reinsertion.txt, section 7)
+#endif
 #ifndef RT_OCCLUSION_SLOT_ORDER
 #define RT_OCCLUSION_SLOT_ORDER 0
 #endif
@@ -1075,6 +1078,43 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           // ordering network and the path_m bookkeeping are skipped (vxrt_trace's MODE_ANY, which
           // returns the reference's FIRST accepted candidate, keeps the ordered path)
           const bool v0 = c[0].d < __builtin_inff(), v1 = c[1].d < __builtin_inff(), v2 = c[2].d < __builtin_inff(), v3 = c[3].d < __builtin_inff();
+#if RT_OCCLUSION_ORDER == 1
+          // measurement variant: the child the ray enters LAST first (an occlusion ray starts on a surface: the boxes around its origin hold
+          // that surface's own neighbourhood, which cannot block it), the others in slot order
+          if (v0 || v1 || v2 || v3) {
+            bool more = true;
+            if (sp + 4 > STACK_CAP) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
+            const float ninf = -__builtin_inff();
+            const float e0 = v0 ? c[0].d : ninf, e1 = v1 ? c[1].d : ninf, e2 = v2 ? c[2].d : ninf, e3 = v3 ? c[3].d : ninf;
+            const float m = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
+            const int pick = e0 == m ? 0 : (e1 == m ? 1 : (e2 == m ? 2 : 3));
+            cur = pick == 0 ? c[0].desc : (pick == 1 ? c[1].desc : (pick == 2 ? c[2].desc : c[3].desc));
+            if (more) {
+              if (v0 && pick != 0) push(c[0].desc, c[0].d);
+              if (v1 && pick != 1) push(c[1].desc, c[1].d);
+              if (v2 && pick != 2) push(c[2].desc, c[2].d);
+              if (v3 && pick != 3) push(c[3].desc, c[3].d);
+            }
+          } else {
+            pop_next();
+          }
+#elif RT_OCCLUSION_ORDER == 2
+          // measurement variant: all children by descending entry distance
+          if (v0 || v1 || v2 || v3) {
+            bool more = true;
+            if (sp + 4 > STACK_CAP) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
+            order_children(c);      // valid first, nearest in c[0]
+            const int nv = (int)v0 + (int)v1 + (int)v2 + (int)v3;
+            cur = nv == 1 ? c[0].desc : (nv == 2 ? c[1].desc : (nv == 3 ? c[2].desc : c[3].desc));
+            if (more) {
+              if (nv > 1) push(c[0].desc, c[0].d);
+              if (nv > 2) push(c[1].desc, c[1].d);
+              if (nv > 3) push(c[2].desc, c[2].d);
+            }
+          } else {
+            pop_next();
+          }
+#else
           if (v0 || v1 || v2 || v3) {
             bool more = true;
             if (sp + 4 > STACK_CAP) { atomicOr(A.status, STATUS_STACK_OVERFLOW); more = false; }
@@ -1094,6 +1134,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           } else {
             pop_next();
           }
+#endif
         } else {
           order_children(c);   // valid children first (d < inf), nearest in c[0]
           // (path_m and the candidates' distances are never NaN -- a filtered child carries +inf -- so the maxima need no
