@@ -204,11 +204,6 @@ uint64_t vxrt_accel_bytes(const vxrt_accel_t* accel);
  * reference's 32 levels, 96 entries + the LDS part); 2 -> 1 if the TLAS root is a single identity instance; 3 -> 1 if the scene
  * takes the ldexp decode / generic slab form. */
 int vxrt_accel_info(const vxrt_accel_t* accel, uint32_t which, uint64_t* value);
-/* The clock of a run, taken on the device: from now on the first workgroup of every main traversal launch on this layout lowers
- * *clock (device memory, one u64, atomic min) to the constant 100 MHz clock at its start.  Set *clock to ~0 before a run, read the same
- * clock behind the run's last kernel: the difference is the run's duration on the device, whatever the host did meanwhile (this is how
- * vx_mpm_query(MCYCLE) is measured).  NULL switches it off.  vxrc_accel_run_clock: the same for the twin's layout. */
-int vxrt_accel_run_clock(vxrt_accel_t* accel, unsigned long long* clock);
 
 /* Number of frames (vxrt_render / vxrt_trace calls) this accel keeps in flight, 1..8, default 1.
  * Each in-flight frame has its own hit-record buffer, deferred-ray list and side stream; calls take
@@ -387,7 +382,6 @@ int vxrc_accel_destroy(vxrc_accel_t* accel);
  * levels, whose wide walk could need more than the reference's 64 stack entries); which = 1 -> internal nodes on the longest
  * root-to-leaf path, counted up to 43 (0 when the wide layout was not requested). */
 int vxrc_accel_info(const vxrc_accel_t* accel, uint32_t which, uint64_t* value);
-int vxrc_accel_run_clock(vxrc_accel_t* accel, unsigned long long* clock);
 /* vxrc_render on a prebuilt layout (asynchronous on `stream`; the layout keeps four frame contexts: frames issued round robin on up to
  * four streams overlap). */
 int vxrc_render_accel(vxrc_accel_t* accel, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
@@ -473,10 +467,11 @@ int vx_hip_buffer_device_ptr(vx_buffer_h hbuffer, void** dev_ptr);
  * 3 = GPUs behind this device, 4 / 5 = joined runs whose MCYCLE came from the device's clock / from the host's, 6 = the last joined run on
  * the host's clock (vx_start -> the stream seen drained), microseconds, 7 = runs whose shares were gathered through RCCL.
  *
- * vx_mpm_query(MCYCLE) = the last run's duration x the shader clock.  The duration is taken on the DEVICE: from the start of the run's
- * first traversal launch to its last kernel, on the constant 100 MHz clock (vxrt_accel_run_clock) -- a host that does other work between
- * vx_start and vx_ready_wait does not lengthen it.  Two kinds of run have no such clock and report the host's (vx_start -> the moment
- * vx_ready_wait or the next call saw the stream drained): reference-quirks runs and runs split over several GPUs.
+ * vx_mpm_query(MCYCLE) = the last run's duration x the shader clock.  The duration is taken on the DEVICE, on its constant 100 MHz clock:
+ * vx_start launches a one-thread kernel on a stream of its own that stores the clock (it starts with the run's first launch and delays
+ * nothing on the run's stream), the run's last kernel -- the one that sends rays and status back -- reads the clock again.  A host that
+ * does other work between vx_start and vx_ready_wait does not lengthen it.  Should the stamp not have landed when the run's last kernel
+ * reads it (never observed) the run reports the host's clock (vx_start -> the moment the stream was seen drained); stats 4 / 5 count both.
  *
  * More than one GPU behind ONE vx_device (the unmodified reference host, which opens one device: tracer.cpp:78):
  *   VORTEX_HIP_DEVICES=0,1,2,3   the first index holds the address space (every vx_mem_* / vx_copy_* call), the others keep a copy of the

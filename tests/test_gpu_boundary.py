@@ -36,9 +36,9 @@ def test_rtu_test_frame_through_vx_api(vrt, po, gpu_device):
 
 def test_mcycle_is_the_runs_time_on_the_device(vrt, gpu_device):
     """vx_mpm_query(MCYCLE) (stub/perf.cpp:195-227 divides by it) = the run's duration x the shader clock, and the duration is taken on the
-    device (first traversal launch's start -> the run's last kernel, 100 MHz clock): a host that sleeps between vx_start and vx_ready_wait
-    does not lengthen it, while the host-side clock of the same run (stat 6) does see the sleep.  Both kernels of the boundary: the RTU
-    frame and the software twin; a reference-quirks run has no device clock and reports the host's (stat 5)."""
+    device (a stamp kernel vx_start launches on a stream of its own -> the run's last kernel, 100 MHz clock): a host that sleeps between
+    vx_start and vx_ready_wait does not lengthen it, while the host-side clock of the same run (stat 6) does see the sleep.  Both kernels of
+    the boundary: the RTU frame and the software twin (reference-quirks runs and runs split over VORTEX_HIP_DEVICES: their own tests)."""
     import time
     w, h = 320, 200
     for twin in (False, True):
@@ -334,9 +334,9 @@ def test_reference_quirks_dcr_renders_what_the_rtu_would_on_this_address_space(v
     want_canon, _, _ = po.render(sc, w, h)
     assert np.array_equal(canon, want_canon)
     tr.dev.dcr_write(0x7F4, 1)
-    n_host0 = tr.dev.hip_stat(5)
+    n_dev0 = tr.dev.hip_stat(4)
     quirk = tr.run()
-    assert tr.dev.mpm_query(vrt.runtime.VX_CSR_MCYCLE, 0) > 0 and tr.dev.hip_stat(5) == n_host0 + 1   # (no device clock in this mode: the host's)
+    assert tr.dev.mpm_query(vrt.runtime.VX_CSR_MCYCLE, 0) > 0 and tr.dev.hip_stat(4) == n_dev0 + 1 and tr.dev.hip_stat(5) == 0   # (the device's clock in this mode too)
     tr.dev.dcr_write(0x7F4, 0)
     again = tr.run()
     assert np.array_equal(again, canon)             # the mode is a switch, nothing sticks

@@ -307,7 +307,6 @@ struct RcArgs {
   // frame of the same window) and where this frame's cost per tile goes (loop iterations of the wavefront that traced it; a leaf-body
   // run counts three) -- the RTU path's longest-first order (rt_kernels.hip), which is worth +18 % on its serial frames
   const uint32_t* tile_order; uint32_t* tile_cost;
-  unsigned long long* run_clock;   // optional (vxrc_accel_run_clock): lowered to the 100 MHz clock at the launch's start by its first workgroup
 };
 
 __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, RcParams p, RcArgs A) {
@@ -335,7 +334,6 @@ __global__ __launch_bounds__(256, RC_WAVES) void rc_persistent_kernel(RcDev sc, 
   uint32_t tries = 0, work = 0, cost_tile = 0xFFFFFFFFu;
   __shared__ uint32_t s_dry;
   if (threadIdx.x == 0) s_dry = 0u;
-  if (A.run_clock && blockIdx.x == 0 && threadIdx.x == 0) atomicMin(A.run_clock, (unsigned long long)wall_clock64());
   __syncthreads();
 
   auto push = [&](uint32_t d) {
@@ -711,7 +709,6 @@ struct vxrc_accel {
   bool multi_stream = false; hipStream_t first_stream = nullptr; bool stream_seen = false;
   uint32_t fast_boxes = 0;   // see RcDev
   uint32_t depth = 0;        // internal nodes on the longest root-to-leaf path (measured when the wide layout was built; 0 = not measured)
-  unsigned long long* run_clock = nullptr;   // vxrc_accel_run_clock
 };
 
 extern "C" int vxrc_accel_destroy(vxrc_accel_t* a) {
@@ -723,12 +720,6 @@ extern "C" int vxrc_accel_destroy(vxrc_accel_t* a) {
     if (c.done) (void)hipEventDestroy(c.done);
   }
   delete a;
-  return 0;
-}
-
-extern "C" int vxrc_accel_run_clock(vxrc_accel_t* a, unsigned long long* clock) {
-  if (!a) return -1;
-  a->run_clock = clock;
   return 0;
 }
 
@@ -873,7 +864,7 @@ extern "C" int vxrc_render_accel(vxrc_accel_t* a, uint32_t width, uint32_t heigh
   RcFrameCtx* c = rc_acquire_ctx(a, hs);
   if (!c) return -1;
   auto fail = [&]() -> int { c->ctl_dirty = true; (void)rc_release_ctx(a, c, hs); return -1; };
-  A.dst = dst; A.colors = colors; A.status = st; A.queue = c->ctl; A.run_clock = a->run_clock;
+  A.dst = dst; A.colors = colors; A.status = st; A.queue = c->ctl;
   if (c->ctl_dirty && hipMemsetAsync(c->ctl, 0, RC_CTL_DWORDS * 4, hs) != hipSuccess) return fail();
   c->ctl_dirty = true;    // until the sort launch that clears the counters again is enqueued
   // longest tile first inside each band, learned from this context's previous frame of the same window (VXRC_LPT=0: off)

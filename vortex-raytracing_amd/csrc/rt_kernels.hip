@@ -622,9 +622,6 @@ struct PersistArgs {
   // optional, every build (the TIMED kernels too: one store per wavefront when it ends, nothing inside the loop): 2 u64 per wavefront of the main
   // launch -- [0] the constant 100 MHz clock at its end, [1] rays it started | physical XCD << 56 (vxrt_debug_end_log; tools/xcd_tail.py)
   unsigned long long* end_log;
-  // optional, every build: the run's clock (vxrt_accel_run_clock) -- the first workgroup of a main launch lowers *run_clock to the constant 100 MHz
-  // clock at its start (the caller sets it to ~0 before a run and reads the earliest start of the run's launches afterwards)
-  unsigned long long* run_clock;
   // batch of frames in one launch (vxrt_render_interleaved_batch): the window's tiles repeat `frame_tiles` apart, frame f = tile /
   // frame_tiles is shaded and lit with pbatch[f]; nullptr = one frame
   const ShadeParams* pbatch; uint32_t frame_tiles;
@@ -698,7 +695,6 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   __shared__ uint32_t s_ctx[WG_WAVES][NCTX][64];
   __shared__ uint32_t s_dry;      // bit s: a wavefront of this workgroup found queue shard s handed out
   if (threadIdx.x == 0) s_dry = 0u;
-  if (!EXACT && A.run_clock && blockIdx.x == 0 && threadIdx.x == 0) atomicMin(A.run_clock, (unsigned long long)wall_clock64());
   __syncthreads();
   uint2* const lstk = &s_stk[threadIdx.x >> 6][0][lane];
   uint32_t* const ctx = &s_ctx[threadIdx.x >> 6][0][lane];
@@ -2888,7 +2884,6 @@ struct vxrt_accel {
   uint32_t ap_count = 0, ap_key[6] = {0, 0, 0, 0, 0, 0};
   uint64_t ap_cap = 0;
   float max_reflectivity = 0.0f;   // over the instance records: > 0 enables the mirror-bounce path
-  unsigned long long* run_clock = nullptr;        // vxrt_accel_run_clock: where the main launches leave the earliest start of a run
   unsigned long long* trace_wave_log = nullptr;   // diagnostic (vxrt_debug_trace_wave_log): per-wavefront log of the counting build's ray-buffer launches
   unsigned long long* end_log = nullptr;   // diagnostic (vxrt_debug_end_log): where the main launches leave their wavefronts' end times
   uint32_t levels = 0;             // internal levels on the longest root-to-leaf path (TLAS + BLAS), counted up to RT_SHALLOW_LEVELS + 1
@@ -3164,7 +3159,6 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   A.total = (uint32_t)n; A.hits = hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
   A.total_dev = n_dev;
   A.end_log = a->end_log;
-  A.run_clock = a->run_clock;
   A.order = order;
   A.counters = stats_counters;
   A.wave_log = stats_counters ? a->trace_wave_log : nullptr;
@@ -3440,7 +3434,7 @@ static int render_common(vxrt_accel_t* a, uint32_t width, uint32_t height, uint3
   PersistArgs A{};
   A.W = width; A.H = height; A.y0 = y0; A.y1 = y1; A.tiles_x = tiles_x; A.row_step = row_step; A.total = n_tiles * 64u;
   A.div_tiles_x = fast_div_make(tiles_x); A.div_frame_tiles = fast_div_make(frame_tiles); A.frame_tiles = frame_tiles;
-  A.hits = (HitRec*)c->hitbuf; A.counters = counters; A.status = st; A.wave_log = wave_log; A.end_log = a->end_log; A.run_clock = a->run_clock;
+  A.hits = (HitRec*)c->hitbuf; A.counters = counters; A.status = st; A.wave_log = wave_log; A.end_log = a->end_log;
   A.utab = a->uvtab; A.vtab = a->uvtab + width;
   if (batch > 1) {
     if (!c->pbatch && hipMalloc((void**)&c->pbatch, VXRT_MAX_BATCH * sizeof(ShadeParams)) != hipSuccess) return fail();
@@ -3858,16 +3852,6 @@ int vxrt_wire_unpack(const uint8_t* wire_all, uint64_t wire_stride_bytes, uint32
 
 // diagnostic (tools/trace_phases.py): the counting build's ray-buffer launches (vxrt_trace_stats) keep vxrt_render_wave_log's 16 u64 per wavefront in
 // `log` from now on (device memory, 16 x 8,192 u64; nullptr: off) -- loop iterations, runs of the node / leaf body and the lanes active in them
-// The clock of a run, on the DEVICE (what vx_mpm_query(MCYCLE) reports through the vx_* boundary): from now on the first workgroup of every main
-// traversal launch on this layout lowers *clock (device memory, one u64) to the constant 100 MHz clock (s_memrealtime) at its start.  A caller
-// that sets *clock to ~0 before a run and reads the same clock behind the run's last kernel has the run's duration on the device, whatever the
-// host did meanwhile.  NULL switches it off (the default: one scalar test per wavefront).
-int vxrt_accel_run_clock(vxrt_accel_t* a, unsigned long long* clock) {
-  if (!a) return -1;
-  a->run_clock = clock;
-  return 0;
-}
-
 int vxrt_debug_trace_wave_log(vxrt_accel_t* a, unsigned long long* log) {
   if (!a) return -1;
   a->trace_wave_log = log;

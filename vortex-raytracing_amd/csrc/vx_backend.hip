@@ -29,10 +29,12 @@ extern "C" uint32_t* vxrt_status_word_device(void);   // rt_kernels.hip
 // rays counter and status word of a run into host memory the device can write (see vx_device::enqueue_readback)
 // ... and clears the counter for the next run: a run is its own launches + this one.  (Rounds 2-3 opened a run with a fill of the counter and
 // an event record and closed it with a second event record -- three more packets on the stream, ~10 us each between a frame's launches.)
-// The run's clock (MCYCLE) is taken on the device without those packets: the first workgroup of each main traversal launch lowers *clock to
-// the constant 100 MHz clock at its start (vxrt_accel_run_clock); this kernel, the run's last, reads the same clock: host[2] = the earliest
-// start, host[3] = now, and *clock goes back to ~0 for the next run.  A run without such a launch (reference-quirks kernels) leaves ~0 in
-// host[2] and its duration is the host's (vx_start -> drained stream).
+// The run's clock (MCYCLE) is taken on the device without packets on the run's stream: vx_start launches vx_stamp_kernel on a stream of its
+// own (clk_stream) -- it starts with the run's first launch -- and this kernel, the run's last, reads the clock again: host[2] = the stamp,
+// host[3] = now, and *clock goes back to ~0 for the next run.  (Round 5's first form stamped inside the traversal kernels: three more
+// spilled registers and 0.6 % of the headline for a diagnostic; profiles/r05_h_run_clock_ab.txt.)  The two kernels are not ordered by an
+// event -- that would be the packet this avoids; a stamp that has not landed reads as ~0 and the run reports the host's clock.
+__global__ void vx_stamp_kernel(unsigned long long* __restrict__ clock) { *clock = (unsigned long long)wall_clock64(); }
 __global__ void vx_readback_kernel(unsigned long long* __restrict__ rays, const uint32_t* __restrict__ status, unsigned long long* __restrict__ clock,
                                    unsigned long long* __restrict__ host) {
   host[0] = *rays;
@@ -154,7 +156,8 @@ struct vx_device {
   float last_ms = 0.f;                // the last run's duration: the device's clock when the run has one, else the host's
   float last_host_ms = 0.f;           // vx_start -> the moment ready_wait saw the stream drained (vx_hip_device_stat 6, in us)
   uint64_t n_dev_clock_runs = 0, n_host_clock_runs = 0;   // vx_hip_device_stat 4 / 5
-  unsigned long long* d_clock = nullptr;   // the run's clock on the device (vxrt_accel_run_clock)
+  unsigned long long* d_clock = nullptr;   // the run's clock on the device (vx_stamp_kernel / vx_readback_kernel)
+  hipStream_t clk_stream = nullptr;        // the stamp's own stream
   std::chrono::steady_clock::time_point t_begin{};   // vx_start of the pending run
   hipDeviceProp_t prop{};
   // acceleration layout of the scene last started, rebuilt only when one of the four traversal
@@ -194,6 +197,7 @@ struct vx_device {
     if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
     if (hipMalloc((void**)&d_rays, sizeof(unsigned long long)) != hipSuccess || hipMemset(d_rays, 0, sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipMalloc((void**)&d_clock, sizeof(unsigned long long)) != hipSuccess || hipMemset(d_clock, 0xFF, sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipStreamCreateWithFlags(&clk_stream, hipStreamNonBlocking) != hipSuccess) return -1;
     if (hipHostMalloc((void**)&h_back, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return -1;
     if (hipHostMalloc((void**)&stage, kStageSlot * kStageSlots, hipHostMallocDefault) != hipSuccess) return -1;
     for (int i = 0; i < 8; ++i) h_back[i] = 0;
@@ -447,6 +451,7 @@ struct vx_device {
     for (auto& kv : allocs) if (kv.second.dptr && !kv.second.pooled) (void)hipFree(kv.second.dptr);
     for (void* sl : slabs) (void)hipFree(sl);
     if (d_rays) (void)hipFree(d_rays);
+    if (clk_stream) { (void)hipStreamSynchronize(clk_stream); (void)hipStreamDestroy(clk_stream); }
     if (d_clock) (void)hipFree(d_clock);
     if (q_image) (void)hipFree(q_image);
     if (q_rays) (void)hipFree(q_rays);
@@ -582,13 +587,20 @@ struct vx_device {
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
 
+  // the start of a run on both clocks: the host's, and the device's through a one-thread kernel on a stream of its own
+  void begin_run() {
+    t_begin = std::chrono::steady_clock::now();
+    (void)hipSetDevice(hip_dev);
+    hipLaunchKernelGGL(vx_stamp_kernel, dim3(1), dim3(1), 0, clk_stream, d_clock);
+    (void)hipGetLastError();
+  }
+
   void finish_run() {
     if (!run_pending) return;
     run_pending = false;
     last_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); have_timing = true;
-    // the device's own clock when the run left one (100 MHz ticks between the first main launch's start and the run's last kernel); a run
-    // split over several GPUs keeps the host's clock: it ends with copies between devices whose clocks are not one clock
-    const bool dev_clock = fanned <= 1 && h_back[2] != ~0ull && h_back[3] > h_back[2];
+    // the device's own clock (100 MHz ticks between the stamp vx_start launched and the run's last kernel, both on the first device)
+    const bool dev_clock = h_back[2] != ~0ull && h_back[3] > h_back[2];
     last_ms = dev_clock ? (float)((double)(h_back[3] - h_back[2]) * 1e-5) : last_host_ms;
     ++(dev_clock ? n_dev_clock_runs : n_host_clock_runs);
     last_rays = h_back[0];   // copied back by the stream at the end of the run (enqueue_readback)
@@ -777,7 +789,6 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
     if (accel) { (void)vxrt_accel_destroy(accel); accel = nullptr; }
     ++n_accel_builds;
     if (vxrt_accel_build(&sc, stream, &accel) != 0) { VXLOG("start: scene rejected (malformed BVH: index out of range, wrong node kind or child not after parent)"); return -1; }
-    (void)vxrt_accel_run_clock(accel, d_clock);
     std::memcpy(accel_key, key, sizeof key);
   }
 
@@ -827,7 +838,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
       if (hipMalloc(&q_rays, nr * 24) != hipSuccess || hipMalloc(&q_hits, nr * 24) != hipSuccess) return -1;
       q_rays_cap = nr;
     }
-    t_begin = std::chrono::steady_clock::now();
+    begin_run();
     int rc = vxrt_camera_rays(ka.dst_width, ka.dst_height, y0, y1, (float*)q_rays, stream);
     // (the DCRs hold 32-bit device addresses: offsets into the image, as they are addresses into the simulator's RAM)
     if (rc == 0) rc = vxrt_trace_reference_quirks(q_image, q_image_size, d_tlas, d_blas, d_bvh, d_tri, (const float*)q_rays, nr, nullptr, (vxrt_hit_t*)q_hits, VXRT_MODE_CLOSEST, stream);
@@ -839,7 +850,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
     run_pending = true;
     return 0;
   }
-  t_begin = std::chrono::steady_clock::now();
+  begin_run();
   // samples_per_pixel: the reference's kernel traces the SAME camera ray that many times into the same payload (kernel.cpp:67-80: GenerateRay
   // takes no sample index, the colour accumulation is commented out), so the pixel is the one sample's -- and the run costs spp times the rays
   // and the time.  Honoured as written: the frame is traced spp times (same pixels; MINSTRET and MCYCLE are what a `-s 4` run expects).
@@ -869,7 +880,7 @@ int vx_device::start(uint64_t krnl_va, uint64_t args_va) {
     if (hipEventRecord(ev_scene, stream) != hipSuccess) return -1;
     for (auto& h : helpers)
       if (prepare_helper(h, sc, ver, bytes, (uint64_t)ka.dst_width * ka.dst_height * 4) != 0) { (void)hipSetDevice(hip_dev); return -1; }
-    t_begin = std::chrono::steady_clock::now();
+    begin_run();
     for (uint32_t k = 0; k < n_dev && rc == 0; ++k) {
       vxrt_accel_t* ak = k ? helpers[k - 1].accel : accel;
       uint32_t* fb = k ? helpers[k - 1].fb : dstp;
@@ -972,10 +983,9 @@ int vx_device::start_raycast(uint64_t args_va) {
     if (rc_accel) { (void)vxrc_accel_destroy(rc_accel); rc_accel = nullptr; }
     ++n_accel_builds;
     if (vxrc_accel_build(&sc, stream, &rc_accel) != 0) { VXLOG("start: raycast scene rejected (malformed BVH2: child / triangle index out of range or child not after parent)"); return -1; }
-    (void)vxrc_accel_run_clock(rc_accel, d_clock);
     std::memcpy(rc_key, key, sizeof key);
   }
-  t_begin = std::chrono::steady_clock::now();
+  begin_run();
   const int rc = vxrc_render_accel(rc_accel, ka.dst_width, ka.dst_height, y0, y1, &pr, (uint32_t*)((char*)r_dst.a->dptr + r_dst.off), nullptr, stream);
   if (rc != 0) { VXLOG("start: raycast launch rejected (shape check)"); return -1; }
   if (enqueue_readback() != 0) return -1;
@@ -1034,7 +1044,7 @@ extern "C" int vx_hip_device_stat(vx_device_h hdevice, uint32_t which, uint64_t*
   case 2: *value = d->n_fanned_runs; return 0;          // runs split over the devices of VORTEX_HIP_DEVICES
   case 3: *value = d->helpers.size() + 1; return 0;     // devices behind this vx_device
   case 4: *value = d->n_dev_clock_runs; return 0;       // joined runs whose MCYCLE came from the device's clock
-  case 5: *value = d->n_host_clock_runs; return 0;      // ... from the host's (reference-quirks runs, runs split over several GPUs)
+  case 5: *value = d->n_host_clock_runs; return 0;      // ... from the host's (the stamp had not landed: never observed)
   case 6: *value = (uint64_t)((double)d->last_host_ms * 1e3); return 0;   // the last joined run on the HOST's clock, microseconds
   case 7: *value = d->n_rccl_runs; return 0;            // runs whose shares were gathered through RCCL (VORTEX_HIP_GATHER=rccl)
   }
