@@ -24,7 +24,7 @@ cut -c1-300 "$OUT/bench_serial.json"
 for i in 1 2 3 4 5; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --random-rays 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('driver command (--gpus 1 --steps 20 --warmup 5):', d['value'], d['ms_per_step'], 'frac', d['roofline']['frac'], 'clock', d['roofline']['clock_ghz_held'])"; done > "$OUT/driver_cmd.txt" 2>&1
 cat "$OUT/driver_cmd.txt"
 tools/rehearse_multi.sh > "$OUT/multi_gpu_rehearsal.txt" 2>&1; tail -4 "$OUT/multi_gpu_rehearsal.txt"
-python tools/config_bench.py 2 3 4 5 6 7 2>/dev/null | grep "^{" > "$OUT/configs.jsonl"; cut -c1-260 "$OUT/configs.jsonl"
+python tools/config_bench.py 2 3 4 5 6 7 8 2>/dev/null | grep "^{" > "$OUT/configs.jsonl"; cut -c1-260 "$OUT/configs.jsonl"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_pipelined" -- python "$ROOT/bench.py" --no-cpu-baseline --other-configs none > "$OUT/stats_pipelined.log" 2>&1 || { echo "rocprof pipelined failed"; exit 1; }
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -- python "$ROOT/bench.py" --no-cpu-baseline --frames-in-flight 1 --other-configs none > "$OUT/stats_serial.log" 2>&1 || { echo "rocprof serial failed"; exit 1; }
