@@ -269,3 +269,49 @@ def test_reinsertion_lowers_the_trees_cost_and_is_deterministic(vrt, gpu_device)
     assert res["4"]["hits"] == res["0"]["hits"] == res["12:3"]["hits"] and res["4"]["dist_sum"] == res["0"]["dist_sum"] == res["12:3"]["dist_sum"]
     assert res["4"]["bytes"] < 0.97 * res["0"]["bytes"]
     assert res["12:3"]["bytes"] < 0.97 * res["0"]["bytes"]
+
+
+@pytest.mark.parametrize("n", [16, 17, 31, 64, 513, 5000, 60000])
+@pytest.mark.parametrize("kind", ["cloud", "clusters", "slivers", "nested"])
+def test_random_soups_through_the_reinsertion_step(vrt, po, gpu_device, n, kind):
+    """Step 4b (parallel reinsertion) on triangle soups made to provoke it -- uniform clouds (everything overlaps everything), tight clusters
+    with copies of the same triangle (equal gains: ties decided by node id), long slivers across the scene (nodes that want to move far),
+    shells nested in shells (subtrees that would rather be inside each other: the ring guard): the tree must keep the format's invariants
+    (every triangle in exactly one leaf, box chains contain their triangles, children after parents -- a ring cut off from the root would
+    lose triangles and fail the refit: vxrt_bvh_build returns -2) and lose no hit against brute force.  n = 16 is the smallest mesh the
+    step runs on; 17 / 31 / 513 leave ragged lists."""
+    rng = np.random.default_rng(n * 7 + len(kind))
+    if kind == "cloud":
+        c = rng.uniform(-80, 80, size=(n, 1, 3))
+        tri = c + rng.uniform(-30, 30, size=(n, 3, 3))
+    elif kind == "clusters":
+        k = max(2, n // 40)
+        centres = rng.uniform(-90, 90, size=(k, 3))
+        base = centres[rng.integers(0, k, n)][:, None, :] + rng.uniform(-2, 2, size=(n, 3, 3))
+        dup = rng.integers(0, n, n // 3)
+        base[dup] = base[rng.integers(0, n, n // 3)]           # exact copies of other triangles
+        tri = base
+    elif kind == "slivers":
+        a = rng.uniform(-100, 100, size=(n, 3))
+        d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        ln = rng.choice([2.0, 150.0], size=(n, 1), p=[0.7, 0.3])
+        tri = np.stack([a, a + d * ln, a + d * ln * 0.5 + rng.uniform(-0.3, 0.3, size=(n, 3))], 1)
+    else:
+        r = rng.choice([5.0, 20.0, 60.0, 100.0], size=(n, 1, 1))
+        u = rng.normal(size=(n, 3, 3)); u /= np.linalg.norm(u, axis=2, keepdims=True)
+        tri = u * r
+    tri = (tri + np.array([200.0, 100.0, 0.0])).astype(np.float32).reshape(n, 9)
+    ds = vrt.tracer.DeviceScene.build_on_gpu(tri, device=gpu_device, leaf_max=2)
+    sc = ds.to_host()
+    depth = check_tree_fast(sc)
+    assert depth == ds.bvh_info.max_depth < 32
+    got_rows = sorted(r.tobytes() for r in sc["tri"].view(np.float32).reshape(-1, 9))
+    assert got_rows == sorted(r.tobytes() for r in tri)
+    rays = po.camera_rays(40, 30)
+    rays = rays[(rays[:, 3:] != 0).all(1)]
+    got = gpu_trace(vrt, ds, rays)
+    want, _ = po.trace_canonical(sc, rays)
+    assert np.array_equal(_bits(got), _bits(want))
+    if n <= 5000:
+        assert np.array_equal(got["dist"], brute_force(sc, rays, po))
+    ds.close()

@@ -45,6 +45,7 @@
 namespace {
 
 constexpr int BB_RI_MAX_ITERS = 32;  // reinsertion iterations at most (step 4b)
+constexpr int BB_RI_STEPS = 1 << 15;  // nodes one mover's search visits at most (the usual search: some tens)
 constexpr int BB_RI_LISTS = 512;     // heights the refit of step 4b follows (a binary tree deeper than that is reported, not emitted)
 #ifndef BB_CHILD_ORDER
 #define BB_CHILD_ORDER 0
@@ -558,7 +559,10 @@ __global__ __launch_bounds__(256) void bb_ri_search_kernel(RiArgs A) {
     uint32_t prev = x, pivot = p, pvl = pl, pvr = pr;
     Box3 pbox = bp;                   // the pivot's box as it is
     Box3 path; bool have_path = false;   // the box of the path's node below the pivot after the cut
-    for (;;) {
+    // (both walks are bounded whatever the links say: BB_RI_LISTS pivots, BB_RI_STEPS nodes searched per mover -- a tree that is one,
+    // as the ring guard keeps it, needs neither bound; a search cut short only finds a smaller gain)
+    uint32_t steps = 0;
+    for (uint32_t up = 0; up < (uint32_t)BB_RI_LISTS; ++up) {
       const uint32_t sib = pvl == prev ? pvr : pvl;
       Box3 bs; uint32_t sl, sr;
       ri_load(A.rec, sib, bs, sl, sr);
@@ -571,6 +575,7 @@ __global__ __launch_bounds__(256) void bb_ri_search_kernel(RiArgs A) {
           const float gain = d_rem - ind - direct;
           if (gain > best && !(pivot == p && node == sib)) { best = gain; best_out = node; }   // (next to its own sibling: where it is)
           const float ind2 = ind + direct - ri_area(bn);
+          if (++steps > (uint32_t)BB_RI_STEPS) break;
           if (nl != BB_NONE && d_rem - ind2 - a_in > best) {
             if (sp < BB_RI_STACK) { sn[sp] = nr; si[sp] = ind2; ++sp; }
             node = nl; ind = ind2;
@@ -643,8 +648,11 @@ __global__ __launch_bounds__(256) void bb_ri_resolve_kernel(RiArgs A, int pass) 
   bool w = A.win0[x] != 0;
   if (w) {
     const unsigned long long key = (b & 0xffffffff00000000ull) | x;
-    for (uint32_t a = A.parent[(uint32_t)b]; a != BB_NONE; a = A.parent[a])
+    uint32_t up = 0;
+    for (uint32_t a = A.parent[(uint32_t)b]; a != BB_NONE; a = A.parent[a]) {
       if (A.win0[a] && ((A.best[a] & 0xffffffff00000000ull) | a) > key) { w = false; break; }
+      if (++up > (uint32_t)BB_RI_LISTS) { w = false; break; }     // (deeper than the refit follows: such a tree is reported, not emitted)
+    }
   }
   A.win[x] = w ? 1 : 0;
 }
