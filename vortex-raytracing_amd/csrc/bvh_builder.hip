@@ -48,7 +48,7 @@ constexpr int BB_RI_MAX_ITERS = 32;  // reinsertion iterations at most (step 4b)
 constexpr int BB_RI_STEPS = 1 << 15;  // nodes one mover's search visits at most (the usual search: some tens)
 constexpr int BB_RI_LISTS = 512;     // heights the refit of step 4b follows (a binary tree deeper than that is reported, not emitted)
 #ifndef BB_CHILD_ORDER
-#define BB_CHILD_ORDER 0
+#define BB_CHILD_ORDER 3          // slots of a wide node: children by centre along the node's widest axis, ascending (see bb_collapse_kernel)
 #endif
 #ifndef BB_RI_ITERS
 #define BB_RI_ITERS 4
@@ -802,7 +802,7 @@ struct CollapseArgs {
   uint32_t level;
   const uint32_t* vals;     // sorted position -> primitive
   uint32_t* order;          // BLAS build: final position -> primitive (the gather's index); nullptr = TLAS build (a leaf names its instance)
-  uint32_t child_order;     // 0: slots as the binary tree hands them out, 1: largest surface area first, 2: smallest first
+  uint32_t child_order;     // 0: slots as the binary tree hands them out, 1: largest surface area first, 2: smallest first, 3 / 4: by centre along the parent's widest axis, ascending / descending
 };
 
 struct BRec { Box3 box; uint32_t left, right, count, plan; };
@@ -924,14 +924,22 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
       }
     }
     // slot order = the order in which the frame's occlusion rays visit the children (any-hit, rt_kernels.hip: slot order, no sorting by
-    // distance): largest surface area first (Nah & Manocha, "SATO: surface area traversal order for shadow ray tracing", 2014) -- the
-    // child most likely to hold an occluder is tried first.  Closest-hit rays sort by distance; for them the slot order only decides ties.
+    // distance); closest-hit rays sort by distance, for them the slot order only decides ties.  Default (3): by the child's centre along
+    // this node's widest axis, ascending -- the order a top-down builder's "left = below the plane" produces and csrc/scene_builder.cpp
+    // emits; clustering and reinsertion leave the two children of a binary node in no particular order.  Measured at three light
+    // positions against the order as built (profiles/r05_g_gpu_reinsertion.txt, section 8): occlusion rays' node fetches -7 % / +2 % / -17 %,
+    // the headline frame on the GPU-built tree 8.4 -> 9.0 Grays/s.  1 / 2: largest / smallest surface area first (Nah & Manocha's SATO
+    // and its opposite), 4: descending centre -- each wins at one light and loses at another; kept for measurements (VXRT_BVH_CHILD_ORDER).
     if (A.child_order != 0u) {
       float key[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float ar = box_area(cr[k].box.lx, cr[k].box.ly, cr[k].box.lz, cr[k].box.hx, cr[k].box.hy, cr[k].box.hz);
-        key[k] = (uint32_t)k < nc ? (A.child_order == 1u ? ar : -ar) : -__builtin_inff();
+        // 3 / 4: by the child's centre along the parent's widest axis, ascending / descending (what a top-down builder's "left = below the plane" gives)
+        const float ex = bx.hx - bx.lx, ey = bx.hy - bx.ly, ez = bx.hz - bx.lz;
+        const float cen = ex >= ey && ex >= ez ? cr[k].box.lx + cr[k].box.hx : (ey >= ez ? cr[k].box.ly + cr[k].box.hy : cr[k].box.lz + cr[k].box.hz);
+        const float kk = A.child_order == 1u ? ar : (A.child_order == 2u ? -ar : (A.child_order == 3u ? -cen : cen));
+        key[k] = (uint32_t)k < nc ? kk : -__builtin_inff();
       }
 #define BB_CSWAP(i, j) do { if (key[j] > key[i]) { const float tk = key[i]; key[i] = key[j]; key[j] = tk; const uint32_t tc = c[i]; c[i] = c[j]; c[j] = tc; \
         const uint32_t ts = slots[i]; slots[i] = slots[j]; slots[j] = ts; const BRec tr = cr[i]; cr[i] = cr[j]; cr[j] = tr; } } while (0)

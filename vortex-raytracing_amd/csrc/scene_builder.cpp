@@ -408,13 +408,22 @@ private:
         c[nc] = y.right; slots[nc] = j - ja;
         ++nc;
       }
-      // slot order = the order in which the frame's occlusion rays (any-hit, unordered: rt_kernels.hip) visit the children.
-      // kChildOrder 2: smallest surface area first -- a small box the ray enters is cheap to search and likely to hold an occluder
-      // (measured against as-built and largest-first: profiles/r05_g_child_order.txt); closest-hit rays sort by distance, for them
-      // the slot order decides ties only
+      // slot order = the order in which the frame's occlusion rays (any-hit, unordered: rt_kernels.hip) visit the children; closest-hit
+      // rays sort by distance, for them the slot order decides ties only.  Measurement knob (VXS_CHILD_ORDER; profiles/
+      // r05_g_gpu_reinsertion.txt sections 6 and 8): 1 / 2 largest / smallest surface area first, 3 / 4 by centre along this node's
+      // widest axis.  The default stays "as built" -- left = below the split plane, mostly what 3 makes exact: on this builder's tree
+      // 3 measured the same as 0 at two lights and 21 % fewer occlusion-ray node fetches at the third; the GPU builder, whose
+      // clustering leaves no such order, uses 3
       if (kChildOrder != 0 && width_ == 4) {
         float key[4];
-        for (uint32_t k = 0; k < nc; ++k) key[k] = kChildOrder == 1 ? -bn[c[k]].box.half_area() : bn[c[k]].box.half_area();
+        // 3 / 4: by the child's centre along this node's widest axis, ascending / descending
+        const V3 ext = x.box.hi - x.box.lo;
+        const int ax = ext.x >= ext.y && ext.x >= ext.z ? 0 : (ext.y >= ext.z ? 1 : 2);
+        for (uint32_t k = 0; k < nc; ++k) {
+          const Box& cb = bn[c[k]].box;
+          const float cen = ax == 0 ? cb.lo.x + cb.hi.x : (ax == 1 ? cb.lo.y + cb.hi.y : cb.lo.z + cb.hi.z);
+          key[k] = kChildOrder == 1 ? -cb.half_area() : (kChildOrder == 2 ? cb.half_area() : (kChildOrder == 3 ? cen : -cen));
+        }
         for (uint32_t i = 1; i < nc; ++i)        // (insertion sort, stable: equal areas keep the order the binary tree gave them)
           for (uint32_t j = i; j > 0 && key[j] < key[j - 1]; --j) { std::swap(key[j], key[j - 1]); std::swap(c[j], c[j - 1]); }
       }
