@@ -14,8 +14,9 @@
 //                                   one workgroup.  (Rounds 1-2: Karras' binary radix tree + a bottom-up box pass.)
 //   4b. the binary tree optimised by parallel reinsertion (round 5; Meister & Bittner 2018): four iterations of "every node looks for the
 //      place where it would cost least, the largest gains that do not touch each other's links are applied, boxes refitted bottom-up",
-//      the last refit recomputing the dynamic programme.  6.7 ms per million triangles in all against 1.5 ms without; the headline
-//      frame on the tree 8.4 Grays/s against 7.95 (the CPU builder's optimised tree: 8.8).  VXRT_BVH_REINSERT=0 switches it off.
+//      the last refit recomputing the dynamic programme.  6.3 ms per million triangles in all against 1.5 ms without; the headline
+//      frame on the tree 8.4 Grays/s against 7.95, 8.9 with the children of a wide node sorted along its widest axis (step 5; the CPU
+//      builder's optimised tree: 8.8).  VXRT_BVH_REINSERT=0 switches it off.
 //   5. collapse to 4-wide + quantise + emit, level by level, following the dynamic programme's choices; every child gets its
 //      range of the final triangle order from its parent; a subtree marked as a leaf (<= leaf_max triangles, and cheaper as
 //      a leaf) lists its triangles there.  Children are allocated after their parent, which is what vxrt_accel_build's
