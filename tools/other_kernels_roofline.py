@@ -35,7 +35,8 @@ for f in pmcs:
         k = short(r["Kernel_Name"])
         if k:
             cnt[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-JOBS = {"0": "frame, primary rays", "1": "frame, primary + occlusion rays", "2": "ray buffer (vxrt_trace, AO rays)", "3": "frame, primary + one diffuse bounce in the lane"}
+JOBS = {"0": "frame, primary rays", "1": "frame, primary + occlusion rays", "2": "ray buffer (vxrt_trace)", "3": "frame, primary + one diffuse bounce in the lane",
+        "4": "ray buffer of any-hit rays in slot order (AO rays, a bounce level's occlusion rays)"}
 print("peak = 1024 SIMDs x %.2f GHz / 2 = %.1f G wave64 VALU instructions/s" % (clock, 1024 * clock / 2))
 for k in sorted(dur):
     c = cnt.get(k)

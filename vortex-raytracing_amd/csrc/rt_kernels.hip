@@ -543,7 +543,11 @@ __device__ __forceinline__ void ao_sample_ray(uint32_t x, uint32_t y, uint32_t W
 #define RT_TOP_MAX 1024
 static_assert(RT_TOP_NODES <= RT_TOP_MAX, "top-of-tree image");
 
-enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2, JOB_RENDER_GI = 3 };
+// JOB_TRACE_UNORDERED: a ray buffer of any-hit rays whose caller only wants "blocked or not" (ambient occlusion, the occlusion rays of a
+// bounce level): JOB_TRACE's kernel with the children visited in slot order, as the frame's occlusion rays are (no sorting by distance,
+// no path maxima).  vxrt_trace's VXRT_MODE_ANY returns the reference's FIRST accepted candidate and keeps JOB_TRACE.
+enum { JOB_RENDER = 0, JOB_RENDER_SHADOW = 1, JOB_TRACE = 2, JOB_RENDER_GI = 3, JOB_TRACE_UNORDERED = 4 };
+__host__ __device__ constexpr bool is_trace_job(int job) { return job == JOB_TRACE || job == JOB_TRACE_UNORDERED; }
 // JOB_RENDER_GI: the whole "one diffuse bounce" frame (BASELINE configs[2] as worded; recipe: oracle/rt_oracle.c:orc_render_gi) in ONE
 // persistent launch -- a lane traces its pixel's primary ray, shades the hit (closest.cpp's else arm), draws the pixel's bounce ray
 // (ao_sample_ray, sample 0 of 1), traces it for its closest hit in the same lane, shades that hit and writes the pixel:
@@ -673,12 +677,12 @@ __device__ __forceinline__ bool is_work_desc(uint32_t d) { return d < DESC_IDLE;
 // scratch is sized for that instead of for the reference's 32 levels: 344 instead of 768 bytes per lane for the 8-wavefront instantiation.
 // (The 1,048,576-triangle atrium is 13 levels deep, the 10 M-triangle hairball 15.)  Timed builds only; deeper scenes take the full-size form.
 template <int JOB, int STATS, bool LDEXP, bool EXACT, bool PACKED = false, bool SHALLOW = false>
-__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JOB_TRACE ? RT_WAVES_TRACE : (JOB == JOB_RENDER_GI ? RT_WAVES_GI : (PACKED ? RT_WAVES_RENDER_PACKED : RT_WAVES_RENDER)))) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
+__global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (is_trace_job(JOB) ? RT_WAVES_TRACE : (JOB == JOB_RENDER_GI ? RT_WAVES_GI : (PACKED ? RT_WAVES_RENDER_PACKED : RT_WAVES_RENDER)))) void rt_persistent_kernel(SceneDev sc, ShadeParams p, PersistArgs A) {
   // stack levels in LDS: what the instantiation's occupancy leaves room for (160 KB per CU)
-  constexpr int LSTK = EXACT ? LDS_STACK : (JOB == JOB_TRACE ? RT_LDS_STACK_TRACE : (JOB == JOB_RENDER_GI ? RT_LDS_STACK_GI : (PACKED ? RT_LDS_STACK_RENDER_PACKED : RT_LDS_STACK_RENDER)));
+  constexpr int LSTK = EXACT ? LDS_STACK : (is_trace_job(JOB) ? RT_LDS_STACK_TRACE : (JOB == JOB_RENDER_GI ? RT_LDS_STACK_GI : (PACKED ? RT_LDS_STACK_RENDER_PACKED : RT_LDS_STACK_RENDER)));
   constexpr int WG_WAVES = EXACT ? 4 : RT_WG_WAVES;
   constexpr bool USE_TOP = RT_TOP_NODES > 0 && !EXACT && !LDEXP;   // (the ldexp decode reads exponents from the reference node by index)
-  constexpr uint32_t DEAD_MAX = JOB == JOB_TRACE ? RT_TRACE_DEAD_MAX : (JOB == JOB_RENDER_GI ? RT_GI_DEAD_MAX : RT_DEAD_MAX);
+  constexpr uint32_t DEAD_MAX = is_trace_job(JOB) ? RT_TRACE_DEAD_MAX : (JOB == JOB_RENDER_GI ? RT_GI_DEAD_MAX : RT_DEAD_MAX);
   // render-with-shadow jobs: retire finished primary rays (their lanes continue with the occlusion ray
   // of the same pixel - same traversal code, so no phase mixing) before the whole tile is done
   constexpr uint32_t FINISH_MIN = JOB == JOB_RENDER_SHADOW ? RT_SHADOW_FINISH_MIN : 65u;
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   // 0-2 active dir, 3-4 hit bx/by (bz = 1 - bx - by is re-derived when the record is written), 5 distance of the pixel's
   // primary hit while its occlusion ray is traced, 6 hit blasIdx, 7 hit triIdx, 8 blasIdx
   // (ray buffers have no "primary hit kept while the occlusion ray runs": slot 5 is dropped there, 8 slots + 7 stack levels fit 7 workgroups per CU)
-  constexpr int NCTX = (!EXACT && JOB == JOB_TRACE) ? 8 : 9;
+  constexpr int NCTX = (!EXACT && is_trace_job(JOB)) ? 8 : 9;
   __shared__ uint32_t s_ctx[WG_WAVES][NCTX][64];
   __shared__ uint32_t s_dry;      // bit s: a wavefront of this workgroup found queue shard s handed out
   if (threadIdx.x == 0) s_dry = 0u;
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   // top of the tree staged in LDS (north_star: "BVH nodes staged through LDS"): the first levels are what every ray of every
   // tile walks, and a ds_read_b128 does not queue behind the CU's vector-memory pipeline
   __shared__ uint4 s_top[USE_TOP ? 4 : 1][USE_TOP ? RT_TOP_NODES : 1];
-  constexpr bool TRI_LDS = RT_TRI_LDS > 0 && !EXACT && JOB != JOB_TRACE;
+  constexpr bool TRI_LDS = RT_TRI_LDS > 0 && !EXACT && !is_trace_job(JOB);
   __shared__ float4 s_tri[TRI_LDS ? WG_WAVES : 1][TRI_LDS ? 3 * RT_TRI_LDS : 1];
   const uint32_t n_top = USE_TOP ? min(sc.n_top, (uint32_t)RT_TOP_NODES) : 0u;
   if (USE_TOP && n_top) {
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
   // the lane's world-space ray, re-derived from its job (deterministic: same bits every time)
   auto world_ray = [&](float& ox, float& oy, float& oz, float& dx, float& dy, float& dz, float& tmax_) {
     tmax_ = RT_LARGE_FLOAT;
-    if (JOB == JOB_TRACE) {
+    if (is_trace_job(JOB)) {
       const float* rp = A.rays + (size_t)job * 6;
       if (RT_TRACE_NT) {   // (a ray is read once, by one lane: streamed past the caches that hold the tree)
         ox = __builtin_nontemporal_load(rp); oy = __builtin_nontemporal_load(rp + 1); oz = __builtin_nontemporal_load(rp + 2);
@@ -850,7 +854,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     if (!EXACT && !safe) {
       // camera rays with a zero direction component are known before the launch (u == 0 or v == 0): the
       // host lists them and a concurrent EXACT launch traces them; everything else is deferred
-      if (JOB != JOB_TRACE && !(flags & F_SHADOW)) cur = DESC_IDLE; else defer(false);
+      if (!is_trace_job(JOB) && !(flags & F_SHADOW)) cur = DESC_IDLE; else defer(false);
       return;
     }
     hitd = tmax_ > RT_LARGE_FLOAT ? RT_LARGE_FLOAT : tmax_;   // (a bound above 1e30 is 1e30: a missed box reports 1e30, rt_traversal.cpp:338, and must stay filtered by `d < hit.dist`)
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     // RT_CHUNK jobs); lanes then draw from the wavefront's private range.
     {
       const unsigned long long idle = __ballot(cur == DESC_IDLE);
-      if (!queue_empty && idle != 0ull && (JOB == JOB_TRACE || FINISH_MIN > 64u || idle == ~0ull || RT_DEAD_MAX < 64)) {
+      if (!queue_empty && idle != 0ull && (is_trace_job(JOB) || FINISH_MIN > 64u || idle == ~0ull || RT_DEAD_MAX < 64)) {
         const uint32_t wl_tries0 = tries; const unsigned long long wl_tpoll0 = (STATS && A.wave_log) ? __builtin_readcyclecounter() : 0ull;
         if (loc_next == loc_end) {   // wave-uniform: reserve the next chunk, stealing from other shards when the home shard is dry
           // shards a wavefront of this WORKGROUP has found handed out (LDS: no memory traffic): not polled again by its other three.  Every
@@ -942,7 +946,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             if (!in_range) { ++tries; continue; }
             const uint32_t s_n = min(per_shard, n_jobs - s_lo);
             uint32_t base = 0;
-            constexpr uint32_t CHUNK = (JOB == JOB_TRACE && !EXACT) ? (uint32_t)RT_TRACE_CHUNK : (uint32_t)RT_CHUNK;
+            constexpr uint32_t CHUNK = (is_trace_job(JOB) && !EXACT) ? (uint32_t)RT_TRACE_CHUNK : (uint32_t)RT_CHUNK;
             if (lane == 0) base = atomicAdd(A.queue + sid * QUEUE_STRIDE, CHUNK);
             base = __shfl(base, 0);
             if (base < s_n) {
@@ -960,7 +964,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           if (STATS && A.wave_log && !USE_TOP && tries != wl_tries0 && lane == 0) wl_no23 += (unsigned)(__builtin_readcyclecounter() - wl_tpoll0);   // (diagnostic: shader clocks of the reservations that met a dry shard)
         }
         uint32_t avail = loc_end - loc_next;
-        if (JOB != JOB_TRACE && !EXACT) {
+        if (!is_trace_job(JOB) && !EXACT) {
           avail = min(avail, 64u - (loc_next & 63u));     // lanes draw from ONE tile at a time (a reservation may span several)
           if (avail != 0u && (A.tile_order || A.tile_cost)) {
             // the tile these jobs belong to: queue position -> tile through the order of the launch; its cost is taken from here to the next tile's start
@@ -987,14 +991,14 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
           if (rank < avail) {
             job = loc_next + rank + loc_off;
             flags = 0;
-            if (!EXACT && JOB == JOB_TRACE && A.order) job = A.order[job];
+            if (!EXACT && is_trace_job(JOB) && A.order) job = A.order[job];
             if (EXACT) {
               const uint32_t wd = A.defer_list[job];
               job = wd & 0x7fffffffu;
               if (wd >> 31) { flags = F_SHADOW | F_RESUMED; if (JOB == JOB_RENDER_SHADOW) CTX(5) = __float_as_uint(hit_slot()->dist); }
             }
             float ox, oy, oz, dx, dy, dz, tm;
-            if (JOB == JOB_TRACE) {
+            if (is_trace_job(JOB)) {
               world_ray(ox, oy, oz, dx, dy, dz, tm);
               start_ray(ox, oy, oz, dx, dy, dz, tm, A.any_hit != 0);
             } else {
@@ -1011,7 +1015,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
       }
       if (__ballot(cur != DESC_IDLE) == 0ull) {
         if (queue_empty && loc_next == loc_end) {
-          if (JOB != JOB_TRACE && !EXACT && A.tile_cost && lane == 0 && lpt_tile != 0xFFFFFFFFu) {
+          if (!is_trace_job(JOB) && !EXACT && A.tile_cost && lane == 0 && lpt_tile != 0xFFFFFFFFu) {
             A.tile_cost[lpt_tile] = lpt_work;
             if (STATS && A.wave_log) A.tile_cost[2u * (A.total >> 6) + lpt_tile] = (uint32_t)min(wall_clock64() - lpt_t0, 0xFFFFFFFFull);
           }
@@ -1026,7 +1030,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     // ================= traverse: one step of whatever each lane holds, per iteration =================
     for (;;) {
       RT_MARK("loop_top");
-      if (JOB != JOB_TRACE && !EXACT) ++lpt_work;   // (wave-uniform: one scalar add per iteration)
+      if (!is_trace_job(JOB) && !EXACT) ++lpt_work;   // (wave-uniform: one scalar add per iteration)
       if (STATS && A.wave_log) {
         const unsigned long long nm = __ballot(is_node_desc(cur));
         ++wl_iter;
@@ -1068,7 +1072,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
         if (STATS) fx.node++;
         Cand c[4];
         eval_children<EXACT, LDEXP>(q0, q1, q2, q3, ref_node, arx, ary, arz, aix, aiy, aiz, hitd, c);
-        if (JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION && STATS != 1 && __all((flags & F_ANYHIT) != 0u)) {   // STATS keeps the reference's order, hence its fetch counts
+        if (((JOB == JOB_RENDER_SHADOW && RT_UNORDERED_OCCLUSION) || JOB == JOB_TRACE_UNORDERED) && STATS != 1 && __all((flags & F_ANYHIT) != 0u)) {   // STATS keeps the reference's order, hence its fetch counts
           // occlusion rays of a frame only feed a boolean (is anything hit before the light?): the set
           // of triangles an any-hit traversal can reach does not depend on the visiting order, so the
           // ordering network and the path_m bookkeeping are skipped (vxrt_trace's MODE_ANY, which
@@ -1162,10 +1166,10 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
       // body then runs for many lanes at once instead of once per iteration for a few
       RT_MARK("leaf");
       const unsigned long long leafm = __ballot(is_leaf_desc(cur));
-      if (leafm != 0ull && ((uint32_t)__popcll(leafm) >= (JOB == JOB_TRACE ? RT_TRACE_LEAF_MIN : RT_LEAF_MIN) || __ballot(is_node_desc(cur) || is_inst_desc(cur)) == 0ull)) {
+      if (leafm != 0ull && ((uint32_t)__popcll(leafm) >= (is_trace_job(JOB) ? RT_TRACE_LEAF_MIN : RT_LEAF_MIN) || __ballot(is_node_desc(cur) || is_inst_desc(cur)) == 0ull)) {
         // ---- BLAS leaf (:123-161): triangles in index order, strict '<' ----
         if (STATS && A.wave_log) { ++wl_leaf_x; wl_leaf_l += (unsigned)__popcll(leafm); }
-        if (JOB != JOB_TRACE && !EXACT) lpt_work += 2u;   // (a leaf-body run costs about 2.5 node-body runs: tools/wave_balance.py)
+        if (!is_trace_job(JOB) && !EXACT) lpt_work += 2u;   // (a leaf-body run costs about 2.5 node-body runs: tools/wave_balance.py)
         {
           // triangles through LDS (RT_TRI_LDS): the lanes of a tile reach the same leaves, and every one of them loads the leaf's
           // triangles for itself.  The leaf of the first leaf lane is loaded ONCE, by 3 lanes per triangle, and handed to the lanes
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
             bool stop = false;
             // ray buffers (incoherent rays, latency-bound leaves): the next triangle's 48 bytes are requested before the
             // current one is tested, +3 %; camera tiles lose 1.5 % to the extra registers, so they load in place
-            constexpr bool PREFETCH = JOB == JOB_TRACE && RT_TRI_PREFETCH;
+            constexpr bool PREFETCH = is_trace_job(JOB) && RT_TRI_PREFETCH;
             float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
             if (PREFETCH) { const float4* tp0 = sc.tri_w + (size_t)leftFirst * 3; n0 = tp0[0]; n1 = tp0[1]; n2 = tp0[2]; }
             for (uint32_t i = 0; i < triCount; ++i) {
@@ -1250,7 +1254,7 @@ __global__ __launch_bounds__(EXACT ? 256 : RT_WG_THREADS, EXACT ? 4 : (JOB == JO
     if (cur == DESC_DONE) {
       const bool found = (flags & F_FOUND) != 0u;
       HitRec h; h.dist = RT_LARGE_FLOAT; h.bx = 0; h.by = 0; h.bz = 0; h.blasIdx = 0; h.triIdx = 0;
-      if (JOB == JOB_TRACE) {
+      if (is_trace_job(JOB)) {
         if (found) {
           h.dist = hitd; h.bx = __uint_as_float(CTX(3)); h.by = __uint_as_float(CTX(4)); h.bz = 1 - h.bx - h.by;   // rt_traversal.cpp:311-313
           h.blasIdx = CTX(6); h.triIdx = CTX(7);
@@ -3149,6 +3153,8 @@ static int ensure_defer(FrameCtx* c, uint64_t jobs, hipStream_t s) {
   return 0;
 }
 
+// internal mode of trace_on_ctx: any-hit rays whose hit records are only read as "blocked or not" (JOB_TRACE_UNORDERED)
+constexpr int MODE_ANY_UNORDERED = 0x100;
 // ray buffer -> hit records on frame context c (the body of vxrt_trace; also the bounce levels of vxrt_render)
 static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_t n, const float* tmax,
                         HitRec* hits, int mode, hipStream_t s, const uint32_t* n_dev = nullptr,
@@ -3156,7 +3162,8 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   uint32_t* st = status_word();
   if (!st) return -1;
   PersistArgs A{};
-  A.total = (uint32_t)n; A.hits = hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY;
+  const bool unordered = mode == MODE_ANY_UNORDERED;
+  A.total = (uint32_t)n; A.hits = hits; A.rays = rays; A.tmax = tmax; A.any_hit = mode == VXRT_MODE_ANY || unordered;
   A.total_dev = n_dev;
   A.end_log = a->end_log;
   A.order = order;
@@ -3206,9 +3213,17 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
 #undef LAUNCH_POOL
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
-#define LAUNCH_T(ST, LD, SH) do { \
-    hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, false, false, SH>), dim3(persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, false, false, SH>, n)), dim3(RT_WG_THREADS), 0, s, a->dev, p, A); \
+#define LAUNCH_TJ(J, ST, LD, SH) do { \
+    hipLaunchKernelGGL((rt_persistent_kernel<J, ST, LD, false, false, SH>), dim3(persistent_grid(rt_persistent_kernel<J, ST, LD, false, false, SH>, n)), dim3(RT_WG_THREADS), 0, s, a->dev, p, A); \
     hipLaunchKernelGGL((rt_persistent_kernel<JOB_TRACE, ST, LD, true>), dim3(std::max<uint32_t>(EXACT_GRID, persistent_grid(rt_persistent_kernel<JOB_TRACE, ST, LD, true>, n / 8, 256))), dim3(256), 0, s, a->dev, p, X); } while (0)
+#define LAUNCH_T(ST, LD, SH) LAUNCH_TJ(JOB_TRACE, ST, LD, SH)
+  // any-hit rays whose caller only wants "blocked or not": children in slot order (the EXACT launch keeps the ordered form: a boolean either way)
+  static const bool unordered_off = [] { const char* e = getenv("VXRT_UNORDERED_ANY"); return e && atoi(e) == 0; }();
+  if (unordered && !unordered_off && !stats_counters) {
+    if (a->shallow) { if (a->dev.exact_decode) LAUNCH_TJ(JOB_TRACE_UNORDERED, 0, true, true); else LAUNCH_TJ(JOB_TRACE_UNORDERED, 0, false, true); }
+    else            { if (a->dev.exact_decode) LAUNCH_TJ(JOB_TRACE_UNORDERED, 0, true, false); else LAUNCH_TJ(JOB_TRACE_UNORDERED, 0, false, false); }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   // (the EXACT launch's grid grows with the ray buffer -- a workgroup per 2,048 rays, up to the machine: how many rays were deferred
   // is known on the device only, and a buffer of axis-parallel rays defers all of them; with nothing deferred its wavefronts find
   // every shard empty without an atomic and exit)
@@ -3216,6 +3231,7 @@ static int trace_on_ctx(vxrt_accel_t* a, FrameCtx* c, const float* rays, uint64_
   else if (a->shallow) { if (a->dev.exact_decode) LAUNCH_T(0, true, true); else LAUNCH_T(0, false, true); }
   else                 { if (a->dev.exact_decode) LAUNCH_T(0, true, false); else LAUNCH_T(0, false, false); }
 #undef LAUNCH_T
+#undef LAUNCH_TJ
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -3275,7 +3291,7 @@ static int render_bounce_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p
     const dim3 grid((n + 255u) / 256u);
     if (shadow) {
       hipLaunchKernelGGL(rt_bounce_shadow_rays_kernel, grid, block, 0, s, p, n, (const float*)L.rays, (const HitRec*)L.hits, L.srays, L.stmax, rays_traced);
-      if (trace_on_ctx(a, c, L.srays, n, L.stmax, L.shits, VXRT_MODE_ANY, s) != 0) return -1;
+      if (trace_on_ctx(a, c, L.srays, n, L.stmax, L.shits, MODE_ANY_UNORDERED, s) != 0) return -1;
     }
     if (c->lv.size() < (size_t)k + 2) c->lv.resize((size_t)k + 2);
     FrameCtx::Level& Nx = c->lv[k + 1];
@@ -3357,7 +3373,7 @@ static int render_ao_tail(vxrt_accel_t* a, FrameCtx* c, const ShadeParams& p, ui
     const uint32_t k = std::min(ns, ao->spp - s0);
     hipLaunchKernelGGL(rt_ao_rays_kernel, rgrid, block, 0, s, ray_cap, width, y0, utab, vtab, (const float4*)c->ao_geo, (const float4*)c->ao_nrm,
                        (const uint32_t*)c->ao_list, c->ao_hdr, ao->spp, s0, k, ao->seed, ao->radius, c->ao_rays, c->ao_tmax);
-    if (trace_on_ctx(a, c, c->ao_rays, n * k, c->ao_tmax, c->ao_hits, VXRT_MODE_ANY, s, c->ao_hdr + 1, nullptr, bin_rays(k)) != 0) return -1;
+    if (trace_on_ctx(a, c, c->ao_rays, n * k, c->ao_tmax, c->ao_hits, MODE_ANY_UNORDERED, s, c->ao_hdr + 1, nullptr, bin_rays(k)) != 0) return -1;
     hipLaunchKernelGGL(rt_ao_accumulate_kernel, rgrid, block, 0, s, ray_cap, (const uint32_t*)c->ao_list, (const uint32_t*)c->ao_hdr, k,
                        (const HitRec*)c->ao_hits, c->ao_cnt);
   }
