@@ -803,6 +803,7 @@ struct CollapseArgs {
   uint32_t level;
   const uint32_t* vals;     // sorted position -> primitive
   uint32_t* order;          // BLAS build: final position -> primitive (the gather's index); nullptr = TLAS build (a leaf names its instance)
+  uint32_t* chunk_tot; uint2* chunk_base;   // per chunk of 256 items of the level: (children | internal children << 16); (first node slot, first queue position)
   uint32_t child_order;     // 0: slots as the binary tree hands them out, 1: largest surface area first, 2: smallest first, 3 / 4: by centre along the parent's widest axis, ascending / descending
 };
 
@@ -858,11 +859,17 @@ __device__ __forceinline__ void bb_emit_leaf(const CollapseArgs& A, uint32_t b, 
 // triangle order (its own range, cut up in slot order), writes its own record and the records of the children that are leaves
 // (two thirds of all nodes: as items of their own they would idle through the internal nodes' work in the same wavefront), and
 // queues the others for the next level.
+//
+// The slots are handed out by PREFIX SUMS in queue order, not by atomics (round 5: with one atomic per workgroup the records' order
+// differed from build to build; the tree did not): a level is three launches -- COUNT (this kernel without its writes: the children
+// and internal children of every chunk of 256 items), bb_collapse_scan_kernel (one workgroup: the chunks' bases, the level's totals),
+// and this kernel again.  Two builds of the same triangles give the same bytes.
+template <bool COUNT>
 __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
   const uint32_t n_items = A.counters[8 + A.level];
   const uint32_t lane = threadIdx.x & 63u;
-  // (every lane of a wavefront runs every iteration: node slots and queue positions are handed out per wavefront, one atomic
-  // each, from a prefix sum over its lanes -- per item they would be 600,000 atomics on one address per level)
+  // (every lane of a wavefront runs every iteration: node slots and queue positions come from prefix sums over the wavefront's lanes,
+  // the workgroup's wavefronts and -- through the scan kernel -- the level's chunks)
   for (uint32_t base = blockIdx.x * blockDim.x; base < n_items; base += gridDim.x * blockDim.x) {
     const uint32_t it = base + threadIdx.x;
     bool act = it < n_items;
@@ -871,8 +878,10 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
     const BRec me = bb_load_rec(A.rec, b);
     const Box3 bx = me.box;
     if (act && (me.plan & PLAN_LEAF) != 0u) {   // only the root can arrive here as a leaf (a mesh of a few triangles)
-      bb_emit_leaf(A, b, me, out, start);
-      atomicAdd(A.counters + 1, 1u); atomicMax(A.counters + 2, me.count);
+      if (!COUNT) {
+        bb_emit_leaf(A, b, me, out, start);
+        atomicAdd(A.counters + 1, 1u); atomicMax(A.counters + 2, me.count);
+      }
       act = false;
     }
     // (all arrays below are indexed with compile-time constants only -- unrolled loops, selects on k == pick -- so that they
@@ -931,7 +940,7 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
     // positions against the order as built (profiles/r05_g_gpu_reinsertion.txt, section 8): occlusion rays' node fetches -7 % / +2 % / -17 %,
     // the headline frame on the GPU-built tree 8.4 -> 9.0 Grays/s.  1 / 2: largest / smallest surface area first (Nah & Manocha's SATO
     // and its opposite), 4: descending centre -- each wins at one light and loses at another; kept for measurements (VXRT_BVH_CHILD_ORDER).
-    if (A.child_order != 0u) {
+    if (!COUNT && A.child_order != 0u) {
       float key[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -956,16 +965,17 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += t; }
     const uint32_t total = __shfl(incl, 63);
-    // ... and one pair of atomics per WORKGROUP (same-address atomics from every wavefront of a level are what the level waits for)
+    // ... the workgroup's chunk of 256 items: its totals out (COUNT), its bases in (from the scan over the chunks)
     __shared__ uint32_t s_tot[4], s_base[2];
     const uint32_t wv = threadIdx.x >> 6;
     if (lane == 0) s_tot[wv] = total;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t bt = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-      s_base[0] = (bt & 0xffffu) ? atomicAdd(A.counters + 0, bt & 0xffffu) : 0u;
-      s_base[1] = (bt >> 16) ? atomicAdd(A.counters + 8 + A.level + 1, bt >> 16) : 0u;
+    if (COUNT) {
+      if (threadIdx.x == 0) A.chunk_tot[base >> 8] = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];   // (children | internal children << 16: at most 1,024 each)
+      __syncthreads();
+      continue;
     }
+    if (threadIdx.x == 0) { const uint2 cb = A.chunk_base[base >> 8]; s_base[0] = cb.x; s_base[1] = cb.y; }
     __syncthreads();
     uint32_t woff = 0;
     for (uint32_t k = 0; k < wv; ++k) woff += s_tot[k];
@@ -1035,6 +1045,37 @@ __global__ __launch_bounds__(256) void bb_collapse_kernel(CollapseArgs A) {
       }
     }
   }
+}
+
+// the chunks' bases of a level: node slots from the nodes allocated so far, queue positions from 0; the level's totals into the counters
+__global__ __launch_bounds__(1024) void bb_collapse_scan_kernel(CollapseArgs A) {
+  const uint32_t n_items = A.counters[8 + A.level];
+  const uint32_t n_chunks = (n_items + 255u) >> 8;
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  __shared__ uint32_t s_w[16][2], s_carry[2];
+  if (threadIdx.x == 0) { s_carry[0] = A.counters[0]; s_carry[1] = 0u; }
+  __syncthreads();
+  for (uint32_t t0 = 0; t0 < n_chunks; t0 += 1024u) {
+    const uint32_t c = t0 + threadIdx.x;
+    const uint32_t v = c < n_chunks ? A.chunk_tot[c] : 0u;
+    const uint32_t a = v & 0xffffu, b = v >> 16;
+    uint32_t ia = a, ib = b;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t ta = __shfl_up(ia, off), tb = __shfl_up(ib, off);
+      if (lane >= (uint32_t)off) { ia += ta; ib += tb; }
+    }
+    if (lane == 63u) { s_w[wv][0] = ia; s_w[wv][1] = ib; }
+    __syncthreads();
+    uint32_t wa = 0, wb = 0, ta = 0, tb = 0;
+    for (uint32_t k = 0; k < 16u; ++k) { if (k < wv) { wa += s_w[k][0]; wb += s_w[k][1]; } ta += s_w[k][0]; tb += s_w[k][1]; }
+    const uint32_t ca = s_carry[0], cb = s_carry[1];
+    if (c < n_chunks) A.chunk_base[c] = make_uint2(ca + wa + ia - a, cb + wb + ib - b);
+    __syncthreads();
+    if (threadIdx.x == 0) { s_carry[0] = ca + ta; s_carry[1] = cb + tb; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { A.counters[0] = s_carry[0]; A.counters[8 + A.level + 1] = s_carry[1]; }
 }
 
 // ---- 6. gather into the final order ----
@@ -1197,6 +1238,7 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
   A.nodes = (uint32_t*)d_nodes; A.counters = counters; A.vals = vals1; A.order = boxes ? nullptr : order;
   static const uint32_t child_order_env = [] { const char* e = getenv("VXRT_BVH_CHILD_ORDER"); return e ? (uint32_t)atoi(e) : (uint32_t)BB_CHILD_ORDER; }();
   A.child_order = child_order_env;
+  A.chunk_tot = (uint32_t*)tile_counts; A.chunk_base = tile_base;   // (the clustering's per-tile arrays are free now: one entry per 256 items, at most n items per level)
   const uint32_t cwide = blocks < 1024u ? blocks : 1024u;
   uint32_t L = 0;
   for (;;) {
@@ -1206,7 +1248,9 @@ static int build_common(void* d_tri, void* d_triEx, uint32_t n_tris, uint32_t tr
       // (level L holds at most 4^L items)
       uint32_t g = cwide;
       if (L < 8) { const uint32_t items = 1u << (2 * L); g = (items + 255u) / 256u < cwide ? (items + 255u) / 256u : cwide; }
-      hipLaunchKernelGGL(bb_collapse_kernel, dim3(g), dim3(256), 0, s, A);
+      hipLaunchKernelGGL(bb_collapse_kernel<true>, dim3(g), dim3(256), 0, s, A);
+      hipLaunchKernelGGL(bb_collapse_scan_kernel, dim3(1), dim3(1024), 0, s, A);
+      hipLaunchKernelGGL(bb_collapse_kernel<false>, dim3(g), dim3(256), 0, s, A);
     }
     if (L >= (uint32_t)BB_MAX_LEVELS) break;
     if (hipMemcpyAsync(sc.pinned, counters + 8 + L, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
