@@ -248,7 +248,8 @@ h2, st2 = po.trace_canonical(out[1], rays)
 # and with them the same fetch counts and hit records for every ray)
 same = (np.array_equal(out[0]["bvh"], out[1]["bvh"]) and np.array_equal(out[0]["tri"], out[1]["tri"]) and np.array_equal(out[0]["triEx"], out[1]["triEx"])
         and st["node_reads"] == st2["node_reads"] and st["tri_reads"] == st2["tri_reads"] and h.tobytes() == h2.tobytes())
-print(json.dumps({"bytes": 52 * st["node_reads"] + 36 * st["tri_reads"], "dist_sum": float(h["dist"][h["dist"] < 1e29].astype(np.float64).sum()), "hits": int((h["dist"] < 1e29).sum()),
+import hashlib
+print(json.dumps({"sha": hashlib.sha256(out[0]["bvh"].tobytes() + out[0]["tri"].tobytes()).hexdigest()[:16], "bytes": 52 * st["node_reads"] + 36 * st["tri_reads"], "dist_sum": float(h["dist"][h["dist"] < 1e29].astype(np.float64).sum()), "hits": int((h["dist"] < 1e29).sum()),
                   "same_twice": bool(same)}))
 """
 
@@ -262,12 +263,13 @@ def test_reinsertion_lowers_the_trees_cost_and_is_deterministic(vrt, gpu_device)
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for setting in ("0", "4", "12:3"):
+    for setting in ("0", "4", "12:3", "4 "):        # ("4 ": the default schedule again, in another process: the same bytes)
         r = subprocess.run([sys.executable, "-c", _COST_CHILD % root], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, VXRT_BVH_REINSERT=setting))
         assert r.returncode == 0, (setting, r.stdout[-2000:], r.stderr[-2000:])
         res[setting] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert res[setting]["same_twice"], setting
     print({k: v["bytes"] for k, v in res.items()})
+    assert res["4"]["sha"] == res["4 "]["sha"] and res["4"]["sha"] != res["0"]["sha"]
     assert res["4"]["hits"] == res["0"]["hits"] == res["12:3"]["hits"] and res["4"]["dist_sum"] == res["0"]["dist_sum"] == res["12:3"]["dist_sum"]
     assert res["4"]["bytes"] < 0.97 * res["0"]["bytes"]
     assert res["12:3"]["bytes"] < 0.97 * res["0"]["bytes"]
