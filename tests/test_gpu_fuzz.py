@@ -2,6 +2,8 @@
 random rotations, non-uniform scales and translations; camera rays, random rays, rays with zero direction components (the EXACT
 path) and rays starting inside the geometry; closest hit, first accepted hit, and occlusion with a per-ray bound.  The HIP
 traversal must return the oracle's hit records bit for bit -- on the tree the CPU builder makes and on the tree built on the GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -46,7 +48,7 @@ def _rays(rng, po, lo, hi):
     return np.concatenate([cam, rnd, inside, axis]).astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VXRT_FUZZ_SEEDS", "6"))))     # (VXRT_FUZZ_SEEDS=n: a soak run over n seeds)
 @pytest.mark.parametrize("builder", ["cpu", "gpu"])
 def test_random_scenes_and_rays(vrt, po, gpu_device, seed, builder):
     rng = np.random.default_rng(1000 + seed)
@@ -69,7 +71,8 @@ def test_random_scenes_and_rays(vrt, po, gpu_device, seed, builder):
     got = gpu_trace(vrt, ds, rays)
     want, _ = po.trace_canonical(sc, rays)
     assert np.array_equal(_bits(got), _bits(want)), "closest hit"
-    assert (got["dist"] < 1e29).sum() > 100
+    if seed < 6:      # (the committed seeds were picked to hit something; a soak run's need not)
+        assert (got["dist"] < 1e29).sum() > 100
     got_any = gpu_trace(vrt, ds, rays, mode=1)
     want_any, _ = po.trace_canonical(sc, rays, any_hit=True)
     assert np.array_equal(_bits(got_any), _bits(want_any)), "first accepted hit"
@@ -77,11 +80,12 @@ def test_random_scenes_and_rays(vrt, po, gpu_device, seed, builder):
     got_t = gpu_trace(vrt, ds, rays, mode=1, tmax=tmax)
     want_t, _ = po.trace_canonical(sc, rays, tmax=tmax, any_hit=True)
     assert np.array_equal(_bits(got_t), _bits(want_t)), "bounded occlusion rays"
-    assert 0 < (got_t["dist"] < 1e29).sum() < (got_any["dist"] < 1e29).sum()
+    if seed < 6:
+        assert 0 < (got_t["dist"] < 1e29).sum() < (got_any["dist"] < 1e29).sum()
     ds.close()
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VXRT_FUZZ_SEEDS", "4"))))
 def test_random_scenes_frames_with_shadow(vrt, po, gpu_device, seed):
     """The frame path on the same kind of scenes: pixels, hit records and the occluded set against the oracle, single frames and a
     batch of three with different lights."""
@@ -107,7 +111,7 @@ def test_random_scenes_frames_with_shadow(vrt, po, gpu_device, seed):
     px, hits, col, nrays = gpu_render(vrt, ds, w, h, shadow=1, params=plist[0])
     want_px, want_hits, want_col, want_n = po.render_ex(sc, w, h, po.shade_params(light_pos=lights[0]), 1)
     assert np.array_equal(px, want_px) and np.array_equal(_bits(hits.reshape(-1)), _bits(want_hits.reshape(-1))) and nrays == want_n
-    assert (hits["dist"] < 1e29).mean() > 0.01
+    assert seed >= 4 or (hits["dist"] < 1e29).mean() > 0.01
     buf = torch.zeros((3, h, w), dtype=torch.int32, device=gpu_device)
     s = torch.cuda.current_stream().cuda_stream
     vrt.rtapi.render_batch(ds.accel, w, h, plist, buf.data_ptr(), w * h, 1, None, s)
@@ -119,7 +123,7 @@ def test_random_scenes_frames_with_shadow(vrt, po, gpu_device, seed):
     ds.close()
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VXRT_FUZZ_SEEDS", "4"))))
 def test_reference_quirks_mode_equals_the_faithful_restatement_on_random_deep_tlas_scenes(vrt, po, gpu_device, seed):
     """The opt-in quirks traversal (vxrt_trace_reference_quirks) against the oracle's FAITHFUL restatement -- the one pinned to the
     reference's object code -- on random scenes of 6-14 instances (a TLAS deeper than one level, where the stale base_ptr of
@@ -155,4 +159,4 @@ def test_reference_quirks_mode_equals_the_faithful_restatement_on_random_deep_tl
         stale += st["stale_base"]
     canon, _ = po.trace_canonical(sc, rays)
     want, _ = po.trace_faithful(img, rays)
-    assert stale > 0 and (_bits(canon).reshape(n, -1) != _bits(want).reshape(n, -1)).any(1).sum() > 0
+    assert seed >= 4 or (stale > 0 and (_bits(canon).reshape(n, -1) != _bits(want).reshape(n, -1)).any(1).sum() > 0)   # (the committed seeds make the quirk live)
