@@ -3,6 +3,7 @@ tests/regression/raytracing/bvh.cpp:30-264).  A builder's tree shape is its own 
 (bvh.cpp:79-86) -- so, as for csrc/scene_builder.cpp, parity is: the structural invariants of the format, every ray finding
 the brute-force distance, and agreement with the SAH tree built on the CPU from the same triangles.  The tree is then consumed
 by the same accel build and traversal kernels, whose results are compared with the oracle ON THAT TREE bit for bit."""
+import os
 import time
 
 import numpy as np
@@ -275,16 +276,19 @@ def test_reinsertion_lowers_the_trees_cost_and_is_deterministic(vrt, gpu_device)
     assert res["12:3"]["bytes"] < 0.97 * res["0"]["bytes"]
 
 
+@pytest.mark.parametrize("rep", range(int(os.environ.get("VXRT_SOUP_REPS", "1"))))     # (VXRT_SOUP_REPS=k: a soak run, k soups per size and kind)
 @pytest.mark.parametrize("n", [16, 17, 31, 64, 513, 5000, 60000])
 @pytest.mark.parametrize("kind", ["cloud", "clusters", "slivers", "nested"])
-def test_random_soups_through_the_reinsertion_step(vrt, po, gpu_device, n, kind):
+def test_random_soups_through_the_reinsertion_step(vrt, po, gpu_device, n, kind, rep):
     """Step 4b (parallel reinsertion) on triangle soups made to provoke it -- uniform clouds (everything overlaps everything), tight clusters
     with copies of the same triangle (equal gains: ties decided by node id), long slivers across the scene (nodes that want to move far),
     shells nested in shells (subtrees that would rather be inside each other: the ring guard): the tree must keep the format's invariants
     (every triangle in exactly one leaf, box chains contain their triangles, children after parents -- a ring cut off from the root would
     lose triangles and fail the refit: vxrt_bvh_build returns -2) and lose no hit against brute force.  n = 16 is the smallest mesh the
     step runs on; 17 / 31 / 513 leave ragged lists."""
-    rng = np.random.default_rng(n * 7 + len(kind))
+    if rep and n > 600:
+        pytest.skip("soak runs repeat the small sizes")
+    rng = np.random.default_rng(n * 7 + len(kind) + 1000003 * rep)
     if kind == "cloud":
         c = rng.uniform(-80, 80, size=(n, 1, 3))
         tri = c + rng.uniform(-30, 30, size=(n, 3, 3))
