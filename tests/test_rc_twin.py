@@ -339,3 +339,29 @@ def test_hip_twin_on_a_chain_like_tree(vrt, po, gpu_device, k, wide):
     np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), want)
     assert len(np.unique(want)) > 3
     ds.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VXRT_FUZZ_SEEDS", "4"))))     # (VXRT_FUZZ_SEEDS=n: a soak run over n seeds)
+def test_hip_twin_on_random_package_built_scenes(vrt, po, gpu_device, seed):
+    """The twin's kernel against the restatement of render.h on scenes the package builds in the twin's formats: 1-4 instances of a blob
+    of 80-1,280 triangles with random reflectivities, random light, 1-3 bounces, 1-2 samples -- pixels equal, colours to 1e-5."""
+    import torch
+    rng = np.random.default_rng(31000 + seed)
+    copies = int(rng.integers(1, 5))
+    sc = vrt.scene.rc_procedural("blob", int(rng.integers(2, 5)), 0, int(rng.integers(1, 1000)), copies=copies,
+                                 reflectivity=[float(r) for r in rng.choice([0.0, 0.0, 0.3, 0.6], size=copies)])
+    w, h = int(rng.choice([64, 136, 200])), int(rng.choice([40, 61, 120]))
+    cam = vrt.scene.rc_camera_like_rtu(w, h)
+    light = (float(rng.uniform(-200, 400)), float(rng.uniform(100, 500)), float(rng.uniform(-200, 200)), 1, 1, 1, 0.3, 0.3, 0.3, 0.4, 0.35, 0.25)
+    depth, spp = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    opx, ocol = po.rc_render(po.rc_args(sc, w, h, cam, light, spp, depth))
+    ds = vrt.tracer.RcDeviceScene(sc, gpu_device)
+    px = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
+    col = torch.zeros(h * w * 3, dtype=torch.float32, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    vrt.rtapi.rc_render(ds.c, w, h, 0, h, vrt.rtapi.rc_params(cam, light, spp, depth), px.data_ptr(), col.data_ptr(), s)
+    assert vrt.rtapi.status(s) == 0
+    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), opx)
+    np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3), ocol, rtol=1e-5)
+    ds.close() if hasattr(ds, "close") else None
