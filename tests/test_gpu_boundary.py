@@ -475,3 +475,36 @@ def test_host_program_on_two_shares(vrt, po, gpu_device, tmp_path):
     rpx, _, _ = po.render(vrt.scene.procedural("cornell"), 48, 40)
     want = np.stack([(rpx >> 16) & 255, (rpx >> 8) & 255, rpx & 255], -1)[::-1]
     assert np.array_equal(vals, want)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VXRT_FUZZ_SEEDS", "4"))))     # (VXRT_FUZZ_SEEDS=n: a soak run over n seeds)
+def test_random_frames_through_the_vx_boundary(vrt, po, gpu_device, seed):
+    """The drop-in call sequence on random inputs: frame sizes from 1x1 to 300x200 (ragged last tile rows and columns, frames smaller
+    than a tile, framebuffers at and below the 4 KB lazy-upload size), shadow rays on or off, 1-3 samples per pixel, random light, an
+    optional row window, an optional cleared framebuffer before the run, two runs on the same device -- every pixel against the oracle,
+    MINSTRET against the oracle's ray count times the samples, rows outside a window untouched."""
+    rng = np.random.default_rng(52000 + seed)
+    sc = vrt.scene.procedural(*[("blob", 3, 0, 2), ("cornell", 0, 0, 1), ("atrium", 3, 0, 3)][int(rng.integers(0, 3))])
+    w = int(rng.choice([1, 7, 8, 9, 31, 32, 33, 64, 100, 136, 300]))
+    h = int(rng.choice([1, 5, 8, 9, 17, 32, 61, 64, 120, 200]))
+    spp = int(rng.integers(1, 4))
+    shadow = bool(rng.integers(0, 2))
+    tr = vrt.tracer.Tracer(w, h, samples_per_pixel=spp)
+    tr.init(sc)
+    for run in range(2):
+        light = (float(rng.uniform(-100, 500)), float(rng.uniform(50, 500)), float(rng.uniform(-200, 200)))
+        window = None
+        if h >= 16 and rng.integers(0, 3) == 0:
+            y0 = int(rng.integers(0, h // 8)) * 8
+            window = (y0, int(rng.integers(y0 + 1, h + 1)))
+        fill = int(rng.integers(0, 256))
+        tr.bufs["out"].write(np.full(w * h * 4, fill, np.uint8))
+        tr.setup(light_pos=light, row_window=window, shadow=shadow)
+        got = tr.run()
+        y0, y1 = window if window else (0, h)
+        want, _, _, nrays = po.render_ex(sc, w, h, po.shade_params(light_pos=light), shadow=int(shadow), y0=y0, y1=y1)
+        assert np.array_equal(got[y0:y1], want[y0:y1]), (seed, run, w, h, spp, shadow, window)
+        keep = np.uint32(fill * 0x01010101)
+        assert (got[:y0] == keep).all() and (got[y1:] == keep).all(), (seed, run, "rows outside the window")
+        assert tr.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0) == spp * nrays, (seed, run, w, h, spp, shadow, window)
+    tr.close()
