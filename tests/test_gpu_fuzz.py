@@ -160,3 +160,52 @@ def test_reference_quirks_mode_equals_the_faithful_restatement_on_random_deep_tl
     canon, _ = po.trace_canonical(sc, rays)
     want, _ = po.trace_faithful(img, rays)
     assert seed >= 4 or (stale > 0 and (_bits(canon).reshape(n, -1) != _bits(want).reshape(n, -1)).any(1).sum() > 0)   # (the committed seeds make the quirk live)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VXRT_FUZZ_SEEDS", "3"))))
+def test_random_secondary_ray_passes(vrt, po, gpu_device, seed):
+    """The passes built on ray buffers, on random inputs: ambient occlusion (whose any-hit rays take the slot-order traversal since round 5),
+    the one-launch diffuse bounce, and the mirror bounce with the shadow extension at every level (a bounce level's occlusion rays take the
+    slot-order traversal too) -- mirror hall with random reflectivities, random frame size, light, samples, radius, seed, depth; counts,
+    ray totals and pixels equal the oracle's, colours within the colour tolerance."""
+    import torch
+    from scenes import mirror_hall
+    from test_gpu_parity import gpu_render, COLOR_RTOL
+    rng = np.random.default_rng(64000 + seed)
+    b = mirror_hall(vrt, float(rng.choice([0.0, 0.4, 0.7])), float(rng.choice([0.0, 0.5])))
+    ds = vrt.tracer.DeviceScene(b, gpu_device)
+    w, h = int(rng.choice([40, 72, 144, 200])), int(rng.choice([24, 61, 88, 120]))
+    light = (float(rng.uniform(50, 350)), float(rng.uniform(120, 400)), float(rng.uniform(-200, 200)))
+    p = vrt.rtapi.default_shade_params()
+    p.light_pos[:] = light
+    px = torch.zeros((h, w), dtype=torch.int32, device=gpu_device)
+    col = torch.zeros(h * w * 3, dtype=torch.float32, device=gpu_device)
+    cnt = torch.full((h, w), -1, dtype=torch.int32, device=gpu_device)
+    nr = torch.zeros(1, dtype=torch.int64, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    # ambient occlusion
+    spp, radius, sd = int(rng.choice([1, 3, 8, 16])), float(rng.uniform(5, 120)), int(rng.integers(1, 1 << 30))
+    vrt.rtapi.render_ao(ds.accel, w, h, 0, h, p, spp, radius, px.data_ptr(), seed=sd, colors_ptr=col.data_ptr(), unoccluded_ptr=cnt.data_ptr(), rays_ptr=nr.data_ptr(), stream=s)
+    assert vrt.rtapi.status(s) == 0
+    rpx, rcol, rcnt, rn = po.render_ao(b, w, h, po.shade_params(light_pos=light), spp=spp, radius=radius, seed=sd)
+    np.testing.assert_array_equal(cnt.cpu().numpy().view(np.uint32), rcnt)
+    assert int(nr.item()) == rn
+    np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3), rcol, rtol=COLOR_RTOL)
+    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), rpx)
+    # one diffuse bounce
+    nr.zero_()
+    vrt.rtapi.render_diffuse_bounce(ds.accel, w, h, 0, h, p, px.data_ptr(), seed=sd, colors_ptr=col.data_ptr(), rays_ptr=nr.data_ptr(), stream=s)
+    assert vrt.rtapi.status(s) == 0
+    rpx, rcol, rn = po.render_gi(b, w, h, po.shade_params(light_pos=light), seed=sd)
+    assert int(nr.item()) == rn
+    np.testing.assert_allclose(col.cpu().numpy().reshape(h, w, 3), rcol, rtol=COLOR_RTOL)
+    np.testing.assert_array_equal(px.cpu().numpy().view(np.uint32), rpx)
+    # mirror bounce, occlusion rays at every level
+    depth, shadow = int(rng.integers(1, 6)), int(rng.integers(0, 2))
+    p.max_depth = depth
+    gpx, ghits, gcol, nrays = gpu_render(vrt, ds, w, h, shadow=shadow, params=p)
+    rpx, rhits, rcol, rn = po.render_ex(b, w, h, po.shade_params(light_pos=light, max_depth=depth), shadow)
+    assert np.array_equal(_bits(ghits), _bits(rhits)) and nrays == rn
+    np.testing.assert_allclose(gcol, rcol, rtol=COLOR_RTOL)
+    np.testing.assert_array_equal(gpx, rpx)
+    ds.close()
