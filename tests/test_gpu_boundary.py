@@ -508,3 +508,37 @@ def test_random_frames_through_the_vx_boundary(vrt, po, gpu_device, seed):
         assert (got[:y0] == keep).all() and (got[y1:] == keep).all(), (seed, run, "rows outside the window")
         assert tr.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0) == spp * nrays, (seed, run, w, h, spp, shadow, window)
     tr.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VXRT_FUZZ_SEEDS", "3"))))
+def test_random_frames_on_several_shares(vrt, po, gpu_device, monkeypatch, seed):
+    """VORTEX_HIP_DEVICES on random inputs: 2-5 shares (the one-GPU box lists device 0 repeatedly), gathered by peer copies or through RCCL
+    (every third seed), frame sizes with ragged last tile rows, fewer tile rows than shares (the run then stays on the first device), shadow
+    rays, samples per pixel -- pixels and MINSTRET as on one device."""
+    rng = np.random.default_rng(77000 + seed)
+    sc = vrt.scene.procedural(*[("blob", 3, 0, 2), ("cornell", 0, 0, 1)][int(rng.integers(0, 2))])
+    n = int(rng.integers(2, 6))
+    w = int(rng.choice([8, 33, 64, 136, 200]))
+    h = int(rng.choice([8, 17, 32, 61, 64, 120]))
+    spp, shadow = int(rng.integers(1, 3)), bool(rng.integers(0, 2))
+    monkeypatch.setenv("VORTEX_HIP_DEVICES", ",".join(["0"] * n))
+    if seed % 3 == 2:
+        monkeypatch.setenv("VORTEX_HIP_GATHER", "rccl")
+    tr = vrt.tracer.Tracer(w, h, samples_per_pixel=spp)
+    tr.init(sc)
+    monkeypatch.delenv("VORTEX_HIP_DEVICES")
+    monkeypatch.delenv("VORTEX_HIP_GATHER", raising=False)
+    assert tr.dev.hip_stat(3) == n
+    for run in range(2):
+        light = (float(rng.uniform(-100, 500)), float(rng.uniform(50, 500)), float(rng.uniform(-200, 200)))
+        tr.bufs["out"].write(np.full(w * h * 4, 0xA5, np.uint8))
+        tr.setup(light_pos=light, shadow=shadow)
+        got = tr.run()
+        want, _, _, nrays = po.render_ex(sc, w, h, po.shade_params(light_pos=light), shadow=int(shadow))
+        assert np.array_equal(got, want), (seed, run, n, w, h, spp, shadow)
+        assert tr.dev.mpm_query(vrt.runtime.VX_CSR_MINSTRET, 0) == spp * nrays
+    split = (h + 7) // 8 >= n
+    assert tr.dev.hip_stat(2) == (2 if split else 0)
+    if seed % 3 == 2:
+        assert tr.dev.hip_stat(7) == (2 if split else 0)
+    tr.close()
