@@ -35,5 +35,20 @@ for rep in range(2):
         run(40)
         torch.cuda.synchronize()
         ms = (time.time() - t0) / 200 * 1e3
-        print(json.dumps({"tree": which, "ms_per_frame_pipelined": round(ms, 4), "mrays_s": round(rays / ms / 1e3, 1)}), flush=True)
+        # random rays (origins in the scene's box, directions on the sphere), closest hit, 8 Mi
+        g = torch.Generator(device="cuda:0"); g.manual_seed(12345)
+        nrr = 8 << 20
+        lo = torch.tensor(sc.bounds[:3], device="cuda:0"); hi = torch.tensor(sc.bounds[3:], device="cuda:0")
+        o = lo + (hi - lo) * torch.rand((nrr, 3), device="cuda:0", generator=g)
+        d = torch.randn((nrr, 3), device="cuda:0", generator=g); d = d / d.norm(dim=1, keepdim=True)
+        rr = torch.cat([o, d], 1).contiguous()
+        hits = torch.zeros((nrr, 6), dtype=torch.int32, device="cuda:0")
+        s0 = streams[0].cuda_stream
+        rt.trace(ds.accel, rr.data_ptr(), nrr, hits.data_ptr(), rt.MODE_CLOSEST, None, s0); torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(5): rt.trace(ds.accel, rr.data_ptr(), nrr, hits.data_ptr(), rt.MODE_CLOSEST, None, s0)
+        torch.cuda.synchronize()
+        ms_rr = (time.time() - t0) / 5 * 1e3
+        print(json.dumps({"tree": which, "ms_per_frame_pipelined": round(ms, 4), "mrays_s": round(rays / ms / 1e3, 1), "random_rays_mrays_s": round(nrr / ms_rr / 1e3, 1)}), flush=True)
+        del rr, hits, o, d
         ds.close()
